@@ -1,0 +1,195 @@
+/* include/kd_hip.h -- C ABI of libkd_hip.so: the MI355X (gfx950) token-passing
+ * WFST search that replaces kaldi-decoder's CPU hot path.
+ *
+ * Plain C, opaque handles, caller-owned buffers, int status codes; no C++,
+ * torch or pybind11 types cross this boundary.  Every entry point names the
+ * reference interface it stands in for ("ref:" paths are relative to
+ * /root/reference/kaldi-decoder/).  A binding for the reference's own pybind11
+ * layer is shown in INTEGRATION.md.
+ *
+ * Threading: a kd_graph is immutable after creation and may be shared by any
+ * number of batches; a kd_batch is not re-entrant (ref: the decoders are
+ * single-threaded objects, csrc/faster-decoder.h:75-76).  All device work of a
+ * batch is enqueued on the HIP stream given at creation; calls that return
+ * results synchronise that stream.
+ *
+ * Errors: every function returns KD_OK (0) or a negative KD_E_* code;
+ * kd_last_error() returns a thread-local message (ref: KALDI_DECODER_ASSERT/ERR
+ * throw std::runtime_error, csrc/log.h:46-51,86-89 -- the host wrapper turns a
+ * non-zero status back into that exception).
+ */
+#ifndef KD_HIP_H_
+#define KD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KD_OK 0
+#define KD_E_INVALID -1    /* bad argument / failed reference-style assertion */
+#define KD_E_HIP -2        /* a HIP runtime call failed (no GPU, OOM, ...)     */
+#define KD_E_STATE -3      /* call order violated (AdvanceDecoding before Init) */
+#define KD_E_CAPACITY -4   /* token arena / table / frame index exhausted      */
+
+/* bits of kd_batch_status()[i] */
+#define KD_UTT_ARENA_FULL 1u
+#define KD_UTT_TABLE_FULL 2u
+#define KD_UTT_FRAMES_FULL 4u
+
+typedef struct kd_graph kd_graph;
+typedef struct kd_batch kd_batch;
+
+const char *kd_last_error(void);
+
+/* Number of visible HIP devices (0 when there is no GPU or no driver). */
+int kd_device_count(void);
+
+/* ---- decoding graph -------------------------------------------------------
+ * Replaces the borrowed `const fst::Fst<fst::StdArc>&` the reference decoders
+ * hold (ref: csrc/faster-decoder.h:179, csrc/lattice-simple-decoder.h:298).
+ * Input is the FST as CSR in its own arc order: arcs of state s are
+ * [row_ptr[s], row_ptr[s+1]); ilabel 0 is epsilon; final_cost[s] = +inf means
+ * Weight::Zero() (not final).  The arrays are copied; the device copy is laid
+ * out as 16-byte state records and 16-byte arcs with every state's emitting
+ * arcs first (stable), and lives until kd_graph_destroy.
+ */
+int kd_graph_create(int device, int32_t num_states, int32_t start,
+                    const int32_t *row_ptr, const int32_t *ilabel,
+                    const int32_t *olabel, const float *weight,
+                    const int32_t *nextstate, const float *final_cost,
+                    kd_graph **out);
+void kd_graph_destroy(kd_graph *g);
+int32_t kd_graph_num_states(const kd_graph *g);
+int64_t kd_graph_num_arcs(const kd_graph *g);
+size_t kd_graph_device_bytes(const kd_graph *g);
+
+/* ---- options ----------------------------------------------------------------
+ * The five search fields are FasterDecoderOptions (ref: csrc/faster-decoder.h:24-49,
+ * same defaults via kd_faster_options_default).  hash_ratio is validated as the
+ * reference does (>= 1.0) and otherwise unused: the HashList is replaced by a
+ * fixed-capacity open-addressed table.  The remaining fields size device
+ * memory; 0 picks a default.
+ */
+typedef struct kd_faster_options {
+  float beam;
+  int32_t max_active;
+  int32_t min_active;
+  float beam_delta;
+  float hash_ratio;
+  /* capacity knobs (not in the reference) */
+  int64_t arena_tokens;  /* back-pointer records shared by the whole batch      */
+  int32_t table_slots;   /* per-utterance spill table, power of two             */
+  int32_t max_frames;    /* frames an utterance can be advanced over            */
+} kd_faster_options;
+
+void kd_faster_options_default(kd_faster_options *o);
+
+/* ---- a batch of independent FasterDecoder instances --------------------------
+ * One kd_batch is `max_batch` FasterDecoder objects over one graph (ref:
+ * FasterDecoder::FasterDecoder, csrc/faster-decoder.cc:21-32 -- same option
+ * assertions).  Utterances never interact; the batch only exists so one kernel
+ * launch advances all of them.  `stream` is a hipStream_t (NULL = default).
+ */
+int kd_batch_create(const kd_graph *g, const kd_faster_options *opts,
+                    int32_t max_batch, void *stream, kd_batch **out);
+void kd_batch_destroy(kd_batch *b);
+
+/* FasterDecoder::SetOptions (ref: csrc/faster-decoder.h:78): search fields only. */
+int kd_batch_set_options(kd_batch *b, const kd_faster_options *opts);
+
+/* FasterDecoder::InitDecoding for utterances [0, batch) (ref:
+ * csrc/faster-decoder.cc:42-56): start token, epsilon closure with cutoff
+ * FLT_MAX, num_frames_decoded = 0. */
+int kd_batch_init_decoding(kd_batch *b, int32_t batch);
+
+/* Memory kind of the log-likelihood pointers handed to kd_batch_advance. */
+#define KD_MEM_HOST 0
+#define KD_MEM_DEVICE 1
+
+/* FasterDecoder::AdvanceDecoding over a DecodableCtc per utterance (ref:
+ * csrc/faster-decoder.cc:126-152, csrc/decodable-ctc.cc:22-38).
+ *   loglikes[i]   row-major [num_rows[i], num_cols] float log-probs, row stride
+ *                 `row_stride` floats; LogLikelihood(frame, index) =
+ *                 loglikes[i][(frame - offset[i]) * row_stride + index - 1]
+ *   offset[i]     DecodableCtc's `offset` (frame index of row 0); may be NULL (0)
+ *   max_num_frames as in the reference (-1: all frames ready)
+ * NumFramesReady = offset + num_rows must be >= frames already decoded.
+ * Host pointers are staged to the device first; device pointers are read in
+ * place and must stay valid until the call returns.
+ */
+int kd_batch_advance(kd_batch *b, const float *const *loglikes,
+                     const int32_t *num_rows, const int32_t *offset,
+                     int32_t num_cols, int64_t row_stride, int mem_kind,
+                     int32_t max_num_frames);
+
+/* As kd_batch_advance but only enqueues the search kernel on the batch's
+ * stream (device pointers only, no synchronisation, no status read-back);
+ * pair with kd_batch_sync.  This is the call timed by bench.py. */
+int kd_batch_advance_async(kd_batch *b, const float *const *loglikes_dev,
+                           const int32_t *num_rows, const int32_t *offset,
+                           int32_t num_cols, int64_t row_stride,
+                           int32_t max_num_frames);
+int kd_batch_sync(kd_batch *b);
+
+/* FasterDecoder::NumFramesDecoded per utterance (ref: csrc/faster-decoder.h:104). */
+int kd_batch_num_frames_decoded(kd_batch *b, int32_t *out);
+
+/* Per-utterance KD_UTT_* bits; non-zero means that utterance stopped early. */
+int kd_batch_status(kd_batch *b, uint32_t *out);
+
+/* FasterDecoder::ReachedFinal per utterance (ref: csrc/faster-decoder.cc:347-354). */
+int kd_batch_reached_final(kd_batch *b, int32_t *out);
+
+/* FasterDecoder::GetBestPath (ref: csrc/faster-decoder.cc:356-424), two steps:
+ * kd_batch_best_path_prepare runs the traceback on the device and returns the
+ * number of arcs of each utterance's path (-1: no token survived, GetBestPath
+ * would return false); kd_batch_best_path_copy writes utterance i's arcs at
+ * [path_offset[i], path_offset[i] + len[i]) of the caller's arrays, in path
+ * order: the linear LatticeArc FST before RemoveEpsLocal (that function lives
+ * in kaldifst, not in the reference tree).  final_weight[2*i..] is the
+ * LatticeWeight set on the last state: (Final(state), 0) when a final state was
+ * reached and use_final_probs, else One() = (0, 0).
+ */
+int kd_batch_best_path_prepare(kd_batch *b, int32_t use_final_probs,
+                               int32_t *path_len);
+int kd_batch_best_path_copy(kd_batch *b, const int64_t *path_offset,
+                            int32_t *ilabel, int32_t *olabel, int32_t *state,
+                            float *graph_cost, float *ac_cost,
+                            float *final_weight);
+
+/* Frontier of one utterance after `frame_plus_one` frames (0 = after
+ * InitDecoding): the tokens the reference keeps in toks_ with cost below the
+ * frame's cutoff, sorted by state.  Pass cap = 0 to query the count. */
+int kd_batch_frame_tokens(kd_batch *b, int32_t utt, int32_t frame_plus_one,
+                          int32_t cap, int32_t *count, int32_t *state,
+                          double *cost);
+
+/* Search counters summed over frames, per utterance: KD_NUM_STATS int64 each. */
+enum {
+  KD_STAT_FRAMES = 0,
+  KD_STAT_TOKENS_IN,        /* tokens entering ProcessEmitting                 */
+  KD_STAT_TOKENS_EXPANDED,  /* of those, cost < weight_cutoff                  */
+  KD_STAT_ARCS_SCANNED,     /* emitting arcs read                              */
+  KD_STAT_ARCS_KEPT,        /* of those, below the running cutoff              */
+  KD_STAT_TOKENS_OUT,       /* tokens written (after closure)                  */
+  KD_STAT_EPS_ARCS_SCANNED, /* epsilon arcs read in ProcessNonemitting         */
+  KD_STAT_EPS_EXPANSIONS,   /* token expansions in ProcessNonemitting          */
+  KD_STAT_MAX_TOKENS,       /* max tokens written in one frame                 */
+  KD_STAT_SPILL_FRAMES,     /* frames that fell back to the global table       */
+  KD_NUM_STATS
+};
+int kd_batch_stats(kd_batch *b, int64_t *out /* [batch][KD_NUM_STATS] */);
+
+/* Device time of the most recent search-kernel launch, from HIP events on the
+ * batch's stream (valid after a sync). */
+int kd_batch_last_kernel_ms(kd_batch *b, float *ms);
+
+size_t kd_batch_device_bytes(const kd_batch *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KD_HIP_H_ */

@@ -1,0 +1,147 @@
+// kaldi-decoder_amd/csrc/kd_device.h -- device-side data layout shared by the
+// search kernel, the traceback kernels and the host C-ABI implementation.
+//
+// HBM layout (DESIGN.md "Data layout"):
+//   graph    StateRec[S] (16 B)  + ArcRec[A] (16 B), arcs of a state contiguous,
+//            emitting arcs first (stable) so the emitting and epsilon passes
+//            each read one contiguous, 16-byte-aligned range per token.
+//   arena    append-only back-pointer records of the whole batch as four
+//            parallel arrays (state, cost, prev, arc); one contiguous block per
+//            (utterance, frame), allocated with a single atomicAdd.
+//   frames   frame_base/frame_count[utt][frame_plus_one] index the blocks.
+#ifndef KD_DEVICE_H_
+#define KD_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kd {
+
+struct __attribute__((aligned(16))) StateRec {
+  int32_t arc_begin;  // first (emitting) arc
+  int32_t emit_end;   // one past the last emitting arc == first epsilon arc
+  int32_t arc_end;    // one past the last arc
+  float final_cost;   // +inf == not final
+};
+
+struct __attribute__((aligned(16))) ArcRec {
+  int32_t ilabel;
+  int32_t olabel;
+  float weight;
+  uint32_t next;  // bits 0..30 next state, bit 31: that state has epsilon arcs
+};
+
+constexpr uint32_t kStateMask = 0x7FFFFFFFu;
+constexpr uint32_t kHasEps = 0x80000000u;
+constexpr uint32_t kKeyEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kArcNone = 0xFFFFFFFFu;
+constexpr uint32_t kSrcEps = 0x80000000u;  // back-pointer source is a table slot
+constexpr uint32_t kSrcNone = 0xFFFFFFFFu;
+constexpr unsigned long long kCostDead = 0xFFFFFFFFFFFFFFFFull;
+
+struct UttDesc {
+  const float *ll;     // row 0 of this utterance's log-likelihood matrix
+  int32_t num_rows;
+  int32_t offset;      // frame index of row 0 (DecodableCtc offset)
+  int32_t target;      // decode until frames_decoded == target
+  int32_t pad;
+};
+
+struct SearchParams {
+  // graph
+  const StateRec *states;
+  const ArcRec *arcs;
+  int32_t start;
+  // FasterDecoderOptions
+  float beam;
+  int32_t max_active;
+  int32_t min_active;
+  float beam_delta;
+  // arena
+  int32_t *tok_state;
+  double *tok_cost;
+  int32_t *tok_prev;
+  int32_t *tok_arc;
+  unsigned long long arena_cap;
+  unsigned long long *arena_top;
+  // frame index, per utterance [max_frames + 1]
+  long long *frame_base;
+  int32_t *frame_count;
+  int32_t max_frames;
+  // per-utterance state
+  int32_t *frames_decoded;
+  uint32_t *status;
+  long long *stats;  // [batch][KD_NUM_STATS]
+  // per-utterance spill table (global memory) and scratch, g_slots entries each
+  uint32_t *g_key;
+  unsigned long long *g_cost;
+  uint32_t *g_arc;
+  uint32_t *g_src;   // also the back-pointer source array of the LDS table
+  uint32_t *g_idx;
+  uint32_t *g_used;
+  uint32_t *g_wl;    // two worklists per utterance
+  int32_t g_log2_slots;
+  // input
+  const UttDesc *utt;
+  int32_t num_cols;
+  long long row_stride;
+  int32_t do_init;   // 1: run InitDecoding instead of advancing
+};
+
+struct PathParams {
+  const StateRec *states;
+  const ArcRec *arcs;
+  const int32_t *tok_state;
+  const double *tok_cost;
+  const int32_t *tok_prev;
+  const int32_t *tok_arc;
+  const long long *frame_base;
+  const int32_t *frame_count;
+  int32_t max_frames;
+  const int32_t *frames_decoded;
+  int32_t use_final_probs;
+  int32_t batch;
+  // outputs of the prepare step
+  int32_t *reached_final;  // [batch]
+  long long *best_tok;     // [batch] arena index or -1
+  int32_t *path_len;       // [batch]
+  float *final_weight;     // [batch][2]
+  // fill step
+  const long long *path_offset;
+  int32_t *o_ilabel, *o_olabel, *o_state;
+  float *o_graph, *o_ac;
+};
+
+// Launchers implemented in kd_search.hip / kd_path.hip
+hipError_t LaunchSearch(const SearchParams &p, int batch, hipStream_t stream);
+size_t SearchLdsBytes();
+hipError_t LaunchPathPrepare(const PathParams &p, int batch, hipStream_t stream);
+hipError_t LaunchPathFill(const PathParams &p, int batch, hipStream_t stream);
+
+// Order-preserving map double -> uint64 (so integer atomicMin orders costs).
+__host__ __device__ inline unsigned long long CostKey(double d) {
+  unsigned long long b;
+  __builtin_memcpy(&b, &d, 8);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ inline double KeyCost(unsigned long long k) {
+  unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  double d;
+  __builtin_memcpy(&d, &b, 8);
+  return d;
+}
+__host__ __device__ inline uint32_t FloatKey(float f) {
+  uint32_t b;
+  __builtin_memcpy(&b, &f, 4);
+  return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float KeyFloat(uint32_t k) {
+  uint32_t b = (k >> 31) ? (k & 0x7FFFFFFFu) : ~k;
+  float f;
+  __builtin_memcpy(&f, &b, 4);
+  return f;
+}
+
+}  // namespace kd
+
+#endif  // KD_DEVICE_H_

@@ -1,0 +1,289 @@
+"""ctypes binding of libkd_hip.so, the C ABI declared in include/kd_hip.h.
+
+This is the "ctypes stub" form of the drop-in boundary: plain
+pointers and sizes in, plain arrays out.  It never falls back to a CPU
+implementation: if the library is missing or there is no GPU the calls raise.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkd_hip.so")
+
+INT_MAX = 2**31 - 1
+KD_MEM_HOST, KD_MEM_DEVICE = 0, 1
+STAT_NAMES = ("frames", "tokens_in", "tokens_expanded", "arcs_scanned", "arcs_kept",
+              "tokens_out", "eps_arcs_scanned", "eps_expansions", "max_tokens", "spill_frames")
+
+# every symbol include/kd_hip.h declares
+SYMBOLS = (
+    "kd_last_error", "kd_device_count", "kd_graph_create", "kd_graph_destroy",
+    "kd_graph_num_states", "kd_graph_num_arcs", "kd_graph_device_bytes",
+    "kd_faster_options_default", "kd_batch_create", "kd_batch_destroy",
+    "kd_batch_set_options", "kd_batch_init_decoding", "kd_batch_advance",
+    "kd_batch_advance_async", "kd_batch_sync", "kd_batch_num_frames_decoded",
+    "kd_batch_status", "kd_batch_reached_final", "kd_batch_best_path_prepare",
+    "kd_batch_best_path_copy", "kd_batch_frame_tokens", "kd_batch_stats",
+    "kd_batch_last_kernel_ms", "kd_batch_device_bytes",
+)
+
+
+class FasterOptions(C.Structure):
+    _fields_ = [("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32),
+                ("beam_delta", C.c_float), ("hash_ratio", C.c_float),
+                ("arena_tokens", C.c_int64), ("table_slots", C.c_int32),
+                ("max_frames", C.c_int32)]
+
+
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C kaldi-decoder_amd` "
+            "(or __graft_entry__.build()); there is no CPU fallback")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  Two HIP runtimes in
+    # one process cannot both own the GPU, so when torch is installed load it
+    # first: libkd_hip.so's DT_NEEDED libamdhip64.so.7 then binds to that copy.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    L.kd_last_error.restype = C.c_char_p
+    L.kd_graph_create.argtypes = [C.c_int, C.c_int32, C.c_int32, _i32p, _i32p, _i32p, _f32p,
+                                  _i32p, _f32p, C.POINTER(C.c_void_p)]
+    L.kd_graph_destroy.argtypes = [C.c_void_p]
+    L.kd_graph_destroy.restype = None
+    L.kd_graph_num_states.argtypes = [C.c_void_p]
+    L.kd_graph_num_arcs.argtypes = [C.c_void_p]
+    L.kd_graph_num_arcs.restype = C.c_int64
+    L.kd_graph_device_bytes.argtypes = [C.c_void_p]
+    L.kd_graph_device_bytes.restype = C.c_size_t
+    L.kd_faster_options_default.argtypes = [C.POINTER(FasterOptions)]
+    L.kd_faster_options_default.restype = None
+    L.kd_batch_create.argtypes = [C.c_void_p, C.POINTER(FasterOptions), C.c_int32, C.c_void_p,
+                                  C.POINTER(C.c_void_p)]
+    L.kd_batch_destroy.argtypes = [C.c_void_p]
+    L.kd_batch_destroy.restype = None
+    L.kd_batch_set_options.argtypes = [C.c_void_p, C.POINTER(FasterOptions)]
+    L.kd_batch_init_decoding.argtypes = [C.c_void_p, C.c_int32]
+    L.kd_batch_advance.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), _i32p, C.c_void_p,
+                                   C.c_int32, C.c_int64, C.c_int, C.c_int32]
+    L.kd_batch_advance_async.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), _i32p, C.c_void_p,
+                                         C.c_int32, C.c_int64, C.c_int32]
+    L.kd_batch_sync.argtypes = [C.c_void_p]
+    L.kd_batch_num_frames_decoded.argtypes = [C.c_void_p, _i32p]
+    L.kd_batch_status.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.uint32)]
+    L.kd_batch_reached_final.argtypes = [C.c_void_p, _i32p]
+    L.kd_batch_best_path_prepare.argtypes = [C.c_void_p, C.c_int32, _i32p]
+    L.kd_batch_best_path_copy.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int64), _i32p,
+                                          _i32p, _i32p, _f32p, _f32p, _f32p]
+    L.kd_batch_frame_tokens.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                        C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]
+    L.kd_batch_stats.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int64)]
+    L.kd_batch_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.kd_batch_device_bytes.argtypes = [C.c_void_p]
+    L.kd_batch_device_bytes.restype = C.c_size_t
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().kd_last_error().decode())
+
+
+def device_count():
+    return lib().kd_device_count()
+
+
+def default_options(**kw):
+    o = FasterOptions()
+    lib().kd_faster_options_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class Graph:
+    """Device copy of a decoding graph (kd_graph)."""
+
+    def __init__(self, g, device=0):
+        self.h = C.c_void_p()
+        arrs = [np.ascontiguousarray(g["row_ptr"], np.int32),
+                np.ascontiguousarray(g["ilabel"], np.int32),
+                np.ascontiguousarray(g["olabel"], np.int32),
+                np.ascontiguousarray(g["weight"], np.float32),
+                np.ascontiguousarray(g["nextstate"], np.int32),
+                np.ascontiguousarray(g["final"], np.float32)]
+        _check(lib().kd_graph_create(device, g["num_states"], g["start"], *arrs,
+                                     C.byref(self.h)))
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().kd_graph_destroy(self.h)
+            self.h = None
+
+    @property
+    def num_states(self):
+        return lib().kd_graph_num_states(self.h)
+
+    @property
+    def num_arcs(self):
+        return lib().kd_graph_num_arcs(self.h)
+
+    @property
+    def device_bytes(self):
+        return lib().kd_graph_device_bytes(self.h)
+
+
+class Path:
+    def __init__(self, ok, il, ol, st, gc, ac, fw):
+        self.ok = ok
+        self.ilabel, self.olabel, self.state = il, ol, st
+        self.graph_cost, self.ac_cost = gc, ac
+        self.final_weight = fw
+
+    @property
+    def isyms(self):
+        return self.ilabel[self.ilabel != 0]
+
+    @property
+    def osyms(self):
+        return self.olabel[self.olabel != 0]
+
+    @property
+    def total_cost(self):
+        return (float(self.graph_cost.astype(np.float64).sum() + self.final_weight[0]),
+                float(self.ac_cost.astype(np.float64).sum() + self.final_weight[1]))
+
+
+class Batch:
+    """`max_batch` independent FasterDecoder instances over one graph (kd_batch)."""
+
+    def __init__(self, graph: Graph, max_batch=1, stream=None, **opts):
+        self.graph = graph
+        self.max_batch = max_batch
+        self.opts = default_options(**opts)
+        self.h = C.c_void_p()
+        self.batch = 0
+        _check(lib().kd_batch_create(graph.h, C.byref(self.opts), max_batch,
+                                     C.c_void_p(stream or 0), C.byref(self.h)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().kd_batch_destroy(self.h)
+            self.h = None
+
+    def set_options(self, **opts):
+        for k, v in opts.items():
+            setattr(self.opts, k, v)
+        _check(lib().kd_batch_set_options(self.h, C.byref(self.opts)))
+
+    def init_decoding(self, batch=None):
+        self.batch = self.max_batch if batch is None else batch
+        _check(lib().kd_batch_init_decoding(self.h, self.batch))
+
+    def _ptrs(self, ptrs):
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        return arr
+
+    def advance_host(self, mats, offsets=None, max_num_frames=-1):
+        """mats: list of C-contiguous float32 [T_i, V] arrays (host)."""
+        assert len(mats) == self.batch
+        mats = [np.ascontiguousarray(m, np.float32) for m in mats]
+        V = mats[0].shape[1]
+        rows = np.asarray([m.shape[0] for m in mats], np.int32)
+        off = None if offsets is None else np.ascontiguousarray(offsets, np.int32)
+        _check(lib().kd_batch_advance(self.h, self._ptrs([m.ctypes.data for m in mats]), rows,
+                                      None if off is None else off.ctypes.data, V, V,
+                                      KD_MEM_HOST, max_num_frames))
+
+    def advance_device(self, dev_ptrs, num_rows, num_cols, row_stride=None, offsets=None,
+                       max_num_frames=-1, sync=True):
+        """dev_ptrs: device addresses (ints) of row-major [T_i, V] float32 matrices."""
+        rows = np.ascontiguousarray(num_rows, np.int32)
+        off = None if offsets is None else np.ascontiguousarray(offsets, np.int32)
+        stride = num_cols if row_stride is None else row_stride
+        fn = lib().kd_batch_advance if sync else lib().kd_batch_advance_async
+        args = [self.h, self._ptrs(list(dev_ptrs)), rows,
+                None if off is None else off.ctypes.data, num_cols, stride]
+        if sync:
+            args.append(KD_MEM_DEVICE)
+        args.append(max_num_frames)
+        _check(fn(*args))
+
+    def sync(self):
+        _check(lib().kd_batch_sync(self.h))
+
+    def num_frames_decoded(self):
+        out = np.zeros(self.batch, np.int32)
+        _check(lib().kd_batch_num_frames_decoded(self.h, out))
+        return out
+
+    def status(self):
+        out = np.zeros(self.batch, np.uint32)
+        _check(lib().kd_batch_status(self.h, out))
+        return out
+
+    def reached_final(self):
+        out = np.zeros(self.batch, np.int32)
+        _check(lib().kd_batch_reached_final(self.h, out))
+        return out.astype(bool)
+
+    def best_paths(self, use_final_probs=True):
+        lens = np.zeros(self.batch, np.int32)
+        _check(lib().kd_batch_best_path_prepare(self.h, int(use_final_probs), lens))
+        n = np.maximum(lens, 0).astype(np.int64)
+        offs = np.zeros(self.batch, np.int64)
+        offs[1:] = np.cumsum(n)[:-1]
+        tot = max(int(n.sum()), 1)
+        il, ol, st = (np.zeros(tot, np.int32) for _ in range(3))
+        gc, ac = np.zeros(tot, np.float32), np.zeros(tot, np.float32)
+        fw = np.zeros(2 * self.batch, np.float32)
+        _check(lib().kd_batch_best_path_copy(self.h, offs, il, ol, st, gc, ac, fw))
+        out = []
+        for i in range(self.batch):
+            a, b = int(offs[i]), int(offs[i] + n[i])
+            out.append(Path(bool(lens[i] >= 0), il[a:b].copy(), ol[a:b].copy(), st[a:b].copy(),
+                            gc[a:b].copy(), ac[a:b].copy(),
+                            (float(fw[2 * i]), float(fw[2 * i + 1]))))
+        return out
+
+    def frame_tokens(self, utt, frame_plus_one):
+        cnt = C.c_int32(0)
+        _check(lib().kd_batch_frame_tokens(self.h, utt, frame_plus_one, 0, C.byref(cnt), None, None))
+        n = cnt.value
+        s = np.zeros(max(n, 1), np.int32)
+        c = np.zeros(max(n, 1), np.float64)
+        if n:
+            _check(lib().kd_batch_frame_tokens(self.h, utt, frame_plus_one, n, C.byref(cnt),
+                                               s.ctypes.data, c.ctypes.data))
+        return s[:n], c[:n]
+
+    def stats(self):
+        out = np.zeros((self.batch, len(STAT_NAMES)), np.int64)
+        _check(lib().kd_batch_stats(self.h, out))
+        return out
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        _check(lib().kd_batch_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    @property
+    def device_bytes(self):
+        return lib().kd_batch_device_bytes(self.h)

@@ -1,0 +1,181 @@
+"""GPU parity: the HIP FasterDecoder (through the C ABI) against the oracle's
+canonical policy -- bit-exact on states/labels and on every cost, which are the
+same IEEE expressions on both sides (integer work: identical; floating point:
+the north star allows 1e-4, we assert equality and report the max deviation)."""
+import numpy as np
+import pytest
+
+from kaldi_decoder import cabi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _V(g):
+    return int(g["ilabel"].max())
+
+
+def _cases():
+    yield "H8", synth.ctc_topo(8), None, dict(beam=6.0)
+    yield "H32", synth.ctc_topo(32), None, dict(beam=16.0)
+    yield "H500", synth.ctc_topo(500), None, dict(beam=15.0)
+    for seed in range(3):
+        yield (f"rand{seed}", synth.random_graph(200 + 300 * seed, 3.0, 24, 0.25, seed), None,
+               dict(beam=6.0 + 3 * seed, min_active=0))
+    g = synth.hl_graph(V=40, n_words=400, seed=3)
+    yield "HL", g, g["lexicon"], dict(beam=12.0, max_active=300)
+    g = synth.hlg_graph(V=40, n_words=200, n_hist=200, avg_succ=8, seed=4)
+    yield "HLG", g, g["lexicon"], dict(beam=10.0)
+    yield "HLGmin", g, g["lexicon"], dict(beam=4.0, min_active=50)
+    yield "HLGmax", g, g["lexicon"], dict(beam=12.0, max_active=40, min_active=0)
+
+
+def _assert_same_path(pg, po, tag):
+    assert pg.ok == po.ok, tag
+    assert pg.ilabel.tolist() == po.ilabel.tolist(), tag
+    assert pg.olabel.tolist() == po.olabel.tolist(), tag
+    assert pg.state.tolist() == po.state.tolist(), tag
+    assert pg.graph_cost.tolist() == po.graph_cost.tolist(), tag
+    assert pg.ac_cost.tolist() == po.ac_cost.tolist(), tag
+    assert pg.final_weight == po.final_weight, tag
+
+
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+def test_frontier_and_best_path_match_oracle(oracle, case):
+    name, g, lex, opts = case
+    T, B = 40, 3
+    G = cabi.Graph(g)
+    OG = oracle.Graph(g)
+    lps = [synth.make_logprobs(T - 5 * i, _V(g), i, peak=6.0, lexicon=lex) for i in range(B)]
+    bt = cabi.Batch(G, max_batch=B, **opts)
+    bt.init_decoding()
+    decs = [oracle.FasterDecoder(OG, policy=1, **opts) for _ in range(B)]
+    for d in decs:
+        d.init_decoding()
+    for i in range(B):
+        s, c = bt.frame_tokens(i, 0)
+        so, co = decs[i].tokens()
+        assert s.tolist() == so.tolist() and c.tolist() == co.tolist(), (name, "init")
+    step = 7
+    for t0 in range(0, T, step):
+        bt.advance_host(lps, max_num_frames=step)
+        for i, d in enumerate(decs):
+            d.advance_decoding(lps[i], max_num_frames=step)
+            n = d.num_frames_decoded()
+            s, c = bt.frame_tokens(i, n)
+            so, co = d.tokens()
+            assert s.tolist() == so.tolist(), (name, i, n)
+            assert c.tolist() == co.tolist(), (name, i, n)
+    assert bt.num_frames_decoded().tolist() == [lp.shape[0] for lp in lps]
+    rf = bt.reached_final()
+    for use_final in (True, False):
+        paths = bt.best_paths(use_final)
+        for i, d in enumerate(decs):
+            assert bool(rf[i]) == d.reached_final()
+            _assert_same_path(paths[i], d.get_best_path(use_final), (name, i, use_final))
+    st = bt.stats()
+    for i, d in enumerate(decs):
+        so = d.stats()
+        assert st[i, 0] == so["frames"]
+        assert st[i, 1] == so["tokens_in"]
+        assert st[i, 2] == so["tokens_expanded"]
+        assert st[i, 3] == so["arcs_scanned"]
+        assert st[i, 5] == so["tokens_out"]
+        # epsilon re-expansion counts depend on relaxation order (worklist rounds
+        # here, a LIFO queue in the reference): not a parity quantity
+        assert st[i, 6] > 0 or so["eps_arcs_scanned"] == 0
+
+
+def test_every_frame_of_one_utterance(oracle):
+    g = synth.hlg_graph(V=40, n_words=200, n_hist=200, avg_succ=8, seed=4)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lp = synth.make_logprobs(60, 40, 3, peak=5.0, lexicon=g["lexicon"])
+    bt = cabi.Batch(G, max_batch=1, beam=9.0)
+    bt.init_decoding()
+    bt.advance_host([lp])
+    d = oracle.FasterDecoder(OG, beam=9.0, policy=1)
+    d.init_decoding()
+    for t in range(60):
+        d.advance_decoding(lp, max_num_frames=1)
+        s, c = bt.frame_tokens(0, t + 1)
+        so, co = d.tokens()
+        assert s.tolist() == so.tolist() and c.tolist() == co.tolist(), t
+
+
+def test_spill_to_global_table(oracle):
+    # a frontier far beyond the 8192-slot LDS table: dense H with a flat posterior
+    V = 500
+    g = synth.random_graph(30000, 4.0, 16, 0.1, 9, max_weight=0.5)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lp = synth.make_logprobs(12, 16, 0, peak=0.0)
+    opts = dict(beam=1000.0, min_active=0)
+    bt = cabi.Batch(G, max_batch=1, **opts)
+    bt.init_decoding()
+    bt.advance_host([lp])
+    d = oracle.FasterDecoder(OG, policy=1, **opts)
+    d.decode(lp)
+    s, c = bt.frame_tokens(0, 12)
+    so, co = d.tokens()
+    assert len(so) > 8192
+    assert s.tolist() == so.tolist() and c.tolist() == co.tolist()
+    assert bt.stats()[0, 9] > 0  # spill frames
+    _assert_same_path(bt.best_paths()[0], d.get_best_path(), "spill")
+
+
+def test_streaming_with_decodable_offset(oracle):
+    g = synth.hl_graph(V=40, n_words=400, seed=3)
+    G = cabi.Graph(g)
+    lp = synth.make_logprobs(50, 40, 1, peak=6.0, lexicon=g["lexicon"])
+    a = cabi.Batch(G, max_batch=1, beam=8.0)
+    a.init_decoding()
+    a.advance_host([lp])
+    b = cabi.Batch(G, max_batch=1, beam=8.0)
+    b.init_decoding()
+    for start in range(0, 50, 9):  # DecodableCtc(chunk, offset=start)
+        b.advance_host([lp[start:start + 9]], offsets=[start])
+    assert b.num_frames_decoded().tolist() == [50]
+    _assert_same_path(a.best_paths()[0], b.best_paths()[0], "stream")
+
+
+def test_device_pointers_and_reinit(oracle):
+    import torch
+    g = synth.hl_graph(V=40, n_words=400, seed=3)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T = 4, 30
+    lps = [synth.make_logprobs(T, 40, i, peak=6.0, lexicon=g["lexicon"]) for i in range(B)]
+    dev = torch.from_numpy(np.stack(lps)).cuda()
+    bt = cabi.Batch(G, max_batch=B, beam=8.0)
+    for _ in range(2):  # InitDecoding can be called again for a new utterance
+        bt.init_decoding()
+        bt.advance_device([dev[i].data_ptr() for i in range(B)], [T] * B, 40)
+        paths = bt.best_paths()
+        for i in range(B):
+            d = oracle.FasterDecoder(OG, beam=8.0, policy=1)
+            d.decode(lps[i])
+            _assert_same_path(paths[i], d.get_best_path(), i)
+    assert bt.last_kernel_ms() > 0
+
+
+def test_error_behaviour():
+    g = synth.ctc_topo(4)
+    G = cabi.Graph(g)
+    for kw in ({"hash_ratio": 0.5}, {"max_active": 1}, {"min_active": -1},
+               {"min_active": 30, "max_active": 30}):
+        with pytest.raises(RuntimeError, match="Check failed"):
+            cabi.Batch(G, **kw)  # faster-decoder.cc:24-28
+    bt = cabi.Batch(G, max_batch=1)
+    bt.batch = 1
+    lp = synth.make_logprobs(3, 4, 0)
+    with pytest.raises(RuntimeError, match="InitDecoding"):
+        bt.advance_host([lp])  # faster-decoder.cc:128-129
+    bt.init_decoding()
+    bt.advance_host([lp])
+    with pytest.raises(RuntimeError, match="num_frames_ready >= num_frames_decoded_"):
+        bt.advance_host([lp[:2]])  # faster-decoder.cc:137
+    # empty frontier: nothing survives -> GetBestPath false
+    arcs = [(0, 1, 1, 0, 0.0)]
+    g2 = synth.graph_from_arcs(2, 0, arcs, {})
+    b2 = cabi.Batch(cabi.Graph(g2), max_batch=1)
+    b2.init_decoding()
+    b2.advance_host([np.zeros((3, 2), np.float32)])
+    p = b2.best_paths()[0]
+    assert not p.ok and not b2.reached_final()[0]
