@@ -183,6 +183,12 @@ enum {
 };
 int kd_batch_stats(kd_batch *b, int64_t *out /* [batch][KD_NUM_STATS] */);
 
+/* Diagnostic builds only (make -C kaldi-decoder_amd prof, -DKD_PROFILE): shader
+ * clock cycles lane 0 spent per phase, 16 int64 per utterance (bucket names in
+ * tools/prof_phases.py).  The shipping library executes no stamps and returns
+ * KD_E_STATE. */
+int kd_batch_phase_cycles(kd_batch *b, int64_t *out /* [batch][16] */);
+
 /* Device time of the most recent search-kernel launch, from HIP events on the
  * batch's stream (valid after a sync). */
 int kd_batch_last_kernel_ms(kd_batch *b, float *ms);

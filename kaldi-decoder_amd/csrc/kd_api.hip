@@ -71,8 +71,8 @@ struct kd_batch {
   DevBuf<int32_t> frame_count, frames_decoded;
   DevBuf<uint32_t> status;
   DevBuf<long long> stats;
-  DevBuf<uint32_t> g_key, g_arc, g_src, g_idx, g_used, g_wl;
-  DevBuf<unsigned long long> g_cost;
+  DevBuf<uint32_t> g_key, g_arc, g_used, g_wl, g_log_h, g_log_arc, g_log_src;
+  DevBuf<unsigned long long> g_cost, g_log_nk;
   DevBuf<UttDesc> utt;
   DevBuf<float> staging;
   DevBuf<const float *> unused_;
@@ -100,7 +100,8 @@ struct kd_batch {
   size_t DeviceBytes() const {
     return tok_state.bytes() + tok_prev.bytes() + tok_arc.bytes() + tok_cost.bytes() +
            frame_base.bytes() + frame_count.bytes() + g_key.bytes() + g_arc.bytes() +
-           g_src.bytes() + g_idx.bytes() + g_used.bytes() + g_wl.bytes() + g_cost.bytes() +
+           g_log_h.bytes() + g_log_arc.bytes() + g_log_src.bytes() + g_log_nk.bytes() +
+           g_used.bytes() + g_wl.bytes() + g_cost.bytes() +
            staging.bytes() + stats.bytes();
   }
 
@@ -117,7 +118,7 @@ struct kd_batch {
     p.tok_cost = tok_cost.p;
     p.tok_prev = tok_prev.p;
     p.tok_arc = tok_arc.p;
-    p.arena_cap = static_cast<unsigned long long>(o.arena_tokens);
+    p.arena_cap = static_cast<unsigned long long>(o.arena_tokens / std::max(max_batch, 1));
     p.arena_top = arena_top.p;
     p.frame_base = frame_base.p;
     p.frame_count = frame_count.p;
@@ -128,10 +129,12 @@ struct kd_batch {
     p.g_key = g_key.p;
     p.g_cost = g_cost.p;
     p.g_arc = g_arc.p;
-    p.g_src = g_src.p;
-    p.g_idx = g_idx.p;
     p.g_used = g_used.p;
     p.g_wl = g_wl.p;
+    p.g_log_h = g_log_h.p;
+    p.g_log_arc = g_log_arc.p;
+    p.g_log_src = g_log_src.p;
+    p.g_log_nk = g_log_nk.p;
     p.g_log2_slots = g_log2_slots;
     p.utt = utt.p;
     p.do_init = do_init;
@@ -346,19 +349,21 @@ int kd_batch_create(const kd_graph *g, const kd_faster_options *opts, int32_t ma
   A(b->tok_prev.Alloc(b->o.arena_tokens));
   A(b->tok_arc.Alloc(b->o.arena_tokens));
   A(b->tok_cost.Alloc(b->o.arena_tokens));
-  A(b->arena_top.Alloc(1));
+  A(b->arena_top.Alloc(max_batch));
   A(b->frame_base.Alloc(nf));
   A(b->frame_count.Alloc(nf));
   A(b->frames_decoded.Alloc(max_batch));
   A(b->status.Alloc(max_batch));
-  A(b->stats.Alloc(static_cast<size_t>(max_batch) * KD_NUM_STATS));
+  A(b->stats.Alloc(static_cast<size_t>(max_batch) * kStatStride));
   A(b->g_key.Alloc(gs));
   A(b->g_cost.Alloc(gs));
   A(b->g_arc.Alloc(gs));
-  A(b->g_src.Alloc(gs));
-  A(b->g_idx.Alloc(gs));
   A(b->g_used.Alloc(gs));
   A(b->g_wl.Alloc(2 * gs));
+  A(b->g_log_h.Alloc(2 * gs));
+  A(b->g_log_arc.Alloc(2 * gs));
+  A(b->g_log_src.Alloc(2 * gs));
+  A(b->g_log_nk.Alloc(2 * gs));
   A(b->utt.Alloc(max_batch));
   A(b->reached_final.Alloc(max_batch));
   A(b->path_len.Alloc(max_batch));
@@ -408,7 +413,7 @@ int kd_batch_init_decoding(kd_batch *b, int32_t batch) {
   if (!b || batch <= 0 || batch > b->max_batch) return Fail(KD_E_INVALID, "bad batch size");
   KD_HIP_TRY(hipSetDevice(b->g->device));
   b->batch = batch;
-  KD_HIP_TRY(hipMemsetAsync(b->arena_top.p, 0, sizeof(unsigned long long), b->stream));
+  KD_HIP_TRY(hipMemsetAsync(b->arena_top.p, 0, b->arena_top.bytes(), b->stream));
   KD_HIP_TRY(hipMemsetAsync(b->frames_decoded.p, 0xFF, b->frames_decoded.bytes(), b->stream));
   KD_HIP_TRY(hipMemsetAsync(b->status.p, 0, b->status.bytes(), b->stream));
   KD_HIP_TRY(hipMemsetAsync(b->stats.p, 0, b->stats.bytes(), b->stream));
@@ -613,9 +618,27 @@ int kd_batch_stats(kd_batch *b, int64_t *out) {
   if (b->pending)
     if (int r = ReadBack(b)) return r;
   static_assert(sizeof(long long) == sizeof(int64_t), "");
-  KD_HIP_TRY(hipMemcpy(out, b->stats.p, static_cast<size_t>(b->batch) * KD_NUM_STATS * sizeof(int64_t),
-                       hipMemcpyDeviceToHost));
+  std::vector<long long> h(static_cast<size_t>(b->batch) * kStatStride);
+  KD_HIP_TRY(hipMemcpy(h.data(), b->stats.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+  for (int i = 0; i < b->batch; ++i)
+    for (int k = 0; k < KD_NUM_STATS; ++k) out[i * KD_NUM_STATS + k] = h[i * kStatStride + k];
   return KD_OK;
+}
+
+int kd_batch_phase_cycles(kd_batch *b, int64_t *out) {
+  if (!b || !out) return Fail(KD_E_INVALID, "bad argument");
+#ifndef KD_PROFILE
+  return Fail(KD_E_STATE, "kd_batch_phase_cycles: not a diagnostic (KD_PROFILE) build");
+#else
+  KD_HIP_TRY(hipSetDevice(b->g->device));
+  if (b->pending)
+    if (int r = ReadBack(b)) return r;
+  std::vector<long long> h(static_cast<size_t>(b->batch) * kStatStride);
+  KD_HIP_TRY(hipMemcpy(h.data(), b->stats.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+  for (int i = 0; i < b->batch; ++i)
+    for (int k = 0; k < kProfSlots; ++k) out[i * kProfSlots + k] = h[i * kStatStride + KD_NUM_STATS + k];
+  return KD_OK;
+#endif
 }
 
 int kd_batch_last_kernel_ms(kd_batch *b, float *ms) {

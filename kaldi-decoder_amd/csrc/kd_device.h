@@ -38,6 +38,8 @@ constexpr uint32_t kArcNone = 0xFFFFFFFFu;
 constexpr uint32_t kSrcEps = 0x80000000u;  // back-pointer source is a table slot
 constexpr uint32_t kSrcNone = 0xFFFFFFFFu;
 constexpr unsigned long long kCostDead = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kProfSlots = 16;   // diagnostic cycle buckets (KD_PROFILE builds)
+constexpr int kStatStride = 32;  // KD_NUM_STATS counters + kProfSlots, padded
 
 struct UttDesc {
   const float *ll;     // row 0 of this utterance's log-likelihood matrix
@@ -62,8 +64,9 @@ struct SearchParams {
   double *tok_cost;
   int32_t *tok_prev;
   int32_t *tok_arc;
-  unsigned long long arena_cap;
-  unsigned long long *arena_top;
+  unsigned long long arena_cap;   // records per utterance: utterance u owns
+                                  // [u * arena_cap, (u + 1) * arena_cap)
+  unsigned long long *arena_top;  // [batch] next free record (absolute index)
   // frame index, per utterance [max_frames + 1]
   long long *frame_base;
   int32_t *frame_count;
@@ -71,15 +74,18 @@ struct SearchParams {
   // per-utterance state
   int32_t *frames_decoded;
   uint32_t *status;
-  long long *stats;  // [batch][KD_NUM_STATS]
+  long long *stats;  // [batch][kStatStride]
   // per-utterance spill table (global memory) and scratch, g_slots entries each
   uint32_t *g_key;
   unsigned long long *g_cost;
   uint32_t *g_arc;
-  uint32_t *g_src;   // also the back-pointer source array of the LDS table
-  uint32_t *g_idx;
   uint32_t *g_used;
   uint32_t *g_wl;    // two worklists per utterance
+  // per-utterance candidate log, 2 * g_slots entries (both table modes)
+  uint32_t *g_log_h;
+  uint32_t *g_log_arc;
+  uint32_t *g_log_src;
+  unsigned long long *g_log_nk;
   int32_t g_log2_slots;
   // input
   const UttDesc *utt;

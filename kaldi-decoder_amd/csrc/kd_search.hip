@@ -10,31 +10,39 @@
 //   hash-list-inl.h:26-173     HashList (-> open-addressed token table in LDS)
 //   faster-decoder.h:110-156   Token (-> append-only arena record)
 //
-// Mapping: one 1024-thread workgroup owns one utterance for the whole launch
-// and loops over its frames; utterances never interact, so the only
-// synchronisation is s_barrier inside the workgroup and a frame costs no
-// kernel launch.  Per frame:
-//   A  cutoff      min / counts / radix-select over the previous frontier
-//   B  emitting    arc-parallel expansion: a block-wide prefix sum over the
-//                  out-degrees of the surviving tokens spreads their arcs
-//                  over the lanes (16-byte arc records, consecutive lanes read
-//                  consecutive arcs), the log-likelihood row sits in LDS, and
-//                  each candidate does one 64-bit ds_min on the destination
-//                  state's slot of the LDS token table
-//   C  epsilon     same machinery over epsilon arc ranges, iterated to a
-//                  fixpoint with a worklist of improved slots
-//   D  compaction  live slots -> one contiguous arena block (state, cost,
-//                  prev, arc); the table is cleared for the next frame
-// The table holds 8192 slots (key, 64-bit cost key, winning arc) = 128 KiB of
-// the CU's 160 KiB LDS.  A frame that would overfill it is re-run against a
-// larger table in global memory (same code, template parameter LDS=false).
+// Mapping: one workgroup owns one utterance for the whole launch and loops
+// over its frames; utterances never interact, so the only synchronisation is
+// s_barrier inside the workgroup and a frame costs no kernel launch.  A frame:
+//   cutoff    best cost comes from the previous frame's compaction; max_active
+//             / min_active need one counting pass and, when they bind, a 4-pass
+//             radix select.  The best token's arcs are scored first to bound
+//             the next cutoff early (faster-decoder.cc:176-189).
+//   filter    one token per lane.  Tokens with <= 4 arcs are scored by their
+//             own lane; the rest are queued in LDS and taken kGroup at a time
+//             by whole waves, so consecutive lanes read consecutive 16-byte
+//             arcs.  The log-likelihood row sits in LDS.  Arcs that beat the
+//             running cutoff are appended to a candidate queue (state, arc,
+//             source, cost key) -- this phase never touches the token table.
+//   insert    one queue entry per lane (dense): entries below the now exact
+//             cutoff do one ds_cmpst (claim) and one 64-bit ds_min (relax) on
+//             the 8192-slot LDS token table; a state's first cost appends its
+//             slot to the frame's live list.
+//   epsilon   filter + insert again over epsilon arc ranges, iterated to a
+//             fixpoint with a worklist of improved slots.
+//   resolve   queue entries that still hold their slot's cost compete for the
+//             lowest arc index (deterministic back-pointer), then the live
+//             list becomes one contiguous arena block (state, cost, prev, arc)
+//             and only the live slots are cleared.
+// The table (key, 64-bit cost key, winning arc) is 128 KiB of the CU's 160 KiB
+// LDS.  A frame whose states do not fit replays its queue into a larger table
+// in global memory (template parameter LDS=false); the filter is not repeated.
 //
 // Semantics are the reference's, made order-free (DESIGN.md "Order
 // dependence"): costs are double and use the reference's expressions, the
 // emitting cutoff is the value the reference's running cutoff ends at
-// (the running value is used only to skip work early), strict improvement
-// replaces, and ties pick the lowest arc index.  The oracle's policy 1 states
-// the same semantics on the CPU and the two are compared bit for bit.
+// (the running value only limits the queue), strict improvement replaces, and
+// ties pick the lowest arc index.  The oracle's policy 1 states the same
+// semantics on the CPU and the two are compared bit for bit.
 
 #include <float.h>
 #include <limits.h>
@@ -45,14 +53,18 @@
 namespace kd {
 namespace {
 
-constexpr int kBlock = 1024;
+#ifndef KD_BLOCK
+#define KD_BLOCK 1024
+#endif
+constexpr int kBlock = KD_BLOCK;  // threads per utterance
 constexpr int kWaves = kBlock / 64;
 constexpr int kLog2Slots = 13;
 constexpr int kSlots = 1 << kLog2Slots;
 constexpr int kSlotsPerThread = kSlots / kBlock;
 constexpr int kLdsFillLimit = kSlots * 3 / 4;
-constexpr int kVmax = 2048;  // log-likelihood row staged in LDS when V <= kVmax
-constexpr int kU = 2;        // arcs per lane per batch
+constexpr int kVmax = 2048;   // log-likelihood row staged in LDS when V <= kVmax
+constexpr int kSmallDeg = 4;  // tokens with at most this many arcs stay on their lane
+constexpr int kGroup = 4;     // queued tokens a wave scores at a time
 constexpr unsigned long long kCostInf = 0xFFF0000000000000ull;  // CostKey(+inf)
 
 struct Shared {
@@ -60,24 +72,35 @@ struct Shared {
   unsigned long long cost[kSlots];
   uint32_t key[kSlots];
   uint32_t arc[kSlots];
-  // expansion scratch: one entry per item of the current chunk
+  // queue of high-degree tokens of the current chunk
   double it_cost[kBlock];
-  int32_t it_scan[kBlock];
   int32_t it_abeg[kBlock];
+  int32_t it_deg[kBlock];
   uint32_t it_src[kBlock];
   float ll[kVmax];
   uint32_t bitmask[kSlots / 32];
   int32_t hist[256];
   unsigned long long red64[kWaves];
-  int32_t red32[kWaves];
-  unsigned long long min_new;
+  unsigned long long min_new;   // min cost key seen by the emitting filter
+  unsigned long long f_best;    // CostKey of the best cost of the frontier to expand
+  unsigned long long f_best_next;
+  long long arena_next;         // next free record of this utterance's arena region
   long long base_out;
-  int32_t scan_total;
-  int32_t fill;
+  double best_cost;             // the frontier's best token ...
+  int32_t best_abeg, best_deg;  // ... and its emitting arc range
+  int32_t f_nlt, f_nle;
+  int32_t n_live;               // slots holding a token this frame (== live-list length)
+  int32_t q_n;                  // candidate queue length
   int32_t overflow;
   int32_t wl_count[2];
+  int32_t it_count[2], it_next[2];
   int32_t sel_bin, sel_k;
-  int32_t stop;
+  int32_t frame_cnt[4];         // this frame: expanded, eps_exp, arcs, eps_arcs
+  long long stat[KD_NUM_STATS];  // whole launch
+#ifdef KD_PROFILE
+  long long cyc[kProfSlots];
+  long long lap_last;
+#endif
 };
 static_assert(sizeof(Shared) <= 163840, "LDS budget");
 
@@ -105,51 +128,40 @@ __device__ __forceinline__ ArcRec LoadArcRec(const ArcRec *base, uint32_t i) {
   return r;
 }
 
+// Per-frame, per-lane work counters, folded into LDS at the end of the frame.
 struct Counters {
-  long long tokens_expanded = 0, arcs_scanned = 0, arcs_kept = 0, eps_arcs = 0, eps_exp = 0;
+  int tokens_expanded = 0, eps_exp = 0, arcs_scanned = 0, eps_arcs = 0;
 };
 
+// Diagnostic build only (make prof): a lap timer on lane 0.  KD_LAP(s, i) adds
+// the shader-clock cycles since the previous lap to bucket i.  The shipping
+// build executes no stamps.
+#ifdef KD_PROFILE
+#define KD_LAP(s, i)                                                              \
+  do {                                                                            \
+    if (threadIdx.x == 0) {                                                       \
+      const long long now_ = static_cast<long long>(__builtin_amdgcn_s_memtime()); \
+      (s).cyc[(LDS_MODE) ? (i) : 14] += now_ - (s).lap_last;                      \
+      (s).lap_last = now_;                                                        \
+    }                                                                             \
+  } while (0)
+#else
+#define KD_LAP(s, i)
+#endif
+
 // ---- block-wide primitives (wave64 shuffles + one LDS hop) -----------------
-__device__ __forceinline__ int BlockExclScan(Shared &s, int v, int &total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int y = __shfl_up(x, d, 64);
-    if (lane >= d) x += y;
-  }
-  if (lane == 63) s.red32[wave] = x;
-  __syncthreads();
-  if (wave == 0) {
-    int w = lane < kWaves ? s.red32[lane] : 0, xs = w;
-#pragma unroll
-    for (int d = 1; d < kWaves; d <<= 1) {
-      int y = __shfl_up(xs, d, 64);
-      if (lane >= d) xs += y;
-    }
-    if (lane < kWaves) s.red32[lane] = xs - w;
-    if (lane == kWaves - 1) s.scan_total = xs;
-  }
-  __syncthreads();
-  int off = s.red32[wave] + x - v;
-  total = s.scan_total;
-  __syncthreads();
-  return off;
-}
-
-__device__ __forceinline__ int BlockSum(Shared &s, int v) {
-  int total;
-  BlockExclScan(s, v, total);
-  return total;
-}
-
-__device__ __forceinline__ unsigned long long BlockMinU64(Shared &s, unsigned long long v) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ unsigned long long WaveMinU64(unsigned long long v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     unsigned long long y = __shfl_xor(v, d, 64);
     v = y < v ? y : v;
   }
+  return v;
+}
+
+__device__ __forceinline__ unsigned long long BlockMinU64(Shared &s, unsigned long long v) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = WaveMinU64(v);
   if (lane == 0) s.red64[wave] = v;
   __syncthreads();
   unsigned long long r = s.red64[0];
@@ -166,9 +178,6 @@ struct Table {
   KD_G uint32_t *gkey;
   KD_G unsigned long long *gcost;
   KD_G uint32_t *garc;
-  KD_G uint32_t *src;   // always global
-  KD_G uint32_t *gidx;
-  KD_G uint32_t *gused;
   uint32_t *bitmask;
   int log2_slots;
   uint32_t mask;
@@ -178,22 +187,26 @@ struct Table {
   __device__ __forceinline__ uint32_t *ArcP(uint32_t h) const { if constexpr (LDS) return &s.arc[h]; else return ToFlat(&garc[h]); }
 
   // Global-table words are updated by L2 atomics, which do not refresh this
-  // CU's L1: read them with agent-scope (sc1) loads.
+  // CU's L1: read and write them with agent-scope (sc1) accesses.
   __device__ __forceinline__ uint32_t LoadKey(uint32_t h) const {
     if constexpr (LDS) return s.key[h];
     else return __hip_atomic_load(ToFlat(&gkey[h]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __device__ __forceinline__ void StoreKey(uint32_t h, uint32_t v) const {
+    if constexpr (LDS) s.key[h] = v;
+    else __hip_atomic_store(ToFlat(&gkey[h]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ unsigned long long LoadCost(uint32_t h) const {
     if constexpr (LDS) return s.cost[h];
     else return __hip_atomic_load(ToFlat(&gcost[h]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __device__ __forceinline__ uint32_t LoadArc(uint32_t h) const {
-    if constexpr (LDS) return s.arc[h];
-    else return __hip_atomic_load(ToFlat(&garc[h]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   __device__ __forceinline__ void StoreCost(uint32_t h, unsigned long long v) const {
     if constexpr (LDS) s.cost[h] = v;
     else __hip_atomic_store(ToFlat(&gcost[h]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __device__ __forceinline__ uint32_t LoadArc(uint32_t h) const {
+    if constexpr (LDS) return s.arc[h];
+    else return __hip_atomic_load(ToFlat(&garc[h]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ void StoreArc(uint32_t h, uint32_t v) const {
     if constexpr (LDS) s.arc[h] = v;
@@ -202,37 +215,25 @@ struct Table {
   __device__ __forceinline__ uint32_t Hash(uint32_t state) const {
     return (state * 2654435761u) >> (32 - log2_slots);
   }
+  __device__ __forceinline__ uint32_t FillLimit() const {
+    return LDS ? kLdsFillLimit : (3u << (log2_slots - 2));
+  }
 
-  // Finds or claims the slot of `k` (state | has-eps flag).  Returns kKeyEmpty
-  // when the table is over its fill limit or the probe sequence is exhausted.
+  // Finds or claims the slot of `k` (state | has-eps flag); kKeyEmpty if the
+  // probe sequence is exhausted (table full).
   __device__ __forceinline__ uint32_t Claim(uint32_t k) const {
     uint32_t h = Hash(k & kStateMask);
-    const uint32_t limit = LDS ? kLdsFillLimit : (3u << (log2_slots - 2));
     for (uint32_t probe = 0; probe <= mask; ++probe) {
-      uint32_t cur = LoadKey(h);
+      const uint32_t cur = LoadKey(h);
       if (cur == k) return h;
       if (cur == kKeyEmpty) {
-        uint32_t old = atomicCAS(KeyP(h), kKeyEmpty, k);
-        if (old == kKeyEmpty) {
-          int pos = atomicAdd(&s.fill, 1);
-          if constexpr (!LDS) {
-            if (static_cast<uint32_t>(pos) <= mask) gused[pos] = h;
-          }
-          if (static_cast<uint32_t>(pos) >= limit) s.overflow = 1;
-          return h;
-        }
-        if (old == k) return h;
+        const uint32_t old = atomicCAS(KeyP(h), kKeyEmpty, k);
+        if (old == kKeyEmpty || old == k) return h;
       }
       h = (h + 1) & mask;
     }
-    s.overflow = 1;
     return kKeyEmpty;
   }
-};
-
-struct Cand {
-  uint32_t h, arc, src;
-  unsigned long long nk;
 };
 
 struct FrameCtx {
@@ -246,31 +247,68 @@ struct FrameCtx {
   double weight_cutoff;  // tokens with cost < this are expanded
   float adaptive_beam;
   double cutoff;  // epsilon-closure cutoff == final emitting cutoff
-  KD_G uint32_t *wl[2];
+  KD_G uint32_t *wl0, *wl1;  // epsilon worklists (slots)
+  KD_G uint32_t *live;       // slots that hold a token this frame, in arena order
+  // candidate queue: destination (state|flag, later its slot), arc, source, cost key
+  KD_G uint32_t *q_h, *q_arc, *q_src;
+  KD_G unsigned long long *q_nk;
+  int q_cap;
 };
 
-// Expands the emitting (EPS=false) arcs of the input frontier, or the epsilon
-// (EPS=true) arcs of the tokens on worklist `wl_in`, into the table.
-// Returns false if the table overflowed (the caller re-runs the frame).
+// Scores one arc out of a token with cost `csrc` and queues it if it survives
+// the (running) cutoff: the reference's test at faster-decoder.cc:208-211
+// (emitting) or :90-95 (epsilon).
+template <bool EPS>
+__device__ __forceinline__ void FilterArc(const FrameCtx &c, const ArcRec &a, uint32_t aidx,
+                                          double csrc, uint32_t srcid) {
+  Shared &s = c.s;
+  double nc;
+  bool keep;
+  unsigned long long seen_min = 0;
+  if constexpr (EPS) {
+    nc = csrc + a.weight;     // faster-decoder.h:134
+    keep = !(nc > c.cutoff);  // faster-decoder.cc:92
+  } else {
+    const float ll = c.ll_in_lds ? s.ll[a.ilabel - 1] : c.ll_row[a.ilabel - 1];
+    const float ac_cost = -1 * ll;   // :209
+    nc = a.weight + csrc + ac_cost;  // :210 (== Token cost, faster-decoder.h:126)
+    seen_min = s.min_new;
+    keep = nc < KeyCost(seen_min) + static_cast<double>(c.adaptive_beam);  // :211, :215-217
+  }
+  if (keep) {
+    const unsigned long long nk = CostKey(nc);
+    const int pos = atomicAdd(&s.q_n, 1);
+    if (pos < c.q_cap) {
+      c.q_h[pos] = a.next;
+      c.q_arc[pos] = aidx;
+      c.q_src[pos] = srcid;
+      c.q_nk[pos] = nk;
+    }
+    if constexpr (!EPS) {
+      if (nk < seen_min) atomicMin(&s.min_new, nk);
+    }
+  }
+}
+
+// Filter phase over the input frontier (EPS=false) or over the tokens on
+// worklist `wl_in` (EPS=true).  Touches the table only to read the worklist
+// tokens' state and cost.
 template <bool LDS, bool EPS>
-__device__ __forceinline__ bool Expand(const FrameCtx &c, const Table<LDS> &t, int n_items,
-                                       const KD_G uint32_t *wl_in, KD_G uint32_t *wl_out,
-                                       int wl_out_idx,
-                                       Counters &cnt) {
+__device__ __forceinline__ void Filter(const FrameCtx &c, const Table<LDS> &t, int n_items,
+                                       const KD_G uint32_t *wl_in, Counters &cnt) {
+  constexpr bool LDS_MODE = LDS;
+  (void)LDS_MODE;
   const SearchParams &p = c.p;
   Shared &s = c.s;
-  const int tid = threadIdx.x;
-  Cand prev[kU];
-#pragma unroll
-  for (int u = 0; u < kU; ++u) prev[u].h = kKeyEmpty;
-
-  for (int chunk = 0; chunk < n_items; chunk += kBlock) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  int par = 0;
+  if (tid == 0) { s.it_count[0] = 0; s.it_next[0] = 0; }
+  __syncthreads();
+  for (int chunk = 0; chunk < n_items; chunk += kBlock, par ^= 1) {
     const int i = chunk + tid;
-    int deg = 0, abeg = 0;
-    double cst = 0.0;
-    uint32_t srcid = 0;
     if (i < n_items) {
-      uint32_t st;
+      uint32_t st, srcid;
+      double cst;
       bool ok;
       if constexpr (!EPS) {
         st = static_cast<uint32_t>(ToG(p.tok_state)[c.base_in + i]);
@@ -286,129 +324,138 @@ __device__ __forceinline__ bool Expand(const FrameCtx &c, const Table<LDS> &t, i
       }
       if (ok) {
         const StateRec r = LoadState(p.states, st);
-        abeg = EPS ? r.emit_end : r.arc_begin;
-        deg = EPS ? r.arc_end - r.emit_end : r.emit_end - r.arc_begin;
-        if (EPS) cnt.eps_exp += 1; else cnt.tokens_expanded += 1;
+        const int abeg = EPS ? r.emit_end : r.arc_begin;
+        const int deg = EPS ? r.arc_end - r.emit_end : r.emit_end - r.arc_begin;
+        if (EPS) { cnt.eps_exp += 1; cnt.eps_arcs += deg; }
+        else { cnt.tokens_expanded += 1; cnt.arcs_scanned += deg; }
+        if (deg > kSmallDeg) {
+          const int q = atomicAdd(&s.it_count[par], 1);
+          s.it_abeg[q] = abeg;
+          s.it_deg[q] = deg;
+          s.it_cost[q] = cst;
+          s.it_src[q] = srcid;
+        } else {
+          // all of this token's arcs in flight before the first is scored
+          ArcRec ar[kSmallDeg];
+#pragma unroll
+          for (int a = 0; a < kSmallDeg; ++a)
+            if (a < deg) ar[a] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg + a));
+#pragma unroll
+          for (int a = 0; a < kSmallDeg; ++a)
+            if (a < deg) FilterArc<EPS>(c, ar[a], static_cast<uint32_t>(abeg + a), cst, srcid);
+        }
       }
     }
-    int total;
-    const int off = BlockExclScan(s, deg, total);
-    s.it_scan[tid] = off;
-    s.it_abeg[tid] = abeg;
-    s.it_cost[tid] = cst;
-    s.it_src[tid] = srcid;
     __syncthreads();
-    if (tid == 0) { if (EPS) cnt.eps_arcs += total; else cnt.arcs_scanned += total; }
-
-    for (int base = 0; base < total; base += kBlock * kU) {
-      // back-pointer sources of the previous batch's winners (see below)
+    KD_LAP(s, EPS ? 7 : 3);
+    const int nq = s.it_count[par];
+    if (tid == 0) { s.it_count[par ^ 1] = 0; s.it_next[par ^ 1] = 0; }
+    // high-degree tokens: a wave takes kGroup of them at a time, lanes over
+    // consecutive arcs; the first 64 arcs of all kGroup tokens are loaded
+    // before any is scored so their latencies overlap
+    while (true) {
+      int q0 = 0;
+      if (lane == 0) q0 = atomicAdd(&s.it_next[par], kGroup);
+      q0 = __builtin_amdgcn_readfirstlane(q0);
+      if (q0 >= nq) break;
+      ArcRec ar[kGroup];
+      int abeg[kGroup], deg[kGroup];
 #pragma unroll
-      for (int u = 0; u < kU; ++u)
-        if (prev[u].h != kKeyEmpty && t.LoadArc(prev[u].h) == prev[u].arc) t.src[prev[u].h] = prev[u].src;
-
-      double runcut;
-      unsigned long long seen_min = 0;
-      if constexpr (EPS) {
-        runcut = c.cutoff;
-      } else {
-        seen_min = s.min_new;
-        runcut = KeyCost(seen_min) + static_cast<double>(c.adaptive_beam);  // :215-217
-      }
-      Cand cur[kU];
-      // phase 1: relax.  One 64-bit atomic min per surviving candidate; a
-      // strict improvement invalidates the slot's winning arc.
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        cur[u].h = kKeyEmpty;
-        const int j = base + u * kBlock + tid;
-        if (j < total) {
-          int lo = 0, hi = kBlock - 1;
-          while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (s.it_scan[mid] <= j) lo = mid; else hi = mid - 1;
-          }
-          const uint32_t aidx = static_cast<uint32_t>(s.it_abeg[lo] + (j - s.it_scan[lo]));
-          const ArcRec a = LoadArcRec(p.arcs, aidx);
-          const double csrc = s.it_cost[lo];
-          double nc;
-          bool keep;
-          if constexpr (EPS) {
-            nc = csrc + a.weight;      // faster-decoder.h:134
-            keep = !(nc > runcut);     // faster-decoder.cc:92
-          } else {
-            const float ll = c.ll_in_lds ? s.ll[a.ilabel - 1] : c.ll_row[a.ilabel - 1];
-            const float ac_cost = -1 * ll;          // :209
-            nc = a.weight + csrc + ac_cost;         // :210 (== Token cost, faster-decoder.h:126)
-            keep = nc < runcut;                     // :211
-          }
-          if (keep) {
-            const uint32_t h = t.Claim(a.next);
-            if (h != kKeyEmpty) {
-              const unsigned long long nk = CostKey(nc);
-              const unsigned long long old = atomicMin(t.CostP(h), nk);
-              if (old > nk) {
-                t.StoreArc(h, kArcNone);
-                if constexpr (EPS) {
-                  if (a.next & kHasEps) {  // re-queue on improvement, :97-113
-                    const uint32_t bit = 1u << (h & 31);
-                    if (!(atomicOr(&t.bitmask[h >> 5], bit) & bit))
-                      wl_out[atomicAdd(&s.wl_count[wl_out_idx], 1)] = h;
-                  }
-                }
-              }
-              if (old >= nk) {
-                cur[u].h = h;
-                cur[u].arc = aidx;
-                cur[u].src = s.it_src[lo];
-                cur[u].nk = nk;
-              }
-              if constexpr (!EPS) {
-                cnt.arcs_kept += 1;
-                if (nk < seen_min) { atomicMin(&s.min_new, nk); seen_min = nk; }
-              }
-            }
-          }
+      for (int g = 0; g < kGroup; ++g) {
+        deg[g] = 0;
+        abeg[g] = 0;
+        if (q0 + g < nq) {
+          abeg[g] = s.it_abeg[q0 + g];
+          deg[g] = s.it_deg[q0 + g];
+          if (lane < deg[g]) ar[g] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg[g] + lane));
         }
       }
-      __syncthreads();
-      const int overflowed = s.overflow;  // only phase 1 writes it
-      // phase 2: candidates that still hold the slot's cost compete for the
-      // lowest arc index (deterministic tie-break).
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        if (cur[u].h != kKeyEmpty) {
-          if (t.LoadCost(cur[u].h) == cur[u].nk) atomicMin(t.ArcP(cur[u].h), cur[u].arc);
-          else cur[u].h = kKeyEmpty;
+      for (int g = 0; g < kGroup; ++g)
+        if (lane < deg[g])
+          FilterArc<EPS>(c, ar[g], static_cast<uint32_t>(abeg[g] + lane), s.it_cost[q0 + g],
+                         s.it_src[q0 + g]);
+      // tails of tokens with more than 64 arcs, four wave-rows in flight
+#pragma unroll 1
+      for (int g = 0; g < kGroup; ++g) {
+        if (deg[g] <= 64) continue;
+        const double cst = s.it_cost[q0 + g];
+        const uint32_t srcid = s.it_src[q0 + g];
+        for (int a0 = 64 + lane; a0 < deg[g]; a0 += 256) {
+          ArcRec tr[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (a0 + 64 * u < deg[g])
+              tr[u] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg[g] + a0 + 64 * u));
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (a0 + 64 * u < deg[g])
+              FilterArc<EPS>(c, tr[u], static_cast<uint32_t>(abeg[g] + a0 + 64 * u), cst, srcid);
         }
       }
-      __syncthreads();
-      // phase 3 (deferred to the top of the next batch, after this barrier):
-      // the lane whose arc won writes the back-pointer source.
-#pragma unroll
-      for (int u = 0; u < kU; ++u) prev[u] = cur[u];
-      if (overflowed) return false;
     }
+    __syncthreads();
+    KD_LAP(s, EPS ? 8 : 4);
   }
-#pragma unroll
-  for (int u = 0; u < kU; ++u)
-    if (prev[u].h != kKeyEmpty && t.LoadArc(prev[u].h) == prev[u].arc) t.src[prev[u].h] = prev[u].src;
-  __syncthreads();
-  return true;
+}
+
+// Insert phase: queue entries [q_begin, q_end), one per lane.  Relaxes the
+// destination's slot; the entry's destination word is replaced by the slot (or
+// kKeyEmpty if the entry lost to the final cutoff) for the resolve passes.
+template <bool LDS, bool EPS>
+__device__ __forceinline__ void Insert(const FrameCtx &c, const Table<LDS> &t, int q_begin,
+                                       int q_end, unsigned long long cutkey,
+                                       KD_G uint32_t *wl_out, int wl_out_idx) {
+  Shared &s = c.s;
+  for (int i = q_begin + threadIdx.x; i < q_end; i += kBlock) {
+    // A spill frame replays emitting entries whose destination word the aborted
+    // LDS attempt already replaced by a slot: take the state from the arc again.
+    const uint32_t k = (!LDS && !EPS) ? LoadArcRec(c.p.arcs, c.q_arc[i]).next : c.q_h[i];
+    const unsigned long long nk = c.q_nk[i];
+    uint32_t h = kKeyEmpty;
+    // emitting entries were queued under the running cutoff: apply the final one (:211);
+    // once the frame is known not to fit, stop probing a full table
+    if ((EPS || nk < cutkey) && !s.overflow) {
+      h = t.Claim(k);
+      if (h == kKeyEmpty) {
+        s.overflow = 1;
+      } else {
+        const unsigned long long old = atomicMin(t.CostP(h), nk);
+        bool push = false;
+        if (old == kCostDead) {  // the state's first token this frame
+          const int pos = atomicAdd(&s.n_live, 1);
+          if (static_cast<uint32_t>(pos) < t.FillLimit()) c.live[pos] = h;
+          else s.overflow = 1;
+          push = (k & kHasEps) != 0;  // every new token is expanded once (:63-65)
+          if constexpr (EPS) {
+            if (push) atomicOr(&t.bitmask[h >> 5], 1u << (h & 31));
+          }
+        } else if (EPS && old > nk && (k & kHasEps)) {  // re-queue on improvement, :97-113
+          const uint32_t bit = 1u << (h & 31);
+          push = !(atomicOr(&t.bitmask[h >> 5], bit) & bit);
+        }
+        if (push) wl_out[atomicAdd(&s.wl_count[wl_out_idx], 1)] = h;
+      }
+    }
+    c.q_h[i] = h;
+  }
 }
 
 // k-th smallest (0-based) of float(cost) over the input frontier: 4-pass
 // byte-wise radix select on order-preserving keys (std::nth_element in
 // faster-decoder.cc:298-321; tmp_array_ is std::vector<float>, :278).
-__device__ __forceinline__ float SelectKth(const FrameCtx &c, int k) {
-  Shared &s = c.s;
+// Rare (only when max_active / min_active bind).
+__device__ __forceinline__ float SelectKth(Shared *sp, const double *tok_cost, long long base_in,
+                                        int n_in, int k) {
+  Shared &s = *sp;
   const int tid = threadIdx.x, lane = tid & 63;
   uint32_t prefix = 0, pmask = 0;
   int kk = k;
   for (int shift = 24; shift >= 0; shift -= 8) {
     if (tid < 256) s.hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < c.n_in; i += kBlock) {
-      const uint32_t key = FloatKey(static_cast<float>(ToG(c.p.tok_cost)[c.base_in + i]));
+    for (int i = tid; i < n_in; i += kBlock) {
+      const uint32_t key = FloatKey(static_cast<float>(ToG(tok_cost)[base_in + i]));
       if ((key & pmask) == prefix) atomicAdd(&s.hist[(key >> shift) & 255], 1);
     }
     __syncthreads();
@@ -439,35 +486,55 @@ __device__ __forceinline__ float SelectKth(const FrameCtx &c, int k) {
   return KeyFloat(prefix);
 }
 
+// Best cost and best token of an arena block (used for the first frame of a
+// launch; later frames get them from the previous frame's compaction).
+__device__ __forceinline__ void FrontierStats(const FrameCtx &c) {
+  const SearchParams &p = c.p;
+  Shared &s = c.s;
+  const int tid = threadIdx.x;
+  unsigned long long mk = kCostDead;
+  int mi = -1;
+  for (int i = tid; i < c.n_in; i += kBlock) {
+    const unsigned long long k = CostKey(ToG(p.tok_cost)[c.base_in + i]);
+    if (k < mk) { mk = k; mi = i; }
+  }
+  const unsigned long long best = BlockMinU64(s, mk);
+  if (tid == 0) { s.f_best = best; s.best_deg = 0; s.best_abeg = 0; s.best_cost = 0.0; }
+  __syncthreads();
+  if (mi >= 0 && mk == best) {
+    const StateRec r = LoadState(p.states, static_cast<uint32_t>(ToG(p.tok_state)[c.base_in + mi]));
+    s.best_abeg = r.arc_begin;
+    s.best_deg = r.emit_end - r.arc_begin;
+    s.best_cost = KeyCost(best);
+  }
+  __syncthreads();
+}
+
 // GetCutoff, faster-decoder.cc:244-336, by value.
 __device__ __forceinline__ void GetCutoff(FrameCtx &c) {
   const SearchParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x;
-  unsigned long long mk = kCostDead;
-  for (int i = tid; i < c.n_in; i += kBlock) {
-    const unsigned long long k = CostKey(ToG(p.tok_cost)[c.base_in + i]);
-    mk = k < mk ? k : mk;
-  }
-  mk = BlockMinU64(s, mk);
-  const double best_cost = KeyCost(mk);
+  const double best_cost = KeyCost(s.f_best);
   const double beam_cutoff = best_cost + p.beam;
   if (p.max_active == INT_MAX && p.min_active == 0) {  // :249-272
     c.weight_cutoff = beam_cutoff;
     c.adaptive_beam = p.beam;
     return;
   }
-  int n_lt = 0, n_le = 0;
+  int lt = 0, le = 0;
   for (int i = tid; i < c.n_in; i += kBlock) {
     const double v = static_cast<float>(ToG(p.tok_cost)[c.base_in + i]);  // narrowed, :278
-    n_lt += v < beam_cutoff;
-    n_le += v <= beam_cutoff;
+    lt += v < beam_cutoff;
+    le += v <= beam_cutoff;
   }
-  n_lt = BlockSum(s, n_lt);
-  n_le = BlockSum(s, n_le);
+  if (lt) atomicAdd(&s.f_nlt, lt);
+  if (le) atomicAdd(&s.f_nle, le);
+  __syncthreads();
+  const int n_lt = s.f_nlt, n_le = s.f_nle;
   // tmp_array_[k] < x  <=>  #{v < x} >= k+1 ;  tmp_array_[k] > x  <=>  #{v <= x} <= k
   if (c.n_in > p.max_active && static_cast<long long>(n_lt) >= static_cast<long long>(p.max_active) + 1) {
-    const double max_active_cutoff = SelectKth(c, p.max_active);  // :297-309
+    const double max_active_cutoff = SelectKth(&s, p.tok_cost, c.base_in, c.n_in, p.max_active);  // :297-309
     c.adaptive_beam = max_active_cutoff - best_cost + p.beam_delta;
     c.weight_cutoff = max_active_cutoff;
     return;
@@ -475,7 +542,7 @@ __device__ __forceinline__ void GetCutoff(FrameCtx &c) {
   double min_active_cutoff = beam_cutoff;  // "not looser" unless proven below
   if (c.n_in > p.min_active) {             // :311-323
     if (p.min_active == 0) min_active_cutoff = best_cost;
-    else if (n_le <= p.min_active) min_active_cutoff = SelectKth(c, p.min_active);
+    else if (n_le <= p.min_active) min_active_cutoff = SelectKth(&s, p.tok_cost, c.base_in, c.n_in, p.min_active);
   } else {
     min_active_cutoff = __longlong_as_double(0x7FF0000000000000ll);
   }
@@ -488,86 +555,102 @@ __device__ __forceinline__ void GetCutoff(FrameCtx &c) {
   }
 }
 
-template <bool LDS>
-__device__ __forceinline__ void ClearTable(const Table<LDS> &t, Shared &s, int n_used) {
-  const int tid = threadIdx.x;
-  if constexpr (LDS) {
-#pragma unroll
-    for (int k = 0; k < kSlotsPerThread; ++k) {
-      const int h = k * kBlock + tid;
-      s.key[h] = kKeyEmpty;
-      s.cost[h] = kCostDead;
-      s.arc[h] = kArcNone;
-    }
-  } else {
-    for (int i = tid; i < n_used; i += kBlock) {
-      const uint32_t h = t.gused[i];
-      t.gkey[h] = kKeyEmpty;
-      t.gcost[h] = kCostDead;
-      t.garc[h] = kArcNone;
-    }
-  }
-  if (tid == 0) { s.fill = 0; s.overflow = 0; }
-  __syncthreads();
-}
-
-// One frame (frame >= 0) or InitDecoding (frame == -1).  Returns 0 on success,
-// 1 if the table overflowed (nothing committed; table left dirty), or a
-// KD_UTT_* bit on a fatal capacity error.
-template <bool LDS>
-__device__ __forceinline__ uint32_t RunFrame(FrameCtx &c, const Table<LDS> &t, int frame,
-                                             Counters &total_cnt, int &n_out_ret) {
+// Everything of a frame before the table is touched: cutoff, the best token's
+// bound, and the emitting filter.  Leaves the candidates in the queue
+// [0, s.q_n) and the exact cutoff in c.cutoff.
+__device__ __forceinline__ void FrameFront(FrameCtx &c, Counters &cnt) {
+  constexpr bool LDS_MODE = true;
+  (void)LDS_MODE;
   const SearchParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x;
-  Counters cnt;
+  GetCutoff(c);
+  KD_LAP(s, 1);
+  // Bound the next cutoff from the best token's arcs first (:176-189); it only
+  // shortens the queue, the final cutoff is the same.
+  {
+    unsigned long long mk = kCostInf;
+    const int bdeg = s.best_deg, babeg = s.best_abeg;
+    const double bcost = s.best_cost;
+    for (int a = tid; a < bdeg; a += kBlock) {
+      const ArcRec arc = LoadArcRec(p.arcs, static_cast<uint32_t>(babeg + a));
+      const float ll = c.ll_in_lds ? s.ll[arc.ilabel - 1] : c.ll_row[arc.ilabel - 1];
+      const float ac_cost = -1 * ll;
+      const unsigned long long k = CostKey(arc.weight + bcost + ac_cost);
+      mk = k < mk ? k : mk;
+    }
+    mk = WaveMinU64(mk);
+    if ((tid & 63) == 0 && mk != kCostInf) atomicMin(&s.min_new, mk);
+  }
+  KD_LAP(s, 2);
+  Table<true> none{s, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  Filter<true, false>(c, none, c.n_in, nullptr, cnt);
+  c.cutoff = KeyCost(s.min_new) + static_cast<double>(c.adaptive_beam);  // value of :240
+}
 
-  if (tid == 0) { s.min_new = kCostInf; s.wl_count[0] = 0; s.wl_count[1] = 0; }
+template <bool LDS>
+__device__ __forceinline__ void FullClear(const Table<LDS> &t, Shared &s) {
+  // only the LDS table is ever cleared wholesale (launch start, aborted frames)
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < kSlotsPerThread; ++k) {
+    const int h = k * kBlock + tid;
+    s.key[h] = kKeyEmpty;
+    s.cost[h] = kCostDead;
+    s.arc[h] = kArcNone;
+  }
+  __syncthreads();
+}
+
+// Clears the slots on the live list (and any claimed-but-unlisted slot is
+// impossible: a slot is listed by whoever gives it its first cost, and every
+// claimer relaxes the slot right after claiming it).
+template <bool LDS>
+__device__ __forceinline__ void ClearLive(const FrameCtx &c, const Table<LDS> &t, int n_live) {
+  for (int i = threadIdx.x; i < n_live; i += kBlock) {
+    const uint32_t h = c.live[i];
+    t.StoreKey(h, kKeyEmpty);
+    t.StoreCost(h, kCostDead);
+    t.StoreArc(h, kArcNone);
+  }
+}
+
+// The table half of a frame (frame >= 0) or of InitDecoding (frame == -1):
+// insert the emitting candidates queue[0, q_emit), run the epsilon closure,
+// resolve back-pointers and compact.  Returns 0 on success, 1 if the table,
+// the live list or the queue overflowed (nothing committed; table dirty), or a
+// KD_UTT_* bit on a fatal capacity error.
+template <bool LDS>
+__device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, int frame,
+                                              int q_emit, Counters &cnt) {
+  constexpr bool LDS_MODE = LDS;
+  (void)LDS_MODE;
+  const SearchParams &p = c.p;
+  Shared &s = c.s;
+  const int tid = threadIdx.x;
+  const unsigned long long cutkey = CostKey(c.cutoff);
+
   if (frame < 0) {
     if (tid == 0) {  // faster-decoder.cc:49-51: dummy arc into the start state, cost 0
       const StateRec r = LoadState(p.states, p.start);
-      const uint32_t k = static_cast<uint32_t>(p.start) | (r.arc_end > r.emit_end ? kHasEps : 0u);
+      const bool eps = r.arc_end > r.emit_end;
       const uint32_t h = t.Hash(static_cast<uint32_t>(p.start));
-      *t.KeyP(h) = k;
+      t.StoreKey(h, static_cast<uint32_t>(p.start) | (eps ? kHasEps : 0u));
       t.StoreCost(h, CostKey(0.0));
-      t.StoreArc(h, kArcNone);
-      t.src[h] = kSrcNone;
-      s.fill = 1;
-      if constexpr (!LDS) t.gused[0] = h;
+      c.live[0] = h;
+      s.n_live = 1;
+      if (eps) { c.wl0[0] = h; s.wl_count[0] = 1; }
     }
-    c.cutoff = static_cast<double>(FLT_MAX);  // :53
-    __syncthreads();
   } else {
-    GetCutoff(c);
-    __syncthreads();
-    if (!Expand<LDS, false>(c, t, c.n_in, nullptr, nullptr, 0, cnt)) return 1;
-    c.cutoff = KeyCost(s.min_new) + static_cast<double>(c.adaptive_beam);  // value of :240
-  }
-
-  // Drop tokens the final cutoff excludes (:211 with the final cutoff), seed
-  // the epsilon worklist with every surviving token that has epsilon arcs.
-  const unsigned long long cutkey = CostKey(c.cutoff);
-  const int n_used = s.fill;
-  {
-    auto visit = [&](uint32_t h) {
-      const uint32_t k = t.LoadKey(h);
-      if (k == kKeyEmpty) return;
-      const unsigned long long ck = t.LoadCost(h);
-      if (ck == kCostDead) return;
-      if (frame >= 0 && ck >= cutkey) { t.StoreCost(h, kCostDead); return; }
-      if (k & kHasEps) c.wl[0][atomicAdd(&s.wl_count[0], 1)] = h;
-    };
-    if constexpr (LDS) {
-#pragma unroll
-      for (int k = 0; k < kSlotsPerThread; ++k) visit(k * kBlock + tid);
-    } else {
-      for (int i = tid; i < n_used; i += kBlock) visit(t.gused[i]);
-    }
+    Insert<LDS, false>(c, t, 0, q_emit, cutkey, c.wl0, 0);
   }
   __syncthreads();
+  KD_LAP(s, 5);
+  if (s.overflow) return 1;
 
   // ProcessNonemitting to a fixpoint (:59-119)
-  int cur = 0;
+  int cur = 0, q_begin = q_emit;
+  KD_G uint32_t *wl_a = c.wl0, *wl_b = c.wl1;
   while (true) {
     const int n_items = s.wl_count[cur];
     if (n_items == 0) break;
@@ -575,97 +658,112 @@ __device__ __forceinline__ uint32_t RunFrame(FrameCtx &c, const Table<LDS> &t, i
     for (int w = tid; w < words; w += kBlock) t.bitmask[w] = 0;
     if (tid == 0) s.wl_count[cur ^ 1] = 0;
     __syncthreads();
-    if (!Expand<LDS, true>(c, t, n_items, c.wl[cur], c.wl[cur ^ 1], cur ^ 1, cnt)) return 1;
+    KD_LAP(s, 6);
+    Filter<LDS, true>(c, t, n_items, wl_a, cnt);
+    const int q_end = s.q_n;
+    if (q_end > c.q_cap) return 1;
+    Insert<LDS, true>(c, t, q_begin, q_end, 0, wl_b, cur ^ 1);
+    __syncthreads();
+    KD_LAP(s, 9);
+    if (s.overflow) return 1;
+    q_begin = q_end;
     cur ^= 1;
+    KD_G uint32_t *tmp = wl_a;
+    wl_a = wl_b;
+    wl_b = tmp;
   }
-  if (s.overflow) return 1;
 
-  // Compaction: live slots -> arena block `frame + 1`.
-  const int n_slots_used = s.fill;
-  int my_live = 0;
-  uint32_t live_bits = 0;
-  if constexpr (LDS) {
+  // Resolve R1: entries that hold their slot's final cost compete for the lowest
+  // arc index.  This lane's first entries stay in registers for R2.
+  const int n_q = q_begin;
+  const int n_out = s.n_live;
+  constexpr int kQRegs = 4;
+  uint32_t lg_h[kQRegs], lg_arc[kQRegs];
 #pragma unroll
-    for (int k = 0; k < kSlotsPerThread; ++k) {
-      const int h = k * kBlock + tid;
-      if (s.key[h] != kKeyEmpty && s.cost[h] != kCostDead) { live_bits |= 1u << k; my_live++; }
+  for (int u = 0; u < kQRegs; ++u) {
+    const int i = u * kBlock + tid;
+    lg_h[u] = kKeyEmpty;
+    lg_arc[u] = 0;
+    if (i < n_q) {
+      const uint32_t h = c.q_h[i];
+      if (h != kKeyEmpty && t.LoadCost(h) == c.q_nk[i]) {
+        const uint32_t aidx = c.q_arc[i];
+        atomicMin(t.ArcP(h), aidx);
+        lg_h[u] = h;
+        lg_arc[u] = aidx;
+      }
     }
-  } else {
-    for (int i = tid; i < n_slots_used; i += kBlock)
-      if (t.LoadCost(t.gused[i]) != kCostDead) my_live++;
   }
-  int n_out;
-  const int off = BlockExclScan(s, my_live, n_out);
+  for (int i = kQRegs * kBlock + tid; i < n_q; i += kBlock) {
+    const uint32_t h = c.q_h[i];
+    if (h != kKeyEmpty && t.LoadCost(h) == c.q_nk[i]) atomicMin(t.ArcP(h), c.q_arc[i]);
+  }
   if (tid == 0) {
-    const unsigned long long b =
-        atomicAdd(ToFlat(ToG(p.arena_top)), static_cast<unsigned long long>(n_out));
-    s.base_out = (b + n_out > p.arena_cap) ? -1 : static_cast<long long>(b);
+    // each utterance owns arena[utt * arena_cap, (utt + 1) * arena_cap)
+    const long long b = s.arena_next;
+    const bool full =
+        b + n_out > static_cast<long long>(c.utt + 1) * static_cast<long long>(p.arena_cap);
+    s.base_out = full ? -1 : b;
+    if (!full) s.arena_next = b + n_out;
+    s.f_best_next = kCostDead;
+    s.best_deg = 0;
+    s.best_abeg = 0;
+    s.best_cost = 0.0;
   }
   __syncthreads();
+  KD_LAP(s, 10);
   const long long base_out = s.base_out;
   if (base_out < 0) return KD_UTT_ARENA_FULL;
+  // C1: live list -> (state, cost); a slot's key word now holds its index in the block.
   {
-    int idx = off;
-    if constexpr (LDS) {
-#pragma unroll
-      for (int k = 0; k < kSlotsPerThread; ++k) {
-        if (live_bits & (1u << k)) {
-          const int h = k * kBlock + tid;
-          const long long g = base_out + idx;
-          ToG(p.tok_state)[g] = static_cast<int32_t>(s.key[h] & kStateMask);
-          ToG(p.tok_cost)[g] = KeyCost(s.cost[h]);
-          const uint32_t a = s.arc[h];
-          ToG(p.tok_arc)[g] = static_cast<int32_t>(a);
-          if (a == kArcNone) live_bits |= 1u << (16 + k);  // start token
-          s.arc[h] = static_cast<uint32_t>(idx);
-          idx++;
-        }
+    unsigned long long my_min = kCostDead;
+    for (int i = tid; i < n_out; i += kBlock) {
+      const uint32_t h = c.live[i];
+      const unsigned long long ck = t.LoadCost(h);
+      const long long g = base_out + i;
+      ToG(p.tok_state)[g] = static_cast<int32_t>(t.LoadKey(h) & kStateMask);
+      ToG(p.tok_cost)[g] = KeyCost(ck);
+      if (t.LoadArc(h) == kArcNone) {  // the start token
+        ToG(p.tok_prev)[g] = -1;
+        ToG(p.tok_arc)[g] = -1;
       }
-    } else {
-      for (int i = tid; i < n_slots_used; i += kBlock) {
-        const uint32_t h = t.gused[i];
-        const unsigned long long ck = t.LoadCost(h);
-        if (ck != kCostDead) {
-          const long long g = base_out + idx;
-          ToG(p.tok_state)[g] = static_cast<int32_t>(t.LoadKey(h) & kStateMask);
-          ToG(p.tok_cost)[g] = KeyCost(ck);
-          ToG(p.tok_arc)[g] = static_cast<int32_t>(t.LoadArc(h));
-          t.gidx[h] = static_cast<uint32_t>(idx);
-          idx++;
-        }
-      }
+      t.StoreKey(h, static_cast<uint32_t>(i));
+      my_min = ck < my_min ? ck : my_min;
     }
+    my_min = WaveMinU64(my_min);
+    if ((tid & 63) == 0 && my_min != kCostDead) atomicMin(&s.f_best_next, my_min);
   }
   __syncthreads();
+  KD_LAP(s, 11);
+  // R2: the winning entry of each slot writes the back-pointer.
   {
-    int idx = off;
-    auto prev_of = [&](uint32_t h, bool is_start) -> int32_t {
-      if (is_start) return -1;
-      const uint32_t sr = t.src[h];
-      if (sr & kSrcEps) {
-        const uint32_t hs = sr & ~kSrcEps;
-        const uint32_t si = LDS ? s.arc[hs] : t.gidx[hs];
-        return static_cast<int32_t>(base_out + si);
-      }
-      return static_cast<int32_t>(c.base_in + sr);
+    auto write_bp = [&](uint32_t h, uint32_t aidx, int i) {
+      const long long g = base_out + t.LoadKey(h);
+      const uint32_t sr = c.q_src[i];
+      const long long prev = (sr & kSrcEps) ? base_out + t.LoadKey(sr & ~kSrcEps) : c.base_in + sr;
+      ToG(p.tok_prev)[g] = static_cast<int32_t>(prev);
+      ToG(p.tok_arc)[g] = static_cast<int32_t>(aidx);
     };
-    if constexpr (LDS) {
 #pragma unroll
-      for (int k = 0; k < kSlotsPerThread; ++k) {
-        if (live_bits & (1u << k)) {
-          ToG(p.tok_prev)[base_out + idx] = prev_of(k * kBlock + tid, (live_bits >> (16 + k)) & 1u);
-          idx++;
-        }
-      }
-    } else {
-      for (int i = tid; i < n_slots_used; i += kBlock) {
-        const uint32_t h = t.gused[i];
-        if (t.LoadCost(h) != kCostDead) {
-          const long long g = base_out + idx;
-          ToG(p.tok_prev)[g] = prev_of(h, ToG(p.tok_arc)[g] == static_cast<int32_t>(kArcNone));
-          idx++;
-        }
-      }
+    for (int u = 0; u < kQRegs; ++u)
+      if (lg_h[u] != kKeyEmpty && t.LoadArc(lg_h[u]) == lg_arc[u])
+        write_bp(lg_h[u], lg_arc[u], u * kBlock + tid);
+    for (int i = kQRegs * kBlock + tid; i < n_q; i += kBlock) {
+      const uint32_t h = c.q_h[i];
+      if (h == kKeyEmpty) continue;
+      const uint32_t aidx = c.q_arc[i];
+      if (t.LoadCost(h) == c.q_nk[i] && t.LoadArc(h) == aidx) write_bp(h, aidx, i);
+    }
+  }
+  // next frame's best token: fetch its arc range now, off the critical path
+  const unsigned long long best = s.f_best_next;
+  for (int i = tid; i < n_out; i += kBlock) {
+    const uint32_t h = c.live[i];
+    if (t.LoadCost(h) == best) {
+      const StateRec r = LoadState(p.states, static_cast<uint32_t>(ToG(p.tok_state)[base_out + i]));
+      s.best_abeg = r.arc_begin;
+      s.best_deg = r.emit_end - r.arc_begin;
+      s.best_cost = KeyCost(best);
     }
   }
   if (tid == 0) {
@@ -673,118 +771,197 @@ __device__ __forceinline__ uint32_t RunFrame(FrameCtx &c, const Table<LDS> &t, i
     ToG(p.frame_base)[fi] = base_out;
     ToG(p.frame_count)[fi] = n_out;
   }
+  // fold this frame's counters into the launch totals
+  if (cnt.tokens_expanded) atomicAdd(&s.frame_cnt[0], cnt.tokens_expanded);
+  if (cnt.eps_exp) atomicAdd(&s.frame_cnt[1], cnt.eps_exp);
+  if (cnt.arcs_scanned) atomicAdd(&s.frame_cnt[2], cnt.arcs_scanned);
+  if (cnt.eps_arcs) atomicAdd(&s.frame_cnt[3], cnt.eps_arcs);
   __syncthreads();
-  total_cnt.tokens_expanded += cnt.tokens_expanded;
-  total_cnt.arcs_scanned += cnt.arcs_scanned;
-  total_cnt.arcs_kept += cnt.arcs_kept;
-  total_cnt.eps_arcs += cnt.eps_arcs;
-  total_cnt.eps_exp += cnt.eps_exp;
-  n_out_ret = n_out;
+  KD_LAP(s, 12);
+  ClearLive<LDS>(c, t, n_out);
+  if (tid == 0) {
+    s.stat[KD_STAT_TOKENS_EXPANDED] += s.frame_cnt[0];
+    s.stat[KD_STAT_EPS_EXPANSIONS] += s.frame_cnt[1];
+    s.stat[KD_STAT_ARCS_SCANNED] += s.frame_cnt[2];
+    s.stat[KD_STAT_EPS_ARCS_SCANNED] += s.frame_cnt[3];
+    s.stat[KD_STAT_ARCS_KEPT] += q_emit;
+    s.stat[KD_STAT_TOKENS_OUT] += n_out;
+    if (n_out > s.stat[KD_STAT_MAX_TOKENS]) s.stat[KD_STAT_MAX_TOKENS] = n_out;
+    if (frame >= 0) {
+      s.stat[KD_STAT_FRAMES] += 1;
+      s.stat[KD_STAT_TOKENS_IN] += c.n_in;
+    }
+    if (!LDS) s.stat[KD_STAT_SPILL_FRAMES] += 1;
+    s.f_best = best;
+  }
+  c.base_in = base_out;
+  c.n_in = n_out;
   return 0;
 }
 
-__device__ __forceinline__ long long BlockSumLL(Shared &s, long long v) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  if (lane == 0) s.red64[wave] = static_cast<unsigned long long>(v);
+__device__ __forceinline__ void InitCtx(FrameCtx &c, const SearchParams &p, int utt) {
+  const long long gslots = 1ll << p.g_log2_slots;
+  c.wl0 = ToG(p.g_wl) + (2ll * utt) * gslots;
+  c.wl1 = ToG(p.g_wl) + (2ll * utt + 1) * gslots;
+  c.live = ToG(p.g_used) + utt * gslots;
+  c.q_cap = static_cast<int>(2 * gslots);
+  c.q_h = ToG(p.g_log_h) + utt * 2 * gslots;
+  c.q_arc = ToG(p.g_log_arc) + utt * 2 * gslots;
+  c.q_src = ToG(p.g_log_src) + utt * 2 * gslots;
+  c.q_nk = ToG(p.g_log_nk) + utt * 2 * gslots;
+  c.ll_in_lds = p.num_cols <= kVmax;
+}
+
+// Spill path.  Inlined (a call would force the caller's state through scratch
+// memory); it sits behind an unlikely branch so block placement keeps its code
+// away from the hot path's instruction-cache lines.
+__device__ __forceinline__ uint32_t FrameBackSpill(const SearchParams &p, Shared *sp, int utt,
+                                                long long base_in, int n_in, double cutoff,
+                                                int frame, int q_emit, int n_expanded,
+                                                int n_arcs) {
+  Shared &s = *sp;
+  FrameCtx c{p, s, utt};
+  InitCtx(c, p, utt);
+  c.base_in = base_in;
+  c.n_in = n_in;
+  c.cutoff = cutoff;
+  Counters cnt;
+  cnt.tokens_expanded = n_expanded;
+  cnt.arcs_scanned = n_arcs;
+  const long long gslots = 1ll << p.g_log2_slots;
+  Table<false> tg{s, ToG(p.g_key) + c.utt * gslots, ToG(p.g_cost) + c.utt * gslots,
+                  ToG(p.g_arc) + c.utt * gslots, reinterpret_cast<uint32_t *>(s.cost),
+                  p.g_log2_slots, static_cast<uint32_t>(gslots - 1)};
+  uint32_t r = FrameBack<false>(c, tg, frame, q_emit, cnt);
+  if (r != 0) {  // leave the global table clean for later frames
+    __syncthreads();
+    const int used = s.n_live < static_cast<int>(tg.FillLimit()) ? s.n_live
+                                                                 : static_cast<int>(tg.FillLimit());
+    ClearLive<false>(c, tg, used);
+  }
   __syncthreads();
-  long long r = 0;
-#pragma unroll
-  for (int w = 0; w < kWaves; ++w) r += static_cast<long long>(s.red64[w]);
-  __syncthreads();
-  return r;
+  return r == 1 ? static_cast<uint32_t>(KD_UTT_TABLE_FULL) : r;
 }
 
 __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Shared &s = *reinterpret_cast<Shared *>(smem);
   const int tid = threadIdx.x, utt = blockIdx.x;
-  const long long gslots = 1ll << p.g_log2_slots;
+  constexpr bool LDS_MODE = true;
+  (void)LDS_MODE;
 
-  Table<true> tl{s, nullptr, nullptr, nullptr, ToG(p.g_src) + utt * gslots, nullptr, nullptr,
-                 s.bitmask, kLog2Slots, kSlots - 1};
-  Table<false> tg{s, ToG(p.g_key) + utt * gslots, ToG(p.g_cost) + utt * gslots,
-                  ToG(p.g_arc) + utt * gslots, ToG(p.g_src) + utt * gslots,
-                  ToG(p.g_idx) + utt * gslots, ToG(p.g_used) + utt * gslots,
-                  reinterpret_cast<uint32_t *>(s.cost), p.g_log2_slots,
-                  static_cast<uint32_t>(gslots - 1)};
+  Table<true> tl{s, nullptr, nullptr, nullptr, s.bitmask, kLog2Slots, kSlots - 1};
   FrameCtx c{p, s, utt};
-  c.wl[0] = ToG(p.g_wl) + (2ll * utt) * gslots;
-  c.wl[1] = ToG(p.g_wl) + (2ll * utt + 1) * gslots;
-  c.ll_in_lds = p.num_cols <= kVmax;
+  InitCtx(c, p, utt);
 
-  if (tid == 0) s.stop = 0;
-  ClearTable<true>(tl, s, 0);
+  if (tid < KD_NUM_STATS) s.stat[tid] = 0;
+  if (tid < 4) s.frame_cnt[tid] = 0;
+#ifdef KD_PROFILE
+  if (tid < kProfSlots) s.cyc[tid] = 0;
+  if (tid == 0) s.lap_last = static_cast<long long>(__builtin_amdgcn_s_memtime());
+#endif
+  FullClear<true>(tl, s);
 
   UttDesc ud;
   ud.ll = ToG(p.utt)[utt].ll;
   ud.offset = ToG(p.utt)[utt].offset;
   ud.target = ToG(p.utt)[utt].target;
-  Counters cnt;
-  long long st_frames = 0, st_tokens_in = 0, st_tokens_out = 0, st_max = 0, st_spill = 0;
   uint32_t err = ToG(p.status)[utt];
   int frame = p.do_init ? -1 : ToG(p.frames_decoded)[utt];
   const int target = p.do_init ? 0 : ud.target;
 
+  c.base_in = 0;
+  c.n_in = 0;
+  if (tid == 0)
+    s.arena_next = p.do_init ? static_cast<long long>(utt) * static_cast<long long>(p.arena_cap)
+                             : static_cast<long long>(ToG(p.arena_top)[utt]);
+  if (frame >= 0 && frame < target) {
+    const long long fi = static_cast<long long>(utt) * (p.max_frames + 1) + frame;
+    c.base_in = ToG(p.frame_base)[fi];
+    c.n_in = ToG(p.frame_count)[fi];
+    FrontierStats(c);
+  }
+  __syncthreads();
+
   while (err == 0 && frame < target) {
+    KD_LAP(s, 13);
+    Counters cnt;
+    if (tid == 0) {
+      s.min_new = kCostInf;
+      s.wl_count[0] = 0;
+      s.wl_count[1] = 0;
+      s.q_n = 0;
+      s.n_live = 0;
+      s.overflow = 0;
+      s.f_nlt = 0;
+      s.f_nle = 0;
+    }
     if (frame >= 0) {
-      const long long fi = static_cast<long long>(utt) * (p.max_frames + 1) + frame;
-      c.base_in = ToG(p.frame_base)[fi];
-      c.n_in = ToG(p.frame_count)[fi];
       c.ll_row = ToG(ud.ll) + static_cast<long long>(frame - ud.offset) * p.row_stride;
       if (c.ll_in_lds)
         for (int v = tid; v < p.num_cols; v += kBlock) s.ll[v] = c.ll_row[v];
-      __syncthreads();
-    } else {
-      c.base_in = 0;
-      c.n_in = 0;
     }
-    int n_out = 0;
-    uint32_t r = 1;
-    // a frontier this large cannot fit the LDS table after expansion
-    if (c.n_in <= kLdsFillLimit) r = RunFrame<true>(c, tl, frame, cnt, n_out);
-    if (r == 1) {
-      __syncthreads();
-      ClearTable<true>(tl, s, 0);  // also resets fill/overflow; s.cost becomes the spill bitmask
-      r = RunFrame<false>(c, tg, frame, cnt, n_out);
-      const int used = s.fill < static_cast<int>(gslots) ? s.fill : static_cast<int>(gslots);
-      __syncthreads();
-      ClearTable<false>(tg, s, used);
-      ClearTable<true>(tl, s, 0);
-      st_spill++;
-      if (r == 1) r = KD_UTT_TABLE_FULL;
+    __syncthreads();
+    KD_LAP(s, 0);
+    int q_emit = 0;
+    if (frame >= 0) {
+      FrameFront(c, cnt);
+      q_emit = s.q_n;
     } else {
-      ClearTable<true>(tl, s, 0);
+      c.cutoff = static_cast<double>(FLT_MAX);  // faster-decoder.cc:53
+    }
+    uint32_t r = 1;
+    // the queue is a complete journal of the frame's inserts: a frame that does
+    // not fit the LDS table is replayed from it into the global table
+    if (q_emit <= c.q_cap) {
+      // a frontier this large will not fit the LDS table after expansion either
+      if (c.n_in <= kLdsFillLimit) r = FrameBack<true>(c, tl, frame, q_emit, cnt);
+      if (__builtin_expect(r == 1, 0)) {
+        __syncthreads();
+        KD_LAP(s, 15);
+        FullClear<true>(tl, s);  // s.cost becomes the spill bitmask
+        if (tid == 0) {
+          s.q_n = q_emit;
+          s.n_live = 0;
+          s.overflow = 0;
+          s.wl_count[0] = 0;
+          s.wl_count[1] = 0;
+        }
+        __syncthreads();
+        // (epsilon counters of the aborted closure are dropped)
+        r = FrameBackSpill(p, &s, utt, c.base_in, c.n_in, c.cutoff, frame, q_emit,
+                           cnt.tokens_expanded, cnt.arcs_scanned);
+        if (r == 0) {
+          c.base_in = s.base_out;
+          c.n_in = s.n_live;
+        }
+        FullClear<true>(tl, s);
+        KD_LAP(s, 14);
+      }
+    } else {
+      r = KD_UTT_TABLE_FULL;
     }
     if (r != 0) { err |= r; break; }
-    if (frame >= 0) {
-      st_frames++;
-      st_tokens_in += c.n_in;
-    }
-    st_tokens_out += n_out;
-    st_max = n_out > st_max ? n_out : st_max;
     frame++;
+    __syncthreads();
+    if (tid < 4) s.frame_cnt[tid] = 0;
   }
 
-  const long long exp_sum = BlockSumLL(s, cnt.tokens_expanded);
-  const long long kept_sum = BlockSumLL(s, cnt.arcs_kept);
-  const long long eps_exp_sum = BlockSumLL(s, cnt.eps_exp);
+  __syncthreads();
   if (tid == 0) {
     ToG(p.frames_decoded)[utt] = frame < 0 ? -1 : frame;
     ToG(p.status)[utt] = err;
-    KD_G long long *st = ToG(p.stats) + static_cast<long long>(utt) * KD_NUM_STATS;
-    st[KD_STAT_FRAMES] += st_frames;
-    st[KD_STAT_TOKENS_IN] += st_tokens_in;
-    st[KD_STAT_TOKENS_EXPANDED] += exp_sum;
-    st[KD_STAT_ARCS_SCANNED] += cnt.arcs_scanned;
-    st[KD_STAT_ARCS_KEPT] += kept_sum;
-    st[KD_STAT_TOKENS_OUT] += st_tokens_out;
-    st[KD_STAT_EPS_ARCS_SCANNED] += cnt.eps_arcs;
-    st[KD_STAT_EPS_EXPANSIONS] += eps_exp_sum;
-    st[KD_STAT_MAX_TOKENS] = st_max > st[KD_STAT_MAX_TOKENS] ? st_max : st[KD_STAT_MAX_TOKENS];
-    st[KD_STAT_SPILL_FRAMES] += st_spill;
+    ToG(p.arena_top)[utt] = static_cast<unsigned long long>(s.arena_next);
   }
+  if (tid < KD_NUM_STATS) {
+    KD_G long long *st = ToG(p.stats) + static_cast<long long>(utt) * kStatStride;
+    if (tid == KD_STAT_MAX_TOKENS) st[tid] = s.stat[tid] > st[tid] ? s.stat[tid] : st[tid];
+    else st[tid] += s.stat[tid];
+  }
+#ifdef KD_PROFILE
+  if (tid < kProfSlots)
+    ToG(p.stats)[static_cast<long long>(utt) * kStatStride + KD_NUM_STATS + tid] += s.cyc[tid];
+#endif
 }
 
 }  // namespace

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkd_hip.so")
+LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("KD_HIP_LIB", "libkd_hip.so"))
 
 INT_MAX = 2**31 - 1
 KD_MEM_HOST, KD_MEM_DEVICE = 0, 1
@@ -29,7 +29,7 @@ SYMBOLS = (
     "kd_batch_advance_async", "kd_batch_sync", "kd_batch_num_frames_decoded",
     "kd_batch_status", "kd_batch_reached_final", "kd_batch_best_path_prepare",
     "kd_batch_best_path_copy", "kd_batch_frame_tokens", "kd_batch_stats",
-    "kd_batch_last_kernel_ms", "kd_batch_device_bytes",
+    "kd_batch_last_kernel_ms", "kd_batch_device_bytes", "kd_batch_phase_cycles",
 )
 
 
@@ -96,6 +96,7 @@ def lib():
     L.kd_batch_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.kd_batch_device_bytes.argtypes = [C.c_void_p]
     L.kd_batch_device_bytes.restype = C.c_size_t
+    L.kd_batch_phase_cycles.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int64)]
     _lib = L
     return L
 
@@ -277,6 +278,11 @@ class Batch:
     def stats(self):
         out = np.zeros((self.batch, len(STAT_NAMES)), np.int64)
         _check(lib().kd_batch_stats(self.h, out))
+        return out
+
+    def phase_cycles(self):
+        out = np.zeros((self.batch, 16), np.int64)
+        _check(lib().kd_batch_phase_cycles(self.h, out))
         return out
 
     def last_kernel_ms(self):

@@ -1,0 +1,74 @@
+"""Utterance sharding across the GPUs of one node and the single result gather.
+
+Utterances never interact and the graph is read-only, so the batch is split
+contiguously over ranks, every rank holds its own copy of the graph, and there
+is no collective on the search path.  The only exchange is the gather of the
+finished results to rank 0: an all_gather of payload sizes followed by one
+gather of the packed int32 payload (RCCL when the backend is "nccl", gloo in the
+CPU tests).  SURVEY.md section 8(e).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous [lo, hi) slice of `total` utterances owned by `rank`."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_paths(paths):
+    """List of (ilabel, olabel) int32 arrays -> one int32 payload.
+
+    Layout: [n_utts, len_0 .. len_{n-1}, ilabel_0.., olabel_0.., ilabel_1.., ...]."""
+    lens = np.asarray([len(p[0]) for p in paths], np.int32)
+    parts = [np.asarray([len(paths)], np.int32), lens]
+    for il, ol in paths:
+        parts.append(np.asarray(il, np.int32))
+        parts.append(np.asarray(ol, np.int32))
+    return np.concatenate(parts) if parts else np.zeros(1, np.int32)
+
+
+def unpack_paths(buf):
+    n = int(buf[0])
+    lens = buf[1:1 + n]
+    pos = 1 + n
+    out = []
+    for k in lens:
+        k = int(k)
+        out.append((buf[pos:pos + k].copy(), buf[pos + k:pos + 2 * k].copy()))
+        pos += 2 * k
+    return out
+
+
+def gather_paths(paths, dst=0, group=None):
+    """Gathers every rank's best paths to `dst` in rank order; returns the
+    concatenated list there and None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return list(paths)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    payload = torch.from_numpy(pack_paths(paths)).to(dev)
+    size = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(size) for _ in range(world)]
+    dist.all_gather(sizes, size, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    padded = torch.zeros(mx, dtype=torch.int32, device=dev)
+    padded[:payload.numel()] = payload
+    if rank == dst:
+        bufs = [torch.zeros(mx, dtype=torch.int32, device=dev) for _ in range(world)]
+        dist.gather(padded, bufs, dst=dst, group=group)
+        out = []
+        for r in range(world):
+            out.extend(unpack_paths(bufs[r][:sizes[r]].cpu().numpy()))
+        return out
+    dist.gather(padded, None, dst=dst, group=group)
+    return None
