@@ -58,6 +58,23 @@ def algorithmic_bytes(stats, V):
         max_tokens=int(stats[:, 8].max()), spill_frames=int(s[9]))
 
 
+def profiled_traffic(workload_desc):
+    """HBM bytes per launch from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_summary.json, written by tools/summarize_profile.py from separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes of this same command); None if there is
+    no summary for this workload."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("bench_line_under_profiler", {}).get("config", {}).get("workload") == workload_desc:
+            best = (d["hbm_bytes_per_launch"], os.path.basename(path))
+    return best
+
+
 def cpu_baseline(g, lps, opts, gpu_paths, budget_s=20.0):
     """The oracle's reference-order FasterDecoder (policy 0), one thread, on a
     bounded sample of the same utterances; also checks 1-best parity."""
@@ -155,6 +172,7 @@ def main():
         stats = bt.stats()  # counters of the last step (reset by InitDecoding)
         alg_bytes, per_frame = algorithmic_bytes(stats, V)
         k_ms = float(np.mean(kernel_ms))
+        traffic = profiled_traffic(wl["desc"])
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         frames_total = world * B * T * args.steps
         out = {
@@ -175,7 +193,9 @@ def main():
                        "graph_arcs": info["arcs"], "batch_per_gpu": B, "frames": T,
                        "decoder_frames_per_s": frames_total / elapsed, **per_frame},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
                          "kernel": "SearchKernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "setup_s": setup_s,

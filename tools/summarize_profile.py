@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 CSVs that a GPU run left under gpurun_out/ into the
+committed summaries under profiles/ (per round).
+
+    python tools/summarize_profile.py r01
+
+Expects gpurun_out/prof_<round>_trace (--kernel-trace --stats),
+gpurun_out/prof_<round>_fetch (--pmc FETCH_SIZE) and gpurun_out/prof_<round>_write
+(--pmc WRITE_SIZE), each produced by its own rocprofv3 run of
+`python3 bench.py --no-cpu` as MI355X_MICROARCH.md prescribes (FETCH_SIZE and
+WRITE_SIZE do not fit one pass).  HBM bytes per launch follow that guide's
+gfx950 rule: FETCH_SIZE is in KiB and tallies 128-byte read requests at 64
+bytes, so reads are 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 is exact.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = "SearchKernel"
+
+
+def one(pattern):
+    hits = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
+    if not hits:
+        raise SystemExit(f"missing gpurun_out/{pattern}")
+    return hits[0]
+
+
+def counter(path, name):
+    rows = [r for r in csv.DictReader(open(path))
+            if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name]
+    # the search kernel is launched once for InitDecoding (tiny) and once per step
+    vals = sorted(float(r["Counter_Value"]) for r in rows)
+    big = [v for v in vals if v > 0.5 * vals[-1]]
+    return sum(big) / len(big), len(big)
+
+
+def main():
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    stats = one(f"prof_{rnd}_trace/*/*_kernel_stats.csv")
+    trace = one(f"prof_{rnd}_trace/*/*_kernel_trace.csv")
+    shutil.copy(stats, os.path.join(out, f"{rnd}_kernel_stats.csv"))
+    durs = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+                  for r in csv.DictReader(open(trace)) if KERNEL in r["Kernel_Name"])
+    adv = [d for d in durs if d > 0.5 * durs[-1]]
+    fetch_kb, nf = counter(one(f"prof_{rnd}_fetch/*/*_counter_collection.csv"), "FETCH_SIZE")
+    write_kb, nw = counter(one(f"prof_{rnd}_write/*/*_counter_collection.csv"), "WRITE_SIZE")
+    bench = {}
+    bj = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_trace.json")
+    if os.path.exists(bj):
+        txt = open(bj).read().strip().splitlines()
+        if txt:
+            bench = json.loads(txt[-1])
+    summary = {
+        "round": rnd,
+        "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu "
+                   "(+ one run each with --pmc FETCH_SIZE / --pmc WRITE_SIZE)",
+        "kernel": KERNEL,
+        "advance_launches": len(adv),
+        "avg_launch_ms": sum(adv) / len(adv),
+        "min_launch_ms": adv[0], "max_launch_ms": adv[-1],
+        "FETCH_SIZE_KiB_per_launch": fetch_kb,
+        "WRITE_SIZE_KiB_per_launch": write_kb,
+        "hbm_read_bytes_per_launch": 2 * fetch_kb * 1024,
+        "hbm_write_bytes_per_launch": write_kb * 1024,
+        "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
+        "note": "reads use the guide's gfx950 x2 FETCH_SIZE correction, calibrated there on wide "
+                "coalesced 16 B/lane streams; this kernel's reads are 16 B/lane gathers, so the "
+                "absolute read figure is an upper estimate (raw counter is half of it)",
+        "bench_line_under_profiler": bench,
+    }
+    with open(os.path.join(out, f"{rnd}_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    print(json.dumps({k: v for k, v in summary.items() if k != "bench_line_under_profiler"}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
