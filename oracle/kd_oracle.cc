@@ -756,6 +756,7 @@ struct Lattice {
   std::vector<int32_t> final_state;
   std::vector<float> final_graph, final_ac;
   std::vector<int32_t> state_frame;  // frame-plus-one of each state (extra info)
+  std::vector<int32_t> state_graph;  // graph state of each lattice state (extra info)
 };
 
 // kaldi-math.h:36-44
@@ -782,6 +783,7 @@ struct LatticeSimpleDecoder {
   };
   struct Token {
     float tot_cost, extra_cost; ForwardLink *links; Token *next;
+    int32_t state = -1;  // graph state (not in the reference's Token; used only to label output)
     void DeleteForwardLinks() {
       for (ForwardLink *l = links, *m; l != nullptr; l = m) { m = l->next; delete l; }
       links = nullptr;
@@ -829,6 +831,7 @@ struct LatticeSimpleDecoder {
     if (g.start < 0) throw std::runtime_error("graph has no start state");
     active_toks.resize(1);
     Token *start_tok = new Token{0.0f, 0.0f, nullptr, nullptr};
+    start_tok->state = g.start;
     active_toks[0].toks = start_tok;
     cur_toks[g.start] = start_tok;
     num_toks++;
@@ -851,6 +854,7 @@ struct LatticeSimpleDecoder {
     auto it = cur_toks.find(state);
     if (it == cur_toks.end()) {
       Token *nt = new Token{tot_cost, 0.0f, nullptr, toks};
+      nt->state = state;
       toks = nt;
       num_toks++;
       cur_toks[state] = nt;
@@ -1080,6 +1084,7 @@ struct LatticeSimpleDecoder {
       for (Token *tok = active_toks[f].toks; tok != nullptr; tok = tok->next) {
         tok_map[tok] = out->num_states++;
         out->state_frame.push_back(f);
+        out->state_graph.push_back(tok->state);
       }
       if (f == 0 && out->num_states > 0) out->start = out->num_states - 1;
     }
@@ -1111,6 +1116,278 @@ struct LatticeSimpleDecoder {
       }
     }
     return cur_state != 0;
+  }
+};
+
+
+// ---------------------------------------------------------------------------
+// Canonical (order-free) lattice decoder: what the GPU implements.
+//
+// LatticeSimpleDecoder's semantics (lattice-simple-decoder.cc) without its order
+// dependence: per frame the emitting cutoff is the value the reference's running
+// cutoff ends at (min tot_cost + beam, :386-390), every arc with tot_cost below
+// it becomes a forward link (:393-398), a token's cost is the min over its
+// incoming links, the epsilon closure links every arc with cur + graph < cutoff
+// from each token's final cost (:164-180), and all pruning happens once, exactly
+// (delta = 0), in FinalizeDecoding -- intermediate PruneActiveTokens calls only
+// ever remove links the final pass removes too (:198-305).  Costs are float with
+// the reference's association (cur + ac + graph, :383-385; cur + graph, :170-172).
+//
+// With max_active / min_active set this is the LatticeFasterDecoder the
+// reference only declares (lattice-faster-decoder.h:23-134): tokens are expanded
+// iff tot_cost < GetCutoff()'s weight cutoff and the emitting / epsilon cutoff is
+// min tot_cost + adaptive_beam (faster-decoder.cc:244-336 applied to float costs).
+// ---------------------------------------------------------------------------
+struct CanonLatticeOpts {
+  float beam = 16.f, lattice_beam = 10.f;
+  int32_t max_active = std::numeric_limits<int32_t>::max(), min_active = 0;
+  float beam_delta = 0.5f;
+};
+
+struct CanonLatticeDecoder {
+  struct Tok { int32_t state; float tot, extra; };
+  struct Link { int32_t src, dst, dst_frame, arc; float graph, ac; bool dead; };
+  const Graph &g;
+  CanonLatticeOpts o;
+  std::vector<std::vector<Tok>> toks;    // [frame_plus_one], sorted by state
+  std::vector<std::vector<Link>> links;  // [frame_plus_one] links leaving that frame's tokens
+  bool finalized = false;
+  float final_relative_cost = 0.f, final_best_cost = 0.f;
+  bool any_final = false;
+  std::vector<float> tmp_array;
+  int64_t links_created = 0;
+
+  CanonLatticeDecoder(const Graph &graph, const CanonLatticeOpts &opts) : g(graph), o(opts) {
+    if (!(o.beam > 0.0 && o.lattice_beam > 0.0)) throw std::runtime_error("beam > 0.0 && lattice_beam > 0.0");
+    if (!(o.max_active > 1 && o.min_active >= 0 && o.min_active < o.max_active))
+      throw std::runtime_error("max_active > 1 && 0 <= min_active < max_active");
+  }
+  int32_t NumFramesDecoded() const { return static_cast<int32_t>(toks.size()) - 1; }
+
+  // epsilon closure of `cur` (state -> cost) with a fixed cutoff; then freeze the
+  // frame's tokens and emit its epsilon links from the final costs
+  void CloseAndFreeze(std::unordered_map<int32_t, float> &cur, float cutoff) {
+    std::vector<int32_t> work;
+    for (auto &kv : cur) if (g.num_ieps[kv.first] != 0) work.push_back(kv.first);
+    while (!work.empty()) {
+      int32_t s = work.back();
+      work.pop_back();
+      float c = cur[s];
+      for (int32_t a = g.row_ptr[s]; a < g.row_ptr[s + 1]; ++a) {
+        if (g.ilabel[a] != 0) continue;
+        float tot = c + g.weight[a];
+        if (!(tot < cutoff)) continue;
+        auto it = cur.find(g.nextstate[a]);
+        if (it == cur.end()) { cur[g.nextstate[a]] = tot; if (g.num_ieps[g.nextstate[a]]) work.push_back(g.nextstate[a]); }
+        else if (it->second > tot) { it->second = tot; if (g.num_ieps[g.nextstate[a]]) work.push_back(g.nextstate[a]); }
+      }
+    }
+    std::vector<Tok> fr;
+    for (auto &kv : cur) fr.push_back(Tok{kv.first, kv.second, 0.0f});
+    std::sort(fr.begin(), fr.end(), [](const Tok &a, const Tok &b) { return a.state < b.state; });
+    std::vector<Link> el;
+    auto idx_of = [&](int32_t state) {
+      auto it = std::lower_bound(fr.begin(), fr.end(), state, [](const Tok &t, int32_t s) { return t.state < s; });
+      return static_cast<int32_t>(it - fr.begin());
+    };
+    const int32_t f = static_cast<int32_t>(toks.size());
+    for (int32_t i = 0; i < static_cast<int32_t>(fr.size()); ++i) {
+      int32_t s = fr[i].state;
+      if (g.num_ieps[s] == 0) continue;
+      for (int32_t a = g.row_ptr[s]; a < g.row_ptr[s + 1]; ++a) {
+        if (g.ilabel[a] != 0) continue;
+        float tot = fr[i].tot + g.weight[a];
+        if (!(tot < cutoff)) continue;
+        el.push_back(Link{i, idx_of(g.nextstate[a]), f, a, g.weight[a], 0.0f, false});
+      }
+    }
+    links_created += static_cast<int64_t>(el.size());
+    toks.push_back(std::move(fr));
+    links.push_back(std::move(el));
+  }
+
+  void InitDecoding() {
+    toks.clear();
+    links.clear();
+    finalized = false;
+    links_created = 0;
+    if (g.start < 0) throw std::runtime_error("graph has no start state");
+    std::unordered_map<int32_t, float> cur;
+    cur[g.start] = 0.0f;
+    CloseAndFreeze(cur, 0.0f + o.beam);  // lattice-simple-decoder.cc:135-154 with one token
+  }
+
+  // faster-decoder.cc:244-336 on this frame's float costs
+  float GetCutoff(const std::vector<Tok> &fr, float *adaptive_beam) {
+    float best = kInfF;
+    for (auto &t : fr) best = std::min(best, t.tot);
+    if (o.max_active == std::numeric_limits<int32_t>::max() && o.min_active == 0) {
+      *adaptive_beam = o.beam;
+      return kInfF;  // LatticeSimpleDecoder expands every token (:376-401)
+    }
+    tmp_array.clear();
+    for (auto &t : fr) tmp_array.push_back(t.tot);
+    double beam_cutoff = static_cast<double>(best) + o.beam, mn = kInfD, mx = kInfD;
+    if (tmp_array.size() > static_cast<size_t>(o.max_active)) {
+      std::nth_element(tmp_array.begin(), tmp_array.begin() + o.max_active, tmp_array.end());
+      mx = tmp_array[o.max_active];
+    }
+    if (mx < beam_cutoff) {
+      *adaptive_beam = mx - best + o.beam_delta;
+      return static_cast<float>(mx);
+    }
+    if (tmp_array.size() > static_cast<size_t>(o.min_active)) {
+      if (o.min_active == 0) mn = best;
+      else {
+        std::nth_element(tmp_array.begin(), tmp_array.begin() + o.min_active,
+                         tmp_array.size() > static_cast<size_t>(o.max_active)
+                             ? tmp_array.begin() + o.max_active : tmp_array.end());
+        mn = tmp_array[o.min_active];
+      }
+    }
+    if (mn > beam_cutoff) {
+      *adaptive_beam = mn - best + o.beam_delta;
+      return static_cast<float>(mn);
+    }
+    *adaptive_beam = o.beam;
+    return static_cast<float>(beam_cutoff);
+  }
+
+  void ProcessFrame(const Decodable &d) {
+    const int32_t frame = NumFramesDecoded();  // index into the decodable
+    const std::vector<Tok> &prev = toks.back();
+    float adaptive_beam;
+    const float weight_cutoff = GetCutoff(prev, &adaptive_beam);
+    float best_new = kInfF;
+    for (auto &t : prev) {
+      if (!(t.tot < weight_cutoff)) continue;
+      for (int32_t a = g.row_ptr[t.state]; a < g.row_ptr[t.state + 1]; ++a) {
+        if (g.ilabel[a] == 0) continue;
+        float ac = -d.LogLikelihood(frame, g.ilabel[a]), tot = t.tot + ac + g.weight[a];
+        best_new = std::min(best_new, tot);
+      }
+    }
+    const float cutoff = best_new + adaptive_beam;
+    std::unordered_map<int32_t, float> cur;
+    struct Pending { int32_t src, state, arc; float ac; };
+    std::vector<Pending> pend;
+    for (int32_t i = 0; i < static_cast<int32_t>(prev.size()); ++i) {
+      const Tok &t = prev[i];
+      if (!(t.tot < weight_cutoff)) continue;
+      for (int32_t a = g.row_ptr[t.state]; a < g.row_ptr[t.state + 1]; ++a) {
+        if (g.ilabel[a] == 0) continue;
+        float ac = -d.LogLikelihood(frame, g.ilabel[a]), tot = t.tot + ac + g.weight[a];
+        if (!(tot < cutoff)) continue;  // :386
+        auto it = cur.find(g.nextstate[a]);
+        if (it == cur.end()) cur[g.nextstate[a]] = tot;
+        else if (it->second > tot) it->second = tot;
+        pend.push_back(Pending{i, g.nextstate[a], a, ac});
+      }
+    }
+    CloseAndFreeze(cur, cutoff);
+    const std::vector<Tok> &fr = toks.back();
+    std::vector<Link> &el = links[links.size() - 2];  // links leaving the previous frame
+    const int32_t f1 = static_cast<int32_t>(toks.size()) - 1;
+    for (auto &pd : pend) {
+      auto it = std::lower_bound(fr.begin(), fr.end(), pd.state, [](const Tok &t, int32_t s) { return t.state < s; });
+      el.push_back(Link{pd.src, static_cast<int32_t>(it - fr.begin()), f1, pd.arc, g.weight[pd.arc], pd.ac, false});
+    }
+    links_created += static_cast<int64_t>(pend.size());
+  }
+
+  bool Decode(const Decodable &d) {  // lattice-simple-decoder.cc:53-73
+    InitDecoding();
+    while (!d.IsLastFrame(NumFramesDecoded() - 1)) ProcessFrame(d);
+    FinalizeDecoding();
+    return any_final;  // the reference returns !final_costs_.empty() (:72)
+  }
+
+  // PruneForwardLinks with delta = 0 for one frame (:228-305); `same` selects
+  // whether links into this very frame (epsilon) need the fixpoint iteration.
+  void PruneFrame(int32_t f, bool last) {
+    std::vector<Tok> &fr = toks[f];
+    std::vector<float> base(fr.size(), kInfF);
+    if (last) {  // PruneForwardLinksFinal (:425-520)
+      float best = kInfF, best_wf = kInfF;
+      any_final = false;
+      for (auto &t : fr) {
+        float fc = g.final_cost[t.state];
+        best = std::min(best, t.tot);
+        best_wf = std::min(best_wf, t.tot + fc);
+        if (fc != kInfF) any_final = true;
+      }
+      final_relative_cost = (best == kInfF && best_wf == kInfF) ? kInfF : best_wf - best;
+      final_best_cost = best_wf != kInfF ? best_wf : best;
+      for (size_t i = 0; i < fr.size(); ++i) {
+        float fc = any_final ? g.final_cost[fr[i].state] : 0.0f;
+        base[i] = fr[i].tot + fc - final_best_cost;
+      }
+    }
+    bool changed = true;
+    while (changed) {
+      changed = false;
+      std::vector<float> ne = base;
+      for (Link &l : links[f]) {
+        if (l.dead) continue;
+        const Tok &src = fr[l.src];
+        const Tok &nx = toks[l.dst_frame][l.dst];
+        float le = nx.extra + ((src.tot + l.ac + l.graph) - nx.tot);
+        if (le > o.lattice_beam) { l.dead = true; continue; }
+        if (le < 0.0f) le = 0.0f;
+        if (le < ne[l.src]) ne[l.src] = le;
+      }
+      for (size_t i = 0; i < fr.size(); ++i) {
+        float v = ne[i];
+        if (last && v > o.lattice_beam) v = kInfF;
+        if (v != fr[i].extra) { changed = true; fr[i].extra = v; }
+      }
+    }
+  }
+
+  void FinalizeDecoding() {  // :407-420
+    const int32_t last = NumFramesDecoded();
+    PruneFrame(last, true);
+    for (int32_t f = last - 1; f >= 0; --f) PruneFrame(f, false);
+    finalized = true;
+  }
+
+  bool GetRawLattice(Lattice *out) const {  // :584-657, tokens labelled (frame, state)
+    *out = Lattice();
+    const int32_t nf = NumFramesDecoded();
+    std::vector<std::vector<int32_t>> id(toks.size());
+    for (int32_t f = 0; f <= nf; ++f) {
+      id[f].assign(toks[f].size(), -1);
+      bool any = false;
+      for (size_t i = 0; i < toks[f].size(); ++i)
+        if (toks[f][i].extra != kInfF) {
+          id[f][i] = out->num_states++;
+          out->state_frame.push_back(f);
+          out->state_graph.push_back(toks[f][i].state);
+          any = true;
+          if (f == 0 && toks[f][i].state == g.start) out->start = id[f][i];
+        }
+      if (!any) { *out = Lattice(); return false; }
+    }
+    for (int32_t f = 0; f <= nf; ++f)
+      for (const Link &l : links[f]) {
+        if (l.dead || id[f][l.src] < 0 || id[l.dst_frame][l.dst] < 0) continue;
+        out->src.push_back(id[f][l.src]);
+        out->dst.push_back(id[l.dst_frame][l.dst]);
+        out->ilabel.push_back(g.ilabel[l.arc]);
+        out->olabel.push_back(g.olabel[l.arc]);
+        out->graph_cost.push_back(l.graph);
+        out->ac_cost.push_back(l.ac);
+      }
+    for (size_t i = 0; i < toks[nf].size(); ++i) {
+      if (id[nf][i] < 0) continue;
+      float fc = g.final_cost[toks[nf][i].state];
+      if (any_final) {
+        if (fc != kInfF) { out->final_state.push_back(id[nf][i]); out->final_graph.push_back(fc); out->final_ac.push_back(0.f); }
+      } else {
+        out->final_state.push_back(id[nf][i]); out->final_graph.push_back(0.f); out->final_ac.push_back(0.f);
+      }
+    }
+    return out->num_states != 0;
   }
 };
 
@@ -1364,6 +1641,86 @@ int kdo_latsimple_best_path(void *hv, int32_t use_final_probs, int32_t cap, int3
   if (Guard([&] {
         Lattice lat;
         h->dec.GetRawLattice(&lat, use_final_probs != 0);
+        LatticeShortestPath(lat, &p);
+      }))
+    return -1;
+  return CopyPath(p, cap, n, il, ol, st, gc, ac, final_w);
+}
+
+
+// -- canonical lattice decoder (policy 1) -----------------------------------------
+struct CanonHandle {
+  CanonLatticeDecoder dec;
+  Lattice lat;
+  CanonHandle(const Graph &g, const CanonLatticeOpts &o) : dec(g, o) {}
+};
+void *kdo_canonlat_create(void *graph, float beam, float lattice_beam, int32_t max_active,
+                          int32_t min_active, float beam_delta) {
+  CanonLatticeOpts o;
+  o.beam = beam; o.lattice_beam = lattice_beam; o.max_active = max_active;
+  o.min_active = min_active; o.beam_delta = beam_delta;
+  CanonHandle *h = nullptr;
+  if (Guard([&] { h = new CanonHandle(*static_cast<Graph *>(graph), o); })) return nullptr;
+  return h;
+}
+void kdo_canonlat_free(void *h) { delete static_cast<CanonHandle *>(h); }
+int kdo_canonlat_decode(void *h, const float *p, int32_t rows, int32_t cols, int32_t offset) {
+  Decodable dec{p, rows, cols, offset};
+  bool r = false;
+  if (Guard([&] { r = static_cast<CanonHandle *>(h)->dec.Decode(dec); })) return -1;
+  return r ? 1 : 0;
+}
+int32_t kdo_canonlat_num_frames_decoded(void *h) { return static_cast<CanonHandle *>(h)->dec.NumFramesDecoded(); }
+float kdo_canonlat_final_relative_cost(void *h) { return static_cast<CanonHandle *>(h)->dec.final_relative_cost; }
+int64_t kdo_canonlat_links_created(void *h) { return static_cast<CanonHandle *>(h)->dec.links_created; }
+int32_t kdo_canonlat_frame_tokens(void *hv, int32_t f, int32_t cap, int32_t *state, float *tot, float *extra) {
+  auto &fr = static_cast<CanonHandle *>(hv)->dec.toks[f];
+  int32_t n = static_cast<int32_t>(fr.size());
+  for (int32_t i = 0; i < n && i < cap; ++i) { state[i] = fr[i].state; tot[i] = fr[i].tot; extra[i] = fr[i].extra; }
+  return n;
+}
+int kdo_canonlat_raw_lattice(void *hv, int32_t *sizes4) {
+  auto *h = static_cast<CanonHandle *>(hv);
+  bool ok = false;
+  if (Guard([&] { ok = h->dec.GetRawLattice(&h->lat); })) return -1;
+  sizes4[0] = h->lat.num_states;
+  sizes4[1] = static_cast<int32_t>(h->lat.src.size());
+  sizes4[2] = static_cast<int32_t>(h->lat.final_state.size());
+  sizes4[3] = h->lat.start;
+  return ok ? 1 : 0;
+}
+static void CopyLattice(const Lattice &l, int32_t *src, int32_t *dst, int32_t *il, int32_t *ol,
+                        float *gc, float *ac, int32_t *fs, float *fg, int32_t *state_frame,
+                        int32_t *state_graph) {
+  size_t na = l.src.size(), nf = l.final_state.size();
+  if (na) {
+    std::memcpy(src, l.src.data(), na * 4); std::memcpy(dst, l.dst.data(), na * 4);
+    std::memcpy(il, l.ilabel.data(), na * 4); std::memcpy(ol, l.olabel.data(), na * 4);
+    std::memcpy(gc, l.graph_cost.data(), na * 4); std::memcpy(ac, l.ac_cost.data(), na * 4);
+  }
+  if (nf) { std::memcpy(fs, l.final_state.data(), nf * 4); std::memcpy(fg, l.final_graph.data(), nf * 4); }
+  if (l.num_states) {
+    std::memcpy(state_frame, l.state_frame.data(), l.num_states * 4);
+    std::memcpy(state_graph, l.state_graph.data(), l.num_states * 4);
+  }
+}
+void kdo_canonlat_copy_lattice(void *hv, int32_t *src, int32_t *dst, int32_t *il, int32_t *ol,
+                               float *gc, float *ac, int32_t *fs, float *fg, int32_t *state_frame,
+                               int32_t *state_graph) {
+  CopyLattice(static_cast<CanonHandle *>(hv)->lat, src, dst, il, ol, gc, ac, fs, fg, state_frame, state_graph);
+}
+void kdo_latsimple_copy_lattice2(void *hv, int32_t *src, int32_t *dst, int32_t *il, int32_t *ol,
+                                 float *gc, float *ac, int32_t *fs, float *fg, int32_t *state_frame,
+                                 int32_t *state_graph) {
+  CopyLattice(static_cast<LatHandle *>(hv)->lat, src, dst, il, ol, gc, ac, fs, fg, state_frame, state_graph);
+}
+int kdo_canonlat_best_path(void *hv, int32_t cap, int32_t *n, int32_t *il, int32_t *ol, int32_t *st,
+                           float *gc, float *ac, float *final_w) {
+  auto *h = static_cast<CanonHandle *>(hv);
+  Path p;
+  if (Guard([&] {
+        Lattice lat;
+        h->dec.GetRawLattice(&lat);
         LatticeShortestPath(lat, &p);
       }))
     return -1;

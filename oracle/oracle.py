@@ -79,6 +79,22 @@ def lib():
     L.kdo_latsimple_copy_lattice.argtypes = [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _f32p, _f32p,
                                              _i32p, _f32p, _i32p]
     L.kdo_latsimple_best_path.argtypes = path_args
+    lat_copy = [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _f32p, _f32p, _i32p, _f32p, _i32p, _i32p]
+    L.kdo_latsimple_copy_lattice2.argtypes = lat_copy
+    L.kdo_canonlat_create.restype = C.c_void_p
+    L.kdo_canonlat_create.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_float]
+    L.kdo_canonlat_free.argtypes = [C.c_void_p]
+    L.kdo_canonlat_decode.argtypes = [C.c_void_p, _f32p, C.c_int32, C.c_int32, C.c_int32]
+    L.kdo_canonlat_num_frames_decoded.argtypes = [C.c_void_p]
+    L.kdo_canonlat_final_relative_cost.restype = C.c_float
+    L.kdo_canonlat_final_relative_cost.argtypes = [C.c_void_p]
+    L.kdo_canonlat_links_created.restype = C.c_int64
+    L.kdo_canonlat_links_created.argtypes = [C.c_void_p]
+    L.kdo_canonlat_frame_tokens.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, _f32p, _f32p]
+    L.kdo_canonlat_raw_lattice.argtypes = [C.c_void_p, _i32p]
+    L.kdo_canonlat_copy_lattice.argtypes = lat_copy
+    L.kdo_canonlat_best_path.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), _i32p, _i32p,
+                                         _i32p, _f32p, _f32p, _f32p]
     _bind_hashlist(L, "kdo_hashlist")
     _LIB = L
     return L
@@ -269,12 +285,36 @@ class SimpleDecoder(_Decoder):
 
 
 class RawLattice:
-    def __init__(self, ok, num_states, start, src, dst, il, ol, gc, ac, fs, fg, frame):
+    def __init__(self, ok, num_states, start, src, dst, il, ol, gc, ac, fs, fg, frame, gstate):
         self.ok, self.num_states, self.start = ok, num_states, start
         self.src, self.dst, self.ilabel, self.olabel = src, dst, il, ol
         self.graph_cost, self.ac_cost = gc, ac
         self.final_state, self.final_graph = fs, fg
-        self.state_frame = frame
+        self.state_frame, self.state_graph = frame, gstate
+
+    def arc_set(self):
+        """Arcs as tuples keyed by (frame, graph state) of both ends: a numbering-free
+        form of the lattice for comparisons."""
+        f, s = self.state_frame, self.state_graph
+        return set(zip(f[self.src].tolist(), s[self.src].tolist(), f[self.dst].tolist(),
+                       s[self.dst].tolist(), self.ilabel.tolist(), self.olabel.tolist(),
+                       self.graph_cost.tolist(), self.ac_cost.tolist()))
+
+    def state_set(self):
+        return set(zip(self.state_frame.tolist(), self.state_graph.tolist()))
+
+    def final_set(self):
+        return set(zip(self.state_graph[self.final_state].tolist(), self.final_graph.tolist()))
+
+
+def _fetch_lattice(ok, sizes, copy_fn, h):
+    ns, na, nf, start = sizes.tolist()
+    src, dst, il, ol = (np.zeros(na, np.int32) for _ in range(4))
+    gc, ac = np.zeros(na, np.float32), np.zeros(na, np.float32)
+    fs, fg = np.zeros(nf, np.int32), np.zeros(nf, np.float32)
+    frame, gstate = np.zeros(ns, np.int32), np.zeros(ns, np.int32)
+    copy_fn(h, src, dst, il, ol, gc, ac, fs, fg, frame, gstate)
+    return RawLattice(ok, ns, start, src, dst, il, ol, gc, ac, fs, fg, frame, gstate)
 
 
 class LatticeSimpleDecoder:
@@ -313,13 +353,69 @@ class LatticeSimpleDecoder:
         r = lib().kdo_latsimple_raw_lattice(self.h, int(use_final_probs), sizes)
         if r < 0:
             raise _err()
-        ns, na, nf, start = sizes.tolist()
-        src, dst, il, ol = (np.zeros(na, np.int32) for _ in range(4))
-        gc, ac = np.zeros(na, np.float32), np.zeros(na, np.float32)
-        fs, fg = np.zeros(nf, np.int32), np.zeros(nf, np.float32)
-        frame = np.zeros(ns, np.int32)
-        lib().kdo_latsimple_copy_lattice(self.h, src, dst, il, ol, gc, ac, fs, fg, frame)
-        return RawLattice(bool(r), ns, start, src, dst, il, ol, gc, ac, fs, fg, frame)
+        return _fetch_lattice(bool(r), sizes, lib().kdo_latsimple_copy_lattice2, self.h)
 
     def get_best_path(self, use_final_probs=True):
         return _best_path(lib().kdo_latsimple_best_path, self.h, use_final_probs)
+
+
+class CanonLatticeDecoder:
+    """Order-free lattice decoder (policy 1): what the GPU lattice decoders compute.
+    max_active / min_active at their defaults == LatticeSimpleDecoder semantics."""
+    h = None
+
+    def __init__(self, graph: Graph, beam=16.0, lattice_beam=10.0, max_active=INT_MAX,
+                 min_active=0, beam_delta=0.5):
+        self.graph = graph
+        h = lib().kdo_canonlat_create(graph.h, beam, lattice_beam, max_active, min_active,
+                                      beam_delta)
+        if not h:
+            raise _err()
+        self.h = C.c_void_p(h)
+
+    def __del__(self):
+        if self.h:
+            lib().kdo_canonlat_free(self.h)
+
+    def decode(self, log_probs, offset=0):
+        lp = np.ascontiguousarray(log_probs, dtype=np.float32)
+        r = lib().kdo_canonlat_decode(self.h, lp, lp.shape[0], lp.shape[1], offset)
+        if r < 0:
+            raise _err()
+        return bool(r)
+
+    def num_frames_decoded(self):
+        return lib().kdo_canonlat_num_frames_decoded(self.h)
+
+    def final_relative_cost(self):
+        return lib().kdo_canonlat_final_relative_cost(self.h)
+
+    def links_created(self):
+        return lib().kdo_canonlat_links_created(self.h)
+
+    def frame_tokens(self, f, cap=1 << 20):
+        st = np.zeros(cap, np.int32)
+        tot = np.zeros(cap, np.float32)
+        ex = np.zeros(cap, np.float32)
+        n = lib().kdo_canonlat_frame_tokens(self.h, f, cap, st, tot, ex)
+        return st[:n].copy(), tot[:n].copy(), ex[:n].copy()
+
+    def get_raw_lattice(self):
+        sizes = np.zeros(4, np.int32)
+        r = lib().kdo_canonlat_raw_lattice(self.h, sizes)
+        if r < 0:
+            raise _err()
+        return _fetch_lattice(bool(r), sizes, lib().kdo_canonlat_copy_lattice, self.h)
+
+    def get_best_path(self):
+        cap = 1 << 16
+        n = C.c_int32(0)
+        il, ol, st = (np.zeros(cap, np.int32) for _ in range(3))
+        gc, ac = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        fw = np.zeros(2, np.float32)
+        r = lib().kdo_canonlat_best_path(self.h, cap, C.byref(n), il, ol, st, gc, ac, fw)
+        if r < 0:
+            raise _err()
+        k = n.value
+        return BestPath(bool(r), il[:k].copy(), ol[:k].copy(), st[:k].copy(), gc[:k].copy(),
+                        ac[:k].copy(), (float(fw[0]), float(fw[1])))
