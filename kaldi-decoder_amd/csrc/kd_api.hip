@@ -73,6 +73,20 @@ struct kd_batch {
   DevBuf<long long> stats;
   DevBuf<uint32_t> g_key, g_arc, g_used, g_wl, g_log_h, g_log_arc, g_log_src;
   DevBuf<unsigned long long> g_cost, g_log_nk;
+  // lattice mode
+  bool lattice = false, finalized = false, lat_stats_valid = false, lat_sizes_valid = false;
+  int32_t lat_use_final = -1;
+  kd_lattice_options lo{};
+  int64_t link_cap = 0;  // per utterance
+  DevBuf<float> g_log_ac, tok_extra, link_ac, link_graph, lat_frc, lat_fbc;
+  DevBuf<int32_t> link_src, link_dst, link_arc, link_emit_count, link_eps_count, tok_newid,
+      lat_any_final, lat_sizes;
+  DevBuf<long long> link_emit_base, link_eps_base, lat_state_off, lat_arc_off, lat_final_off;
+  DevBuf<unsigned long long> link_top;
+  DevBuf<uint32_t> lat_scratch;
+  DevBuf<int32_t> lo_src, lo_dst, lo_il, lo_ol, lo_sf, lo_sg, lo_fs;
+  DevBuf<float> lo_gc, lo_ac, lo_fg;
+  std::vector<int32_t> h_lat_sizes;
   DevBuf<UttDesc> utt;
   DevBuf<float> staging;
   DevBuf<const float *> unused_;
@@ -138,6 +152,59 @@ struct kd_batch {
     p.g_log2_slots = g_log2_slots;
     p.utt = utt.p;
     p.do_init = do_init;
+    p.lattice = lattice ? 1 : 0;
+    p.g_log_ac = g_log_ac.p;
+    p.tok_extra = tok_extra.p;
+    p.link_src = link_src.p;
+    p.link_dst = link_dst.p;
+    p.link_arc = link_arc.p;
+    p.link_ac = link_ac.p;
+    p.link_graph = link_graph.p;
+    p.link_cap = static_cast<unsigned long long>(link_cap);
+    p.link_top = link_top.p;
+    p.link_emit_base = link_emit_base.p;
+    p.link_emit_count = link_emit_count.p;
+    p.link_eps_base = link_eps_base.p;
+    p.link_eps_count = link_eps_count.p;
+    return p;
+  }
+
+  LatticeParams LParams() const {
+    LatticeParams p{};
+    p.states = g->states.p;
+    p.arcs = g->arcs.p;
+    p.start = g->start;
+    p.lattice_beam = lo.lattice_beam;
+    p.tok_state = tok_state.p;
+    p.tok_cost = tok_cost.p;
+    p.tok_extra = tok_extra.p;
+    p.tok_newid = tok_newid.p;
+    p.frame_base = frame_base.p;
+    p.frame_count = frame_count.p;
+    p.max_frames = o.max_frames;
+    p.frames_decoded = frames_decoded.p;
+    p.link_src = link_src.p;
+    p.link_dst = link_dst.p;
+    p.link_arc = link_arc.p;
+    p.link_ac = link_ac.p;
+    p.link_graph = link_graph.p;
+    p.link_emit_base = link_emit_base.p;
+    p.link_emit_count = link_emit_count.p;
+    p.link_eps_base = link_eps_base.p;
+    p.link_eps_count = link_eps_count.p;
+    p.scratch = lat_scratch.p;
+    p.scratch_stride = static_cast<long long>(o.arena_tokens / std::max(max_batch, 1));
+    p.final_relative_cost = lat_frc.p;
+    p.final_best_cost = lat_fbc.p;
+    p.any_final = lat_any_final.p;
+    p.finalized = finalized ? 1 : 0;
+    p.sizes = lat_sizes.p;
+    p.out_state_off = lat_state_off.p;
+    p.out_arc_off = lat_arc_off.p;
+    p.out_final_off = lat_final_off.p;
+    p.o_src = lo_src.p; p.o_dst = lo_dst.p; p.o_ilabel = lo_il.p; p.o_olabel = lo_ol.p;
+    p.o_state_frame = lo_sf.p; p.o_state_graph = lo_sg.p; p.o_final_state = lo_fs.p;
+    p.o_graph = lo_gc.p; p.o_ac = lo_ac.p; p.o_final_graph = lo_fg.p;
     return p;
   }
 
@@ -210,6 +277,8 @@ int Launch(kd_batch *b, int do_init, int32_t num_cols, int64_t row_stride) {
   b->timed = true;
   b->pending = true;
   b->path_valid = false;
+  b->lat_stats_valid = false;
+  b->lat_sizes_valid = false;
   return KD_OK;
 }
 
@@ -220,6 +289,8 @@ int PlanAdvance(kd_batch *b, const int32_t *num_rows, const int32_t *offset,
   if (!b->initialized)
     return Fail(KD_E_STATE, "Check failed: num_frames_decoded_ >= 0 && "
                             "\"You must call InitDecoding() before AdvanceDecoding()\"");
+  if (b->finalized)
+    return Fail(KD_E_STATE, "FinalizeDecoding() has been called: cannot decode further");
   for (int i = 0; i < b->batch; ++i) {
     const int32_t off = offset ? offset[i] : 0;
     const int32_t ready = off + num_rows[i];
@@ -319,12 +390,9 @@ void kd_faster_options_default(kd_faster_options *o) {
   o->max_frames = 0;
 }
 
-int kd_batch_create(const kd_graph *g, const kd_faster_options *opts, int32_t max_batch,
-                    void *stream, kd_batch **out) {
-  if (!out) return Fail(KD_E_INVALID, "out is NULL");
-  *out = nullptr;
-  if (!g || !opts || max_batch <= 0) return Fail(KD_E_INVALID, "bad argument");
-  if (int r = CheckOptions(*opts)) return r;
+static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
+                       const kd_lattice_options *lopts, int32_t max_batch, void *stream,
+                       kd_batch **out) {
   KD_HIP_TRY(hipSetDevice(g->device));
   kd_batch *b = new (std::nothrow) kd_batch;
   if (!b) return Fail(KD_E_INVALID, "out of host memory");
@@ -388,8 +456,98 @@ int kd_batch_create(const kd_graph *g, const kd_faster_options *opts, int32_t ma
   b->h_reached.assign(max_batch, 0);
   b->h_final_weight.assign(2 * static_cast<size_t>(max_batch), 0.f);
   b->h_utt.assign(max_batch, UttDesc{});
+  if (lopts) {
+    b->lattice = true;
+    b->lo = *lopts;
+    int64_t links = lopts->arena_links > 0 ? lopts->arena_links : 4 * b->o.arena_tokens;
+    links = std::min<int64_t>(links, (1ll << 31) - 1);
+    b->link_cap = links / max_batch;
+    const size_t nl = static_cast<size_t>(b->link_cap) * max_batch;
+    hipError_t e2 = hipSuccess;
+    auto A2 = [&](hipError_t r) { if (e2 == hipSuccess) e2 = r; };
+    A2(b->g_log_ac.Alloc(2 * gs));
+    A2(b->tok_extra.Alloc(b->o.arena_tokens));
+    A2(b->tok_newid.Alloc(b->o.arena_tokens));
+    A2(b->lat_scratch.Alloc(b->o.arena_tokens));
+    A2(b->link_src.Alloc(nl));
+    A2(b->link_dst.Alloc(nl));
+    A2(b->link_arc.Alloc(nl));
+    A2(b->link_ac.Alloc(nl));
+    A2(b->link_graph.Alloc(nl));
+    A2(b->link_top.Alloc(max_batch));
+    A2(b->link_emit_base.Alloc(nf));
+    A2(b->link_emit_count.Alloc(nf));
+    A2(b->link_eps_base.Alloc(nf));
+    A2(b->link_eps_count.Alloc(nf));
+    A2(b->lat_frc.Alloc(max_batch));
+    A2(b->lat_fbc.Alloc(max_batch));
+    A2(b->lat_any_final.Alloc(max_batch));
+    A2(b->lat_sizes.Alloc(4 * static_cast<size_t>(max_batch)));
+    A2(b->lat_state_off.Alloc(max_batch));
+    A2(b->lat_arc_off.Alloc(max_batch));
+    A2(b->lat_final_off.Alloc(max_batch));
+    if (e2 == hipSuccess) e2 = hipMemset(b->link_emit_count.p, 0, b->link_emit_count.bytes());
+    if (e2 == hipSuccess) e2 = hipMemset(b->link_eps_count.p, 0, b->link_eps_count.bytes());
+    if (e2 != hipSuccess) {
+      delete b;
+      return Fail(KD_E_HIP, std::string("lattice batch allocation: ") + hipGetErrorString(e2));
+    }
+    b->h_lat_sizes.assign(4 * static_cast<size_t>(max_batch), 0);
+  }
   *out = b;
   return KD_OK;
+}
+
+int kd_batch_create(const kd_graph *g, const kd_faster_options *opts, int32_t max_batch,
+                    void *stream, kd_batch **out) {
+  if (!out) return Fail(KD_E_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!g || !opts || max_batch <= 0) return Fail(KD_E_INVALID, "bad argument");
+  if (int r = CheckOptions(*opts)) return r;
+  return CreateBatch(g, opts, nullptr, max_batch, stream, out);
+}
+
+void kd_lattice_options_default(kd_lattice_options *o) {
+  // lattice-faster-decoder.h:48-66
+  o->beam = 16.0f;
+  o->max_active = std::numeric_limits<int32_t>::max();
+  o->min_active = 200;
+  o->lattice_beam = 10.0f;
+  o->prune_interval = 25;
+  o->beam_delta = 0.5f;
+  o->hash_ratio = 2.0f;
+  o->prune_scale = 0.1f;
+  o->arena_tokens = 0;
+  o->arena_links = 0;
+  o->table_slots = 0;
+  o->max_frames = 0;
+}
+
+int kd_batch_create_lattice(const kd_graph *g, const kd_lattice_options *lo, int32_t max_batch,
+                            void *stream, kd_batch **out) {
+  if (!out) return Fail(KD_E_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!g || !lo || max_batch <= 0) return Fail(KD_E_INVALID, "bad argument");
+  // lattice-faster-decoder.h:128-133
+  if (!(lo->beam > 0.0 && lo->max_active > 1 && lo->lattice_beam > 0.0 &&
+        lo->min_active <= lo->max_active && lo->prune_interval > 0 && lo->beam_delta > 0.0 &&
+        lo->hash_ratio >= 1.0 && lo->prune_scale > 0.0 && lo->prune_scale < 1.0))
+    return Fail(KD_E_INVALID,
+                "Check failed: beam > 0.0 && max_active > 1 && lattice_beam > 0.0 && "
+                "min_active <= max_active && prune_interval > 0 && beam_delta > 0.0 && "
+                "hash_ratio >= 1.0 && prune_scale > 0.0 && prune_scale < 1.0");
+  if (lo->min_active < 0) return Fail(KD_E_INVALID, "Check failed: min_active >= 0");
+  kd_faster_options fo;
+  kd_faster_options_default(&fo);
+  fo.beam = lo->beam;
+  fo.max_active = lo->max_active;
+  fo.min_active = lo->min_active;
+  fo.beam_delta = lo->beam_delta;
+  fo.hash_ratio = lo->hash_ratio;
+  fo.arena_tokens = lo->arena_tokens;
+  fo.table_slots = lo->table_slots;
+  fo.max_frames = lo->max_frames;
+  return CreateBatch(g, &fo, lo, max_batch, stream, out);
 }
 
 void kd_batch_destroy(kd_batch *b) {
@@ -414,9 +572,11 @@ int kd_batch_init_decoding(kd_batch *b, int32_t batch) {
   KD_HIP_TRY(hipSetDevice(b->g->device));
   b->batch = batch;
   KD_HIP_TRY(hipMemsetAsync(b->arena_top.p, 0, b->arena_top.bytes(), b->stream));
+  if (b->lattice) KD_HIP_TRY(hipMemsetAsync(b->link_top.p, 0, b->link_top.bytes(), b->stream));
   KD_HIP_TRY(hipMemsetAsync(b->frames_decoded.p, 0xFF, b->frames_decoded.bytes(), b->stream));
   KD_HIP_TRY(hipMemsetAsync(b->status.p, 0, b->status.bytes(), b->stream));
   KD_HIP_TRY(hipMemsetAsync(b->stats.p, 0, b->stats.bytes(), b->stream));
+  b->finalized = false;
   for (auto &u : b->h_utt) u = UttDesc{};
   KD_HIP_TRY(hipMemcpyAsync(b->utt.p, b->h_utt.data(), batch * sizeof(UttDesc),
                             hipMemcpyHostToDevice, b->stream));
@@ -609,6 +769,137 @@ int kd_batch_frame_tokens(kd_batch *b, int32_t utt, int32_t frame_plus_one, int3
   for (int i = 0; i < n; ++i) order[i] = i;
   std::sort(order.begin(), order.end(), [&](int x, int y) { return s[x] < s[y]; });
   for (int i = 0; i < n; ++i) { state[i] = s[order[i]]; cost[i] = c[order[i]]; }
+  return KD_OK;
+}
+
+static int LatticeStats(kd_batch *b) {
+  if (b->lat_stats_valid) return KD_OK;
+  LatticeParams p = b->LParams();
+  p.stats_only = 1;
+  KD_HIP_TRY(LaunchLatticePrune(p, b->batch, b->stream));
+  b->lat_stats_valid = true;
+  return KD_OK;
+}
+
+int kd_batch_finalize_decoding(kd_batch *b) {
+  if (!b) return Fail(KD_E_INVALID, "bad argument");
+  if (!b->lattice) return Fail(KD_E_STATE, "not a lattice batch");
+  if (!b->initialized) return Fail(KD_E_STATE, "InitDecoding() has not been called");
+  if (b->finalized) return Fail(KD_E_STATE, "Check failed: !decoding_finalized_");
+  KD_HIP_TRY(hipSetDevice(b->g->device));
+  if (b->pending)
+    if (int r = ReadBack(b)) return r;
+  LatticeParams p = b->LParams();
+  p.stats_only = 0;
+  KD_HIP_TRY(LaunchLatticePrune(p, b->batch, b->stream));
+  KD_HIP_TRY(hipStreamSynchronize(b->stream));
+  b->finalized = true;
+  b->lat_stats_valid = true;
+  b->lat_sizes_valid = false;
+  return KD_OK;
+}
+
+int kd_batch_final_relative_cost(kd_batch *b, float *out) {
+  if (!b || !out) return Fail(KD_E_INVALID, "bad argument");
+  if (!b->lattice) return Fail(KD_E_STATE, "not a lattice batch");
+  if (!b->initialized) return Fail(KD_E_STATE, "InitDecoding() has not been called");
+  KD_HIP_TRY(hipSetDevice(b->g->device));
+  if (b->pending)
+    if (int r = ReadBack(b)) return r;
+  if (int r = LatticeStats(b)) return r;
+  KD_HIP_TRY(hipMemcpyAsync(out, b->lat_frc.p, b->batch * sizeof(float), hipMemcpyDeviceToHost,
+                            b->stream));
+  KD_HIP_TRY(hipStreamSynchronize(b->stream));
+  return KD_OK;
+}
+
+int kd_batch_raw_lattice_prepare(kd_batch *b, int32_t use_final_probs, int32_t *sizes) {
+  if (!b || !sizes) return Fail(KD_E_INVALID, "bad argument");
+  if (!b->lattice) return Fail(KD_E_STATE, "not a lattice batch");
+  if (!b->initialized) return Fail(KD_E_STATE, "InitDecoding() has not been called");
+  if (b->finalized && !use_final_probs)  // lattice-simple-decoder.cc:594-597
+    return Fail(KD_E_STATE, "You cannot call FinalizeDecoding() and then call "
+                            "GetRawLattice() with use_final_probs == false");
+  KD_HIP_TRY(hipSetDevice(b->g->device));
+  if (b->pending)
+    if (int r = ReadBack(b)) return r;
+  for (int i = 0; i < b->batch; ++i)
+    if (!(b->h_decoded[i] > 0)) return Fail(KD_E_STATE, "Check failed: num_frames > 0");
+  if (int r = LatticeStats(b)) return r;
+  if (!(b->lat_sizes_valid && b->lat_use_final == (use_final_probs ? 1 : 0))) {
+    LatticeParams p = b->LParams();
+    p.use_final_probs = use_final_probs ? 1 : 0;
+    KD_HIP_TRY(LaunchLatticeCount(p, b->batch, b->stream));
+    KD_HIP_TRY(hipMemcpyAsync(b->h_lat_sizes.data(), b->lat_sizes.p, 4 * b->batch * sizeof(int32_t),
+                              hipMemcpyDeviceToHost, b->stream));
+    KD_HIP_TRY(hipStreamSynchronize(b->stream));
+    b->lat_sizes_valid = true;
+    b->lat_use_final = use_final_probs ? 1 : 0;
+  }
+  std::memcpy(sizes, b->h_lat_sizes.data(), 4 * b->batch * sizeof(int32_t));
+  return KD_OK;
+}
+
+int kd_batch_raw_lattice_copy(kd_batch *b, const int64_t *state_off, const int64_t *arc_off,
+                              const int64_t *final_off, int32_t *src, int32_t *dst,
+                              int32_t *ilabel, int32_t *olabel, float *graph_cost,
+                              float *ac_cost, int32_t *state_frame, int32_t *state_graph,
+                              int32_t *final_state, float *final_graph) {
+  if (!b || !state_off || !arc_off || !final_off) return Fail(KD_E_INVALID, "bad argument");
+  if (!b->lattice || !b->lat_sizes_valid)
+    return Fail(KD_E_STATE, "call kd_batch_raw_lattice_prepare first");
+  KD_HIP_TRY(hipSetDevice(b->g->device));
+  std::vector<long long> so(b->batch), ao(b->batch), fo(b->batch);
+  size_t ns = 0, na = 0, nfn = 0;
+  for (int i = 0; i < b->batch; ++i) {
+    so[i] = static_cast<long long>(ns);
+    ao[i] = static_cast<long long>(na);
+    fo[i] = static_cast<long long>(nfn);
+    ns += b->h_lat_sizes[4 * i];
+    na += b->h_lat_sizes[4 * i + 1];
+    nfn += b->h_lat_sizes[4 * i + 2];
+  }
+  if (ns == 0) return KD_OK;
+  hipError_t e = hipSuccess;
+  auto R = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  R(b->lo_src.Reserve(na)); R(b->lo_dst.Reserve(na)); R(b->lo_il.Reserve(na));
+  R(b->lo_ol.Reserve(na)); R(b->lo_gc.Reserve(na)); R(b->lo_ac.Reserve(na));
+  R(b->lo_sf.Reserve(ns)); R(b->lo_sg.Reserve(ns)); R(b->lo_fs.Reserve(nfn));
+  R(b->lo_fg.Reserve(nfn));
+  if (e != hipSuccess) return Fail(KD_E_HIP, std::string("lattice output: ") + hipGetErrorString(e));
+  KD_HIP_TRY(hipMemcpyAsync(b->lat_state_off.p, so.data(), b->batch * 8, hipMemcpyHostToDevice, b->stream));
+  KD_HIP_TRY(hipMemcpyAsync(b->lat_arc_off.p, ao.data(), b->batch * 8, hipMemcpyHostToDevice, b->stream));
+  KD_HIP_TRY(hipMemcpyAsync(b->lat_final_off.p, fo.data(), b->batch * 8, hipMemcpyHostToDevice, b->stream));
+  LatticeParams p = b->LParams();
+  p.use_final_probs = b->lat_use_final;
+  KD_HIP_TRY(LaunchLatticeFill(p, b->batch, b->stream));
+  std::vector<int32_t> hsrc(na), hdst(na), hil(na), hol(na), hsf(ns), hsg(ns), hfs(nfn);
+  std::vector<float> hgc(na), hac(na), hfg(nfn);
+  auto D = [&](void *d, const void *s2, size_t bytes) {
+    if (bytes) R(hipMemcpyAsync(d, s2, bytes, hipMemcpyDeviceToHost, b->stream));
+  };
+  D(hsrc.data(), b->lo_src.p, na * 4); D(hdst.data(), b->lo_dst.p, na * 4);
+  D(hil.data(), b->lo_il.p, na * 4); D(hol.data(), b->lo_ol.p, na * 4);
+  D(hgc.data(), b->lo_gc.p, na * 4); D(hac.data(), b->lo_ac.p, na * 4);
+  D(hsf.data(), b->lo_sf.p, ns * 4); D(hsg.data(), b->lo_sg.p, ns * 4);
+  D(hfs.data(), b->lo_fs.p, nfn * 4); D(hfg.data(), b->lo_fg.p, nfn * 4);
+  if (e != hipSuccess) return Fail(KD_E_HIP, std::string("lattice copy: ") + hipGetErrorString(e));
+  KD_HIP_TRY(hipStreamSynchronize(b->stream));
+  for (int i = 0; i < b->batch; ++i) {
+    const size_t s1 = b->h_lat_sizes[4 * i], a1 = b->h_lat_sizes[4 * i + 1],
+                 f1 = b->h_lat_sizes[4 * i + 2];
+    auto C4 = [&](void *d, const void *s2, size_t n) { if (d && n) std::memcpy(d, s2, n * 4); };
+    C4(src ? src + arc_off[i] : nullptr, hsrc.data() + ao[i], a1);
+    C4(dst ? dst + arc_off[i] : nullptr, hdst.data() + ao[i], a1);
+    C4(ilabel ? ilabel + arc_off[i] : nullptr, hil.data() + ao[i], a1);
+    C4(olabel ? olabel + arc_off[i] : nullptr, hol.data() + ao[i], a1);
+    C4(graph_cost ? graph_cost + arc_off[i] : nullptr, hgc.data() + ao[i], a1);
+    C4(ac_cost ? ac_cost + arc_off[i] : nullptr, hac.data() + ao[i], a1);
+    C4(state_frame ? state_frame + state_off[i] : nullptr, hsf.data() + so[i], s1);
+    C4(state_graph ? state_graph + state_off[i] : nullptr, hsg.data() + so[i], s1);
+    C4(final_state ? final_state + final_off[i] : nullptr, hfs.data() + fo[i], f1);
+    C4(final_graph ? final_graph + final_off[i] : nullptr, hfg.data() + fo[i], f1);
+  }
   return KD_OK;
 }
 

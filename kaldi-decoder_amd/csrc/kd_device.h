@@ -92,6 +92,61 @@ struct SearchParams {
   int32_t num_cols;
   long long row_stride;
   int32_t do_init;   // 1: run InitDecoding instead of advancing
+  // lattice mode (LatticeSimpleDecoder / LatticeFasterDecoder semantics)
+  int32_t lattice;           // 0: FasterDecoder (double costs), 1: lattice decoders (float costs)
+  int32_t expand_all;        // lattice: LatticeSimpleDecoder expands every token
+  float *g_log_ac;           // queue: acoustic cost (emitting) / source cost at generation (epsilon)
+  float *tok_extra;          // [arena] extra_cost of each token
+  int32_t *link_src;         // link arena, utterance u owns [u*link_cap, (u+1)*link_cap)
+  int32_t *link_dst;         // -1 once pruned
+  int32_t *link_arc;
+  float *link_ac;
+  float *link_graph;
+  unsigned long long link_cap;
+  unsigned long long *link_top;  // [batch] next free link (absolute index)
+  // per utterance [max_frames + 1]: links leaving frame f's tokens
+  long long *link_emit_base;     // into frame f+1
+  int32_t *link_emit_count;
+  long long *link_eps_base;      // into frame f itself
+  int32_t *link_eps_count;
+};
+
+struct LatticeParams {
+  const StateRec *states;
+  const ArcRec *arcs;
+  int32_t start;
+  float lattice_beam;
+  const int32_t *tok_state;
+  const double *tok_cost;
+  float *tok_extra;
+  int32_t *tok_newid;        // [arena] state id in the exported lattice, -1 if pruned
+  const long long *frame_base;
+  const int32_t *frame_count;
+  int32_t max_frames;
+  const int32_t *frames_decoded;
+  const int32_t *link_src;
+  int32_t *link_dst;
+  const int32_t *link_arc;
+  const float *link_ac;
+  const float *link_graph;
+  const long long *link_emit_base;
+  const int32_t *link_emit_count;
+  const long long *link_eps_base;
+  const int32_t *link_eps_count;
+  uint32_t *scratch;         // [batch][scratch_stride] per-frame extra-cost keys beyond LDS
+  long long scratch_stride;
+  // per utterance results
+  float *final_relative_cost;
+  float *final_best_cost;
+  int32_t *any_final;
+  int32_t stats_only;        // 1: ComputeFinalCosts only (FinalRelativeCost before finalizing)
+  int32_t use_final_probs;
+  int32_t finalized;
+  // export
+  int32_t *sizes;            // [batch][4]: states, arcs, finals, start
+  const long long *out_state_off, *out_arc_off, *out_final_off;
+  int32_t *o_src, *o_dst, *o_ilabel, *o_olabel, *o_state_frame, *o_state_graph, *o_final_state;
+  float *o_graph, *o_ac, *o_final_graph;
 };
 
 struct PathParams {
@@ -123,6 +178,9 @@ hipError_t LaunchSearch(const SearchParams &p, int batch, hipStream_t stream);
 size_t SearchLdsBytes();
 hipError_t LaunchPathPrepare(const PathParams &p, int batch, hipStream_t stream);
 hipError_t LaunchPathFill(const PathParams &p, int batch, hipStream_t stream);
+hipError_t LaunchLatticePrune(const LatticeParams &p, int batch, hipStream_t stream);
+hipError_t LaunchLatticeCount(const LatticeParams &p, int batch, hipStream_t stream);
+hipError_t LaunchLatticeFill(const LatticeParams &p, int batch, hipStream_t stream);
 
 // Order-preserving map double -> uint64 (so integer atomicMin orders costs).
 __host__ __device__ inline unsigned long long CostKey(double d) {

@@ -91,6 +91,10 @@ struct Shared {
   int32_t f_nlt, f_nle;
   int32_t n_live;               // slots holding a token this frame (== live-list length)
   int32_t q_n;                  // candidate queue length
+  int32_t n_emit_links;         // lattice: emitting entries below the final cutoff
+  int32_t n_eps_links;          // lattice: epsilon links written so far
+  int32_t n_emit_written;       // lattice: emitting links written so far
+  long long link_next;          // lattice: next free link of this utterance
   int32_t overflow;
   int32_t wl_count[2];
   int32_t it_count[2], it_next[2];
@@ -252,7 +256,9 @@ struct FrameCtx {
   // candidate queue: destination (state|flag, later its slot), arc, source, cost key
   KD_G uint32_t *q_h, *q_arc, *q_src;
   KD_G unsigned long long *q_nk;
+  KD_G float *q_ac;
   int q_cap;
+  bool lattice;
 };
 
 // Scores one arc out of a token with cost `csrc` and queues it if it survives
@@ -264,16 +270,34 @@ __device__ __forceinline__ void FilterArc(const FrameCtx &c, const ArcRec &a, ui
   Shared &s = c.s;
   double nc;
   bool keep;
+  float aux = 0.f;  // lattice: acoustic cost (emitting) / source cost (epsilon)
   unsigned long long seen_min = 0;
   if constexpr (EPS) {
-    nc = csrc + a.weight;     // faster-decoder.h:134
-    keep = !(nc > c.cutoff);  // faster-decoder.cc:92
+    if (c.lattice) {
+      // lattice-simple-decoder.cc:170-174: float, strict
+      const float cur_cost = static_cast<float>(csrc), tot_cost = cur_cost + a.weight;
+      nc = tot_cost;
+      keep = tot_cost < static_cast<float>(c.cutoff);
+      aux = cur_cost;
+    } else {
+      nc = csrc + a.weight;     // faster-decoder.h:134
+      keep = !(nc > c.cutoff);  // faster-decoder.cc:92
+    }
   } else {
     const float ll = c.ll_in_lds ? s.ll[a.ilabel - 1] : c.ll_row[a.ilabel - 1];
-    const float ac_cost = -1 * ll;   // :209
-    nc = a.weight + csrc + ac_cost;  // :210 (== Token cost, faster-decoder.h:126)
     seen_min = s.min_new;
-    keep = nc < KeyCost(seen_min) + static_cast<double>(c.adaptive_beam);  // :211, :215-217
+    if (c.lattice) {
+      // lattice-simple-decoder.cc:383-390: float, cur + ac + graph
+      const float ac_cost = -ll, cur_cost = static_cast<float>(csrc),
+                  tot_cost = cur_cost + ac_cost + a.weight;
+      nc = tot_cost;
+      keep = tot_cost < static_cast<float>(KeyCost(seen_min)) + c.adaptive_beam;
+      aux = ac_cost;
+    } else {
+      const float ac_cost = -1 * ll;   // :209
+      nc = a.weight + csrc + ac_cost;  // :210 (== Token cost, faster-decoder.h:126)
+      keep = nc < KeyCost(seen_min) + static_cast<double>(c.adaptive_beam);  // :211, :215-217
+    }
   }
   if (keep) {
     const unsigned long long nk = CostKey(nc);
@@ -283,6 +307,7 @@ __device__ __forceinline__ void FilterArc(const FrameCtx &c, const ArcRec &a, ui
       c.q_arc[pos] = aidx;
       c.q_src[pos] = srcid;
       c.q_nk[pos] = nk;
+      if (c.lattice) c.q_ac[pos] = aux;
     }
     if constexpr (!EPS) {
       if (nk < seen_min) atomicMin(&s.min_new, nk);
@@ -435,6 +460,7 @@ __device__ __forceinline__ void Insert(const FrameCtx &c, const Table<LDS> &t, i
           push = !(atomicOr(&t.bitmask[h >> 5], bit) & bit);
         }
         if (push) wl_out[atomicAdd(&s.wl_count[wl_out_idx], 1)] = h;
+        if (!EPS && c.lattice) atomicAdd(&s.n_emit_links, 1);
       }
     }
     c.q_h[i] = h;
@@ -518,7 +544,8 @@ __device__ __forceinline__ void GetCutoff(FrameCtx &c) {
   const double best_cost = KeyCost(s.f_best);
   const double beam_cutoff = best_cost + p.beam;
   if (p.max_active == INT_MAX && p.min_active == 0) {  // :249-272
-    c.weight_cutoff = beam_cutoff;
+    // LatticeSimpleDecoder has no cutoff on the tokens it expands (:376-401)
+    c.weight_cutoff = p.lattice ? __longlong_as_double(0x7FF0000000000000ll) : beam_cutoff;
     c.adaptive_beam = p.beam;
     return;
   }
@@ -539,6 +566,8 @@ __device__ __forceinline__ void GetCutoff(FrameCtx &c) {
     c.weight_cutoff = max_active_cutoff;
     return;
   }
+  // the lattice decoders keep the cutoff in float
+  const double beam_cutoff_r = p.lattice ? static_cast<double>(static_cast<float>(beam_cutoff)) : beam_cutoff;
   double min_active_cutoff = beam_cutoff;  // "not looser" unless proven below
   if (c.n_in > p.min_active) {             // :311-323
     if (p.min_active == 0) min_active_cutoff = best_cost;
@@ -551,7 +580,7 @@ __device__ __forceinline__ void GetCutoff(FrameCtx &c) {
     c.weight_cutoff = min_active_cutoff;
   } else {
     c.adaptive_beam = p.beam;
-    c.weight_cutoff = beam_cutoff;
+    c.weight_cutoff = beam_cutoff_r;
   }
 }
 
@@ -576,7 +605,9 @@ __device__ __forceinline__ void FrameFront(FrameCtx &c, Counters &cnt) {
       const ArcRec arc = LoadArcRec(p.arcs, static_cast<uint32_t>(babeg + a));
       const float ll = c.ll_in_lds ? s.ll[arc.ilabel - 1] : c.ll_row[arc.ilabel - 1];
       const float ac_cost = -1 * ll;
-      const unsigned long long k = CostKey(arc.weight + bcost + ac_cost);
+      const unsigned long long k =
+          c.lattice ? CostKey(static_cast<double>(static_cast<float>(bcost) + ac_cost + arc.weight))
+                    : CostKey(arc.weight + bcost + ac_cost);
       mk = k < mk ? k : mk;
     }
     mk = WaveMinU64(mk);
@@ -585,7 +616,10 @@ __device__ __forceinline__ void FrameFront(FrameCtx &c, Counters &cnt) {
   KD_LAP(s, 2);
   Table<true> none{s, nullptr, nullptr, nullptr, nullptr, 0, 0};
   Filter<true, false>(c, none, c.n_in, nullptr, cnt);
-  c.cutoff = KeyCost(s.min_new) + static_cast<double>(c.adaptive_beam);  // value of :240
+  if (c.lattice)  // float, lattice-simple-decoder.cc:388-390
+    c.cutoff = static_cast<float>(KeyCost(s.min_new)) + c.adaptive_beam;
+  else
+    c.cutoff = KeyCost(s.min_new) + static_cast<double>(c.adaptive_beam);  // value of :240
 }
 
 template <bool LDS>
@@ -723,6 +757,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
       const long long g = base_out + i;
       ToG(p.tok_state)[g] = static_cast<int32_t>(t.LoadKey(h) & kStateMask);
       ToG(p.tok_cost)[g] = KeyCost(ck);
+      if (c.lattice) ToG(p.tok_extra)[g] = 0.0f;  // lattice-simple-decoder.cc:91-95
       if (t.LoadArc(h) == kArcNone) {  // the start token
         ToG(p.tok_prev)[g] = -1;
         ToG(p.tok_arc)[g] = -1;
@@ -753,6 +788,43 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
       if (h == kKeyEmpty) continue;
       const uint32_t aidx = c.q_arc[i];
       if (t.LoadCost(h) == c.q_nk[i] && t.LoadArc(h) == aidx) write_bp(h, aidx, i);
+    }
+  }
+  // Lattice decoders: every queue entry below the cutoff is a ForwardLink
+  // (lattice-simple-decoder.cc:393-398, :179-180).  Emitting links leave the
+  // previous frame's tokens; epsilon links stay inside this frame and are kept
+  // only if generated from their source token's final cost (:164-165 deletes
+  // and regenerates the links of a re-expanded token).
+  if (c.lattice) {
+    const long long lbase = s.link_next;
+    const int n_emit = s.n_emit_links;
+    const bool full = lbase + n_emit + (n_q - q_emit) >
+                      static_cast<long long>(c.utt + 1) * static_cast<long long>(p.link_cap);
+    if (full) return KD_UTT_ARENA_FULL;
+    for (int i = tid; i < n_q; i += kBlock) {
+      const uint32_t h = c.q_h[i];
+      if (h == kKeyEmpty) continue;
+      const uint32_t sr = c.q_src[i];
+      long long at, src_tok;
+      float ac;
+      if (i < q_emit) {
+        src_tok = c.base_in + sr;
+        ac = c.q_ac[i];
+        at = lbase + atomicAdd(&s.n_emit_written, 1);
+      } else {
+        const uint32_t hs = sr & ~kSrcEps;
+        // source cost at generation vs its final cost (its slot's cost word is intact)
+        if (c.q_ac[i] != static_cast<float>(KeyCost(t.LoadCost(hs)))) continue;
+        src_tok = base_out + t.LoadKey(hs);
+        ac = 0.0f;
+        at = lbase + n_emit + atomicAdd(&s.n_eps_links, 1);
+      }
+      const uint32_t aidx = c.q_arc[i];
+      ToG(p.link_src)[at] = static_cast<int32_t>(src_tok);
+      ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + t.LoadKey(h));
+      ToG(p.link_arc)[at] = static_cast<int32_t>(aidx);
+      ToG(p.link_ac)[at] = ac;
+      ToG(p.link_graph)[at] = LoadArcRec(p.arcs, aidx).weight;
     }
   }
   // next frame's best token: fetch its arc range now, off the critical path
@@ -793,6 +865,17 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
     }
     if (!LDS) s.stat[KD_STAT_SPILL_FRAMES] += 1;
     s.f_best = best;
+    if (c.lattice) {
+      const long long lbase = s.link_next;
+      const long long fb = static_cast<long long>(c.utt) * (p.max_frames + 1);
+      if (frame >= 0) {
+        ToG(p.link_emit_base)[fb + frame] = lbase;
+        ToG(p.link_emit_count)[fb + frame] = s.n_emit_links;
+      }
+      ToG(p.link_eps_base)[fb + frame + 1] = lbase + s.n_emit_links;
+      ToG(p.link_eps_count)[fb + frame + 1] = s.n_eps_links;
+      s.link_next = lbase + s.n_emit_links + s.n_eps_links;
+    }
   }
   c.base_in = base_out;
   c.n_in = n_out;
@@ -809,6 +892,8 @@ __device__ __forceinline__ void InitCtx(FrameCtx &c, const SearchParams &p, int 
   c.q_arc = ToG(p.g_log_arc) + utt * 2 * gslots;
   c.q_src = ToG(p.g_log_src) + utt * 2 * gslots;
   c.q_nk = ToG(p.g_log_nk) + utt * 2 * gslots;
+  c.q_ac = ToG(p.g_log_ac) + utt * 2 * gslots;
+  c.lattice = p.lattice != 0;
   c.ll_in_lds = p.num_cols <= kVmax;
 }
 
@@ -872,9 +957,13 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
 
   c.base_in = 0;
   c.n_in = 0;
-  if (tid == 0)
+  if (tid == 0) {
     s.arena_next = p.do_init ? static_cast<long long>(utt) * static_cast<long long>(p.arena_cap)
                              : static_cast<long long>(ToG(p.arena_top)[utt]);
+    if (p.lattice)
+      s.link_next = p.do_init ? static_cast<long long>(utt) * static_cast<long long>(p.link_cap)
+                              : static_cast<long long>(ToG(p.link_top)[utt]);
+  }
   if (frame >= 0 && frame < target) {
     const long long fi = static_cast<long long>(utt) * (p.max_frames + 1) + frame;
     c.base_in = ToG(p.frame_base)[fi];
@@ -895,6 +984,9 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
       s.overflow = 0;
       s.f_nlt = 0;
       s.f_nle = 0;
+      s.n_emit_links = 0;
+      s.n_eps_links = 0;
+      s.n_emit_written = 0;
     }
     if (frame >= 0) {
       c.ll_row = ToG(ud.ll) + static_cast<long long>(frame - ud.offset) * p.row_stride;
@@ -908,7 +1000,9 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
       FrameFront(c, cnt);
       q_emit = s.q_n;
     } else {
-      c.cutoff = static_cast<double>(FLT_MAX);  // faster-decoder.cc:53
+      // faster-decoder.cc:53; the lattice decoders use best (= 0) + beam
+      // (lattice-simple-decoder.cc:135-154)
+      c.cutoff = p.lattice ? static_cast<double>(0.0f + p.beam) : static_cast<double>(FLT_MAX);
     }
     uint32_t r = 1;
     // the queue is a complete journal of the frame's inserts: a frame that does
@@ -952,6 +1046,7 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
     ToG(p.frames_decoded)[utt] = frame < 0 ? -1 : frame;
     ToG(p.status)[utt] = err;
     ToG(p.arena_top)[utt] = static_cast<unsigned long long>(s.arena_next);
+    if (p.lattice) ToG(p.link_top)[utt] = static_cast<unsigned long long>(s.link_next);
   }
   if (tid < KD_NUM_STATS) {
     KD_G long long *st = ToG(p.stats) + static_cast<long long>(utt) * kStatStride;

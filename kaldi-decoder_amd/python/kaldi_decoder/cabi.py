@@ -30,6 +30,8 @@ SYMBOLS = (
     "kd_batch_status", "kd_batch_reached_final", "kd_batch_best_path_prepare",
     "kd_batch_best_path_copy", "kd_batch_frame_tokens", "kd_batch_stats",
     "kd_batch_last_kernel_ms", "kd_batch_device_bytes", "kd_batch_phase_cycles",
+    "kd_lattice_options_default", "kd_batch_create_lattice", "kd_batch_finalize_decoding",
+    "kd_batch_final_relative_cost", "kd_batch_raw_lattice_prepare", "kd_batch_raw_lattice_copy",
 )
 
 
@@ -38,6 +40,14 @@ class FasterOptions(C.Structure):
                 ("beam_delta", C.c_float), ("hash_ratio", C.c_float),
                 ("arena_tokens", C.c_int64), ("table_slots", C.c_int32),
                 ("max_frames", C.c_int32)]
+
+
+class LatticeOptions(C.Structure):
+    _fields_ = [("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32),
+                ("lattice_beam", C.c_float), ("prune_interval", C.c_int32),
+                ("beam_delta", C.c_float), ("hash_ratio", C.c_float), ("prune_scale", C.c_float),
+                ("arena_tokens", C.c_int64), ("arena_links", C.c_int64),
+                ("table_slots", C.c_int32), ("max_frames", C.c_int32)]
 
 
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -97,6 +107,16 @@ def lib():
     L.kd_batch_device_bytes.argtypes = [C.c_void_p]
     L.kd_batch_device_bytes.restype = C.c_size_t
     L.kd_batch_phase_cycles.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int64)]
+    L.kd_lattice_options_default.argtypes = [C.POINTER(LatticeOptions)]
+    L.kd_lattice_options_default.restype = None
+    L.kd_batch_create_lattice.argtypes = [C.c_void_p, C.POINTER(LatticeOptions), C.c_int32,
+                                          C.c_void_p, C.POINTER(C.c_void_p)]
+    L.kd_batch_finalize_decoding.argtypes = [C.c_void_p]
+    L.kd_batch_final_relative_cost.argtypes = [C.c_void_p, _f32p]
+    L.kd_batch_raw_lattice_prepare.argtypes = [C.c_void_p, C.c_int32, _i32p]
+    _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+    L.kd_batch_raw_lattice_copy.argtypes = [C.c_void_p, _i64p, _i64p, _i64p, _i32p, _i32p, _i32p,
+                                            _i32p, _f32p, _f32p, _i32p, _i32p, _i32p, _f32p]
     _lib = L
     return L
 
@@ -170,6 +190,37 @@ class Path:
     def total_cost(self):
         return (float(self.graph_cost.astype(np.float64).sum() + self.final_weight[0]),
                 float(self.ac_cost.astype(np.float64).sum() + self.final_weight[1]))
+
+
+class RawLattice:
+    """GetRawLattice output of one utterance as arrays (states are frame-major)."""
+
+    def __init__(self, ok, num_states, start, src, dst, il, ol, gc, ac, sf, sg, fs, fg):
+        self.ok, self.num_states, self.start = ok, num_states, start
+        self.src, self.dst, self.ilabel, self.olabel = src, dst, il, ol
+        self.graph_cost, self.ac_cost = gc, ac
+        self.state_frame, self.state_graph = sf, sg
+        self.final_state, self.final_graph = fs, fg
+
+    def arc_set(self):
+        f, s = self.state_frame, self.state_graph
+        return set(zip(f[self.src].tolist(), s[self.src].tolist(), f[self.dst].tolist(),
+                       s[self.dst].tolist(), self.ilabel.tolist(), self.olabel.tolist(),
+                       self.graph_cost.tolist(), self.ac_cost.tolist()))
+
+    def state_set(self):
+        return set(zip(self.state_frame.tolist(), self.state_graph.tolist()))
+
+    def final_set(self):
+        return set(zip(self.state_graph[self.final_state].tolist(), self.final_graph.tolist()))
+
+
+def default_lattice_options(**kw):
+    o = LatticeOptions()
+    lib().kd_lattice_options_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
 
 
 class Batch:
@@ -293,3 +344,50 @@ class Batch:
     @property
     def device_bytes(self):
         return lib().kd_batch_device_bytes(self.h)
+
+
+class LatticeBatch(Batch):
+    """`max_batch` lattice decoders (LatticeSimpleDecoder semantics; with max_active /
+    min_active the LatticeFasterDecoder configuration) over one graph."""
+
+    def __init__(self, graph: Graph, max_batch=1, stream=None, **opts):
+        self.graph = graph
+        self.max_batch = max_batch
+        self.lopts = default_lattice_options(**opts)
+        self.h = C.c_void_p()
+        self.batch = 0
+        _check(lib().kd_batch_create_lattice(graph.h, C.byref(self.lopts), max_batch,
+                                             C.c_void_p(stream or 0), C.byref(self.h)))
+
+    def finalize_decoding(self):
+        _check(lib().kd_batch_finalize_decoding(self.h))
+
+    def final_relative_cost(self):
+        out = np.zeros(self.batch, np.float32)
+        _check(lib().kd_batch_final_relative_cost(self.h, out))
+        return out
+
+    def raw_lattices(self, use_final_probs=True):
+        sizes = np.zeros(4 * self.batch, np.int32)
+        _check(lib().kd_batch_raw_lattice_prepare(self.h, int(use_final_probs), sizes))
+        sz = sizes.reshape(self.batch, 4).astype(np.int64)
+        so, ao, fo = (np.zeros(self.batch, np.int64) for _ in range(3))
+        so[1:], ao[1:], fo[1:] = np.cumsum(sz[:-1, 0]), np.cumsum(sz[:-1, 1]), np.cumsum(sz[:-1, 2])
+        ns, na, nf = (max(int(sz[:, k].sum()), 1) for k in range(3))
+        src, dst, il, ol = (np.zeros(na, np.int32) for _ in range(4))
+        gc, ac = np.zeros(na, np.float32), np.zeros(na, np.float32)
+        sf, sg = np.zeros(ns, np.int32), np.zeros(ns, np.int32)
+        fs, fg = np.zeros(nf, np.int32), np.zeros(nf, np.float32)
+        _check(lib().kd_batch_raw_lattice_copy(self.h, so, ao, fo, src, dst, il, ol, gc, ac, sf,
+                                               sg, fs, fg))
+        out = []
+        for i in range(self.batch):
+            a, b = int(ao[i]), int(ao[i] + sz[i, 1])
+            s0, s1 = int(so[i]), int(so[i] + sz[i, 0])
+            f0, f1 = int(fo[i]), int(fo[i] + sz[i, 2])
+            out.append(RawLattice(bool(sz[i, 0] > 0), int(sz[i, 0]), int(sz[i, 3]),
+                                  src[a:b].copy(), dst[a:b].copy(), il[a:b].copy(),
+                                  ol[a:b].copy(), gc[a:b].copy(), ac[a:b].copy(),
+                                  sf[s0:s1].copy(), sg[s0:s1].copy(), fs[f0:f1].copy(),
+                                  fg[f0:f1].copy()))
+        return out

@@ -1,0 +1,100 @@
+"""GPU parity of the lattice decoders against the oracle's canonical lattice
+policy: identical lattices (as numbering-free arc sets with bit-equal float
+costs), identical state sets, final weights and final_relative_cost."""
+import numpy as np
+import pytest
+
+from kaldi_decoder import cabi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    for seed in range(3):
+        yield (f"rand{seed}", synth.random_graph(150 + 200 * seed, 3.0, 16, 0.2, 300 + seed), None,
+               16, dict(beam=6.0 + seed, lattice_beam=3.0 + seed, min_active=0))
+    g = synth.hl_graph(V=30, n_words=200, seed=5)
+    yield "HL", g, g["lexicon"], 30, dict(beam=10.0, lattice_beam=6.0, min_active=0)
+    g = synth.hlg_graph(V=30, n_words=100, n_hist=100, avg_succ=6, seed=6)
+    yield "HLG", g, g["lexicon"], 30, dict(beam=9.0, lattice_beam=5.0, min_active=0)
+    yield "HLGfaster", g, g["lexicon"], 30, dict(beam=9.0, lattice_beam=5.0, max_active=60,
+                                                 min_active=10)
+    yield "H16", synth.ctc_topo(16), None, 16, dict(beam=8.0, lattice_beam=4.0, min_active=0)
+
+
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+def test_raw_lattice_matches_canonical_oracle(oracle, case):
+    name, g, lex, V, opts = case
+    B, T = 3, 50
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lps = [synth.make_logprobs(T - 4 * i, V, i, peak=5.0, lexicon=lex) for i in range(B)]
+    lb = cabi.LatticeBatch(G, max_batch=B, **opts)
+    lb.init_decoding()
+    lb.advance_host(lps)
+    frc_before = lb.final_relative_cost()
+    lb.finalize_decoding()
+    lats = lb.raw_lattices()
+    frc = lb.final_relative_cost()
+    for i in range(B):
+        oo = {k: v for k, v in opts.items() if k != "prune_interval"}
+        can = oracle.CanonLatticeDecoder(OG, **oo)
+        can.decode(lps[i])
+        cl = can.get_raw_lattice()
+        gl = lats[i]
+        assert gl.ok == cl.ok, (name, i)
+        assert gl.num_states == cl.num_states, (name, i)
+        assert gl.state_set() == cl.state_set(), (name, i)
+        assert gl.arc_set() == cl.arc_set(), (name, i)
+        assert gl.final_set() == cl.final_set(), (name, i)
+        assert gl.state_graph[gl.start] == g["start"] and gl.state_frame[gl.start] == 0
+        assert frc[i] == can.final_relative_cost() == frc_before[i], (name, i)
+        # states are frame-major
+        assert np.all(np.diff(gl.state_frame) >= 0)
+
+
+def test_lattice_superset_of_reference_order_decoder_minus_extras(oracle):
+    # against the reference restatement itself (policy 0): GPU lattice is contained in it
+    g = synth.hlg_graph(V=30, n_words=100, n_hist=100, avg_succ=6, seed=6)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lp = synth.make_logprobs(60, 30, 2, peak=5.0, lexicon=g["lexicon"])
+    lb = cabi.LatticeBatch(G, max_batch=1, beam=9.0, lattice_beam=5.0, min_active=0)
+    lb.init_decoding()
+    lb.advance_host([lp])
+    lb.finalize_decoding()
+    gl = lb.raw_lattices()[0]
+    ref = oracle.LatticeSimpleDecoder(OG, beam=9.0, lattice_beam=5.0)
+    ref.decode(lp)
+    rl = ref.get_raw_lattice()
+    assert gl.arc_set() <= rl.arc_set()
+    assert lb.final_relative_cost()[0] == ref.final_relative_cost()
+
+
+def test_lattice_error_behaviour_and_unfinalized_export(oracle):
+    g = synth.random_graph(100, 3.0, 8, 0.2, 5)
+    G = cabi.Graph(g)
+    with pytest.raises(RuntimeError, match="Check failed"):
+        cabi.LatticeBatch(G, lattice_beam=0.0)  # lattice-faster-decoder.h:128-133
+    with pytest.raises(RuntimeError, match="Check failed"):
+        cabi.LatticeBatch(G, prune_scale=1.5)
+    lb = cabi.LatticeBatch(G, max_batch=1, beam=8.0, lattice_beam=4.0, min_active=0)
+    lp = synth.make_logprobs(20, 8, 0, peak=4.0)
+    lb.init_decoding()
+    with pytest.raises(RuntimeError, match="num_frames > 0"):
+        lb.raw_lattices()  # lattice-simple-decoder.cc:610
+    lb.advance_host([lp])
+    raw_nf = lb.raw_lattices(use_final_probs=False)[0]   # allowed before FinalizeDecoding
+    raw = lb.raw_lattices(use_final_probs=True)[0]
+    assert raw.num_states == raw_nf.num_states and len(raw_nf.final_state) >= len(raw.final_state)
+    lb.finalize_decoding()
+    pruned = lb.raw_lattices()[0]
+    assert pruned.arc_set() <= raw.arc_set() and pruned.num_states <= raw.num_states
+    with pytest.raises(RuntimeError, match="use_final_probs == false"):
+        lb.raw_lattices(use_final_probs=False)  # :594-597
+    with pytest.raises(RuntimeError, match="decoding_finalized_"):
+        lb.finalize_decoding()
+    with pytest.raises(RuntimeError, match="FinalizeDecoding"):
+        lb.advance_host([lp])
+    lb.init_decoding()  # a new utterance resets everything
+    lb.advance_host([lp])
+    lb.finalize_decoding()
+    assert lb.raw_lattices()[0].arc_set() == pruned.arc_set()
