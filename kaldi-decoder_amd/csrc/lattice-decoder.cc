@@ -1,0 +1,262 @@
+// kaldi-decoder_amd/csrc/lattice-decoder.cc -- marshalling for the lattice decoders
+// and the host-side shortest path over an exported lattice.
+
+#include "lattice-decoder.h"
+
+#include <algorithm>
+
+namespace kaldi_decoder {
+
+// Frames a decodable holds: NumFramesReady(), or -- for decodables that only
+// implement IsLastFrame(), which is all LatticeSimpleDecoder::Decode uses
+// (lattice-simple-decoder.cc:56) -- the first frame for which it returns true.
+static int32_t FramesOf(DecodableInterface *d) {
+  try {
+    return d->NumFramesReady();
+  } catch (const std::exception &) {
+    int32_t f = -1;
+    while (!d->IsLastFrame(f)) ++f;
+    return f + 1;
+  }
+}
+
+static kd_lattice_options ToC(const LatticeFasterDecoderConfig &c, const DeviceOptions &d) {
+  kd_lattice_options o;
+  kd_lattice_options_default(&o);
+  o.beam = c.beam;
+  o.max_active = c.max_active;
+  o.min_active = c.min_active;
+  o.lattice_beam = c.lattice_beam;
+  o.prune_interval = c.prune_interval;
+  o.beam_delta = c.beam_delta;
+  o.hash_ratio = c.hash_ratio;
+  o.prune_scale = c.prune_scale;
+  o.arena_tokens = d.arena_tokens;
+  o.table_slots = d.table_slots;
+  o.max_frames = d.max_frames;
+  return o;
+}
+
+BatchLatticeDecoder::BatchLatticeDecoder(const Fst &fst, const LatticeFasterDecoderConfig &config,
+                                         int32_t max_batch, const DeviceOptions &dev)
+    : fst_(fst), max_batch_(max_batch) {
+  const kd_lattice_options o = ToC(config, dev);
+  KdCheck(kd_batch_create_lattice(fst.OnDevice(dev.device), &o, max_batch, nullptr, &b_));
+}
+
+BatchLatticeDecoder::~BatchLatticeDecoder() { kd_batch_destroy(b_); }
+
+void BatchLatticeDecoder::InitDecoding(int32_t batch) {
+  KdCheck(kd_batch_init_decoding(b_, batch));
+  batch_ = batch;
+}
+
+void BatchLatticeDecoder::AdvanceDecoding(const std::vector<DecodableInterface *> &decodables,
+                                          int32_t max_num_frames) {
+  if (batch_ == 0) throw std::runtime_error("You must call InitDecoding() before AdvanceDecoding()");
+  if (static_cast<int32_t>(decodables.size()) != batch_)
+    throw std::runtime_error("AdvanceDecoding: one decodable per utterance expected");
+  std::vector<int32_t> decoded(batch_);
+  KdCheck(kd_batch_num_frames_decoded(b_, decoded.data()));
+  std::vector<const float *> ptr(batch_);
+  std::vector<int32_t> rows(batch_), off(batch_);
+  const int32_t cols = decodables[0]->NumIndices();
+  bool all_ctc = true, all_dev = true, any_dev = false;
+  int64_t stride = -1;
+  for (int i = 0; i < batch_; ++i) {
+    auto *d = dynamic_cast<DecodableCtc *>(decodables[i]);
+    if (!d) { all_ctc = false; all_dev = false; continue; }
+    any_dev |= d->OnDevice();
+    all_dev &= d->OnDevice();
+    if (stride < 0) stride = d->RowStride();
+    if (d->RowStride() != stride || d->NumCols() != cols) all_ctc = false;
+  }
+  if (any_dev && !all_dev) throw std::runtime_error("AdvanceDecoding: mix of host and device decodables");
+  if (all_ctc) {
+    for (int i = 0; i < batch_; ++i) {
+      auto *d = static_cast<DecodableCtc *>(decodables[i]);
+      ptr[i] = d->Data();
+      rows[i] = d->NumRows();
+      off[i] = d->Offset();
+    }
+    KdCheck(kd_batch_advance(b_, ptr.data(), rows.data(), off.data(), cols, stride,
+                             all_dev ? KD_MEM_DEVICE : KD_MEM_HOST, max_num_frames));
+    return;
+  }
+  size_t total = 0;
+  std::vector<size_t> start(batch_);
+  for (int i = 0; i < batch_; ++i) {
+    if (decodables[i]->NumIndices() != cols) throw std::runtime_error("AdvanceDecoding: NumIndices() differ");
+    int32_t target = FramesOf(decodables[i]);
+    if (max_num_frames >= 0) target = std::min(target, decoded[i] + max_num_frames);
+    rows[i] = std::max(target - decoded[i], 0);
+    off[i] = decoded[i];
+    start[i] = total;
+    total += static_cast<size_t>(rows[i]) * cols;
+  }
+  scratch_.resize(std::max<size_t>(total, 1));
+  for (int i = 0; i < batch_; ++i) {
+    float *dst = scratch_.data() + start[i];
+    for (int32_t f = 0; f < rows[i]; ++f)
+      for (int32_t k = 1; k <= cols; ++k)
+        dst[static_cast<size_t>(f) * cols + k - 1] = decodables[i]->LogLikelihood(decoded[i] + f, k);
+    ptr[i] = dst;
+  }
+  KdCheck(kd_batch_advance(b_, ptr.data(), rows.data(), off.data(), cols, cols, KD_MEM_HOST, -1));
+}
+
+void BatchLatticeDecoder::FinalizeDecoding() { KdCheck(kd_batch_finalize_decoding(b_)); }
+
+std::vector<bool> BatchLatticeDecoder::Decode(const std::vector<DecodableInterface *> &decodables) {
+  InitDecoding(static_cast<int32_t>(decodables.size()));  // lattice-simple-decoder.cc:53-73
+  AdvanceDecoding(decodables);
+  FinalizeDecoding();
+  // the reference returns !final_costs_.empty(): some token of the last frame is in a final state
+  std::vector<float> frc = FinalRelativeCost();
+  std::vector<bool> r(batch_);
+  for (int i = 0; i < batch_; ++i) r[i] = frc[i] != std::numeric_limits<float>::infinity();
+  return r;
+}
+
+std::vector<float> BatchLatticeDecoder::FinalRelativeCost() const {
+  std::vector<float> r(std::max(batch_, 1));
+  KdCheck(kd_batch_final_relative_cost(b_, r.data()));
+  r.resize(batch_);
+  return r;
+}
+
+std::vector<int32_t> BatchLatticeDecoder::NumFramesDecoded() const {
+  if (batch_ == 0) return {-1};
+  std::vector<int32_t> r(batch_);
+  KdCheck(kd_batch_num_frames_decoded(b_, r.data()));
+  return r;
+}
+
+std::vector<bool> BatchLatticeDecoder::GetRawLattice(
+    std::vector<Lattice> *out, bool use_final_probs,
+    std::vector<std::vector<int32_t>> *state_frame) const {
+  std::vector<int32_t> sz(4 * static_cast<size_t>(std::max(batch_, 1)));
+  KdCheck(kd_batch_raw_lattice_prepare(b_, use_final_probs ? 1 : 0, sz.data()));
+  std::vector<int64_t> so(batch_), ao(batch_), fo(batch_);
+  size_t ns = 0, na = 0, nf = 0;
+  for (int i = 0; i < batch_; ++i) {
+    so[i] = static_cast<int64_t>(ns);
+    ao[i] = static_cast<int64_t>(na);
+    fo[i] = static_cast<int64_t>(nf);
+    ns += sz[4 * i];
+    na += sz[4 * i + 1];
+    nf += sz[4 * i + 2];
+  }
+  std::vector<int32_t> src(std::max<size_t>(na, 1)), dst(src.size()), il(src.size()), ol(src.size()),
+      sf(std::max<size_t>(ns, 1)), sg(sf.size()), fs(std::max<size_t>(nf, 1));
+  std::vector<float> gc(src.size()), ac(src.size()), fg(fs.size());
+  KdCheck(kd_batch_raw_lattice_copy(b_, so.data(), ao.data(), fo.data(), src.data(), dst.data(),
+                                    il.data(), ol.data(), gc.data(), ac.data(), sf.data(), sg.data(),
+                                    fs.data(), fg.data()));
+  out->assign(batch_, Lattice());
+  if (state_frame) state_frame->assign(batch_, {});
+  std::vector<bool> ok(batch_);
+  for (int i = 0; i < batch_; ++i) {
+    Lattice &lat = (*out)[i];
+    const int32_t n = sz[4 * i];
+    ok[i] = n > 0;
+    if (!ok[i]) continue;
+    for (int32_t s = 0; s < n; ++s) lat.AddState();
+    lat.SetStart(sz[4 * i + 3]);
+    for (int32_t k = 0; k < sz[4 * i + 1]; ++k) {
+      const size_t j = static_cast<size_t>(ao[i]) + k;
+      lat.AddArc(src[j], LatticeArc{il[j], ol[j], LatticeWeight{gc[j], ac[j]}, dst[j]});
+    }
+    for (int32_t k = 0; k < sz[4 * i + 2]; ++k) {
+      const size_t j = static_cast<size_t>(fo[i]) + k;
+      lat.SetFinal(fs[j], LatticeWeight{fg[j], 0.0f});
+    }
+    if (state_frame) (*state_frame)[i].assign(sf.begin() + so[i], sf.begin() + so[i] + n);
+  }
+  return ok;
+}
+
+std::vector<bool> BatchLatticeDecoder::GetBestPath(std::vector<Lattice> *out,
+                                                   bool use_final_probs) const {
+  std::vector<Lattice> raw;
+  GetRawLattice(&raw, use_final_probs);  // lattice-simple-decoder.cc:574-580
+  out->assign(batch_, Lattice());
+  std::vector<bool> ok(batch_);
+  for (int i = 0; i < batch_; ++i) {
+    ShortestPath(raw[i], &(*out)[i]);
+    ok[i] = (*out)[i].NumStates() > 0;
+  }
+  return ok;
+}
+
+float BatchLatticeDecoder::LastKernelMs() const {
+  float ms = 0.f;
+  KdCheck(kd_batch_last_kernel_ms(b_, &ms));
+  return ms;
+}
+
+std::vector<int64_t> BatchLatticeDecoder::Stats() const {
+  std::vector<int64_t> s(static_cast<size_t>(std::max(batch_, 1)) * KD_NUM_STATS);
+  KdCheck(kd_batch_stats(b_, s.data()));
+  return s;
+}
+
+bool ShortestPath(const Lattice &in, Lattice *out) {
+  out->DeleteStates();
+  const int32_t n = in.NumStates();
+  if (n == 0 || in.Start() < 0) return false;
+  const float inf = std::numeric_limits<float>::infinity();
+  std::vector<float> d1(n, inf), d2(n, inf);
+  std::vector<int32_t> back_state(n, -1), back_arc(n, -1);
+  auto better = [](float a1, float a2, float b1, float b2) {
+    const float sa = a1 + a2, sb = b1 + b2;
+    if (sa < sb) return true;
+    if (sa > sb) return false;
+    return a1 < b1;
+  };
+  // label-correcting relaxation (the lattice is acyclic; arc costs may be negative)
+  std::vector<int32_t> queue{in.Start()};
+  std::vector<char> inq(n, 0);
+  d1[in.Start()] = d2[in.Start()] = 0.f;
+  inq[in.Start()] = 1;
+  for (size_t qi = 0; qi < queue.size(); ++qi) {
+    const int32_t s = queue[qi];
+    inq[s] = 0;
+    const auto &arcs = in.Arcs(s);
+    for (size_t k = 0; k < arcs.size(); ++k) {
+      const LatticeArc &a = arcs[k];
+      const float n1 = d1[s] + a.weight.graph, n2 = d2[s] + a.weight.acoustic;
+      if (better(n1, n2, d1[a.nextstate], d2[a.nextstate])) {
+        d1[a.nextstate] = n1;
+        d2[a.nextstate] = n2;
+        back_state[a.nextstate] = s;
+        back_arc[a.nextstate] = static_cast<int32_t>(k);
+        if (!inq[a.nextstate]) { inq[a.nextstate] = 1; queue.push_back(a.nextstate); }
+      }
+    }
+  }
+  int32_t best = -1;
+  float b1 = inf, b2 = inf;
+  for (int32_t s = 0; s < n; ++s) {
+    const LatticeWeight f = in.Final(s);
+    if (f.IsZero() || d1[s] == inf) continue;
+    const float n1 = d1[s] + f.graph, n2 = d2[s] + f.acoustic;
+    if (best < 0 || better(n1, n2, b1, b2)) { best = s; b1 = n1; b2 = n2; }
+  }
+  if (best < 0) return false;
+  std::vector<LatticeArc> path;
+  for (int32_t s = best; s != in.Start(); s = back_state[s])
+    path.push_back(in.Arcs(back_state[s])[back_arc[s]]);
+  std::reverse(path.begin(), path.end());
+  int32_t cur = out->AddState();
+  out->SetStart(cur);
+  for (LatticeArc a : path) {
+    a.nextstate = out->AddState();
+    out->AddArc(cur, a);
+    cur = a.nextstate;
+  }
+  out->SetFinal(cur, in.Final(best));
+  return true;
+}
+
+}  // namespace kaldi_decoder

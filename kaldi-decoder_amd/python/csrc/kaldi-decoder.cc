@@ -20,6 +20,7 @@
 #include "decodable-itf.h"
 #include "faster-decoder.h"
 #include "fst.h"
+#include "lattice-decoder.h"
 
 namespace py = pybind11;
 using namespace kaldi_decoder;
@@ -198,6 +199,131 @@ PYBIND11_MODULE(_kaldi_decoder, m) {
       .def("advance_decoding", &FasterDecoder::AdvanceDecoding, py::arg("decodable"),
            py::arg("max_num_frames") = -1)
       .def("num_frames_decoded", &FasterDecoder::NumFramesDecoded);
+
+  // ---- lattice decoders (ref: python/csrc/lattice-simple-decoder.cc:15-68) ----
+  py::class_<LatticeSimpleDecoderConfig>(m, "LatticeSimpleDecoderConfig")
+      .def(py::init<float, float, int32_t, bool, bool, float, float>(), py::arg("beam") = 16.0,
+           py::arg("lattice_beam") = 10.0, py::arg("prune_interval") = 25,
+           py::arg("determinize_lattice") = true, py::arg("prune_lattice") = true,
+           py::arg("beam_ratio") = 0.9, py::arg("prune_scale") = 0.1)
+      .def_readwrite("beam", &LatticeSimpleDecoderConfig::beam)
+      .def_readwrite("lattice_beam", &LatticeSimpleDecoderConfig::lattice_beam)
+      .def_readwrite("prune_interval", &LatticeSimpleDecoderConfig::prune_interval)
+      .def_readwrite("determinize_lattice", &LatticeSimpleDecoderConfig::determinize_lattice)
+      .def_readwrite("prune_lattice", &LatticeSimpleDecoderConfig::prune_lattice)
+      .def_readwrite("beam_ratio", &LatticeSimpleDecoderConfig::beam_ratio)
+      .def_readwrite("prune_scale", &LatticeSimpleDecoderConfig::prune_scale)
+      .def("__str__", &LatticeSimpleDecoderConfig::ToString);
+
+  py::class_<LatticeFasterDecoderConfig>(m, "LatticeFasterDecoderConfig")
+      .def(py::init<float, int32_t, int32_t, float, int32_t, bool, float, float, float, int32_t,
+                    int32_t>(),
+           py::arg("beam") = 16.0, py::arg("max_active") = std::numeric_limits<int32_t>::max(),
+           py::arg("min_active") = 200, py::arg("lattice_beam") = 10.0,
+           py::arg("prune_interval") = 25, py::arg("determinize_lattice") = true,
+           py::arg("beam_delta") = 0.5, py::arg("hash_ratio") = 2.0, py::arg("prune_scale") = 0.1,
+           py::arg("memory_pool_tokens_block_size") = 1 << 8,
+           py::arg("memory_pool_links_block_size") = 1 << 8)
+      .def_readwrite("beam", &LatticeFasterDecoderConfig::beam)
+      .def_readwrite("max_active", &LatticeFasterDecoderConfig::max_active)
+      .def_readwrite("min_active", &LatticeFasterDecoderConfig::min_active)
+      .def_readwrite("lattice_beam", &LatticeFasterDecoderConfig::lattice_beam)
+      .def_readwrite("prune_interval", &LatticeFasterDecoderConfig::prune_interval)
+      .def_readwrite("determinize_lattice", &LatticeFasterDecoderConfig::determinize_lattice)
+      .def_readwrite("beam_delta", &LatticeFasterDecoderConfig::beam_delta)
+      .def_readwrite("hash_ratio", &LatticeFasterDecoderConfig::hash_ratio)
+      .def_readwrite("prune_scale", &LatticeFasterDecoderConfig::prune_scale)
+      .def_readwrite("memory_pool_tokens_block_size",
+                     &LatticeFasterDecoderConfig::memory_pool_tokens_block_size)
+      .def_readwrite("memory_pool_links_block_size",
+                     &LatticeFasterDecoderConfig::memory_pool_links_block_size)
+      .def("__str__", &LatticeFasterDecoderConfig::ToString);
+
+  auto best_path = [](auto &self, bool use_final_probs) {
+    Lattice lat;
+    const bool ok = self.GetBestPath(&lat, use_final_probs);
+    return std::make_pair(ok, std::move(lat));
+  };
+  auto raw_lattice = [](auto &self, bool use_final_probs) {
+    Lattice lat;
+    const bool ok = self.GetRawLattice(&lat, use_final_probs);
+    return std::make_pair(ok, std::move(lat));
+  };
+
+  py::class_<LatticeSimpleDecoder>(m, "LatticeSimpleDecoder")
+      .def(py::init<const Fst &, const LatticeSimpleDecoderConfig &, const DeviceOptions &>(),
+           py::arg("fst"), py::arg("config"), py::arg("device_options") = DeviceOptions(),
+           py::keep_alive<1, 2>())
+      .def("get_config", &LatticeSimpleDecoder::GetOptions)
+      .def("num_frames_decoded", &LatticeSimpleDecoder::NumFramesDecoded)
+      .def("final_relative_cost", &LatticeSimpleDecoder::FinalRelativeCost)
+      .def("decode", &LatticeSimpleDecoder::Decode, py::arg("decodable"))
+      .def("init_decoding", &LatticeSimpleDecoder::InitDecoding)
+      .def("finalize_decoding", &LatticeSimpleDecoder::FinalizeDecoding)
+      .def("get_best_path",
+           [best_path](LatticeSimpleDecoder &self, bool u) { return best_path(self, u); },
+           py::arg("use_final_probs") = true)
+      .def("get_raw_lattice",
+           [raw_lattice](LatticeSimpleDecoder &self, bool u) { return raw_lattice(self, u); },
+           py::arg("use_final_probs") = true);
+
+  py::class_<LatticeFasterDecoder>(m, "LatticeFasterDecoder")
+      .def(py::init<const Fst &, const LatticeFasterDecoderConfig &, const DeviceOptions &>(),
+           py::arg("fst"), py::arg("config"), py::arg("device_options") = DeviceOptions(),
+           py::keep_alive<1, 2>())
+      .def("get_config", &LatticeFasterDecoder::GetOptions)
+      .def("num_frames_decoded", &LatticeFasterDecoder::NumFramesDecoded)
+      .def("final_relative_cost", &LatticeFasterDecoder::FinalRelativeCost)
+      .def("decode", &LatticeFasterDecoder::Decode, py::arg("decodable"))
+      .def("init_decoding", &LatticeFasterDecoder::InitDecoding)
+      .def("advance_decoding", &LatticeFasterDecoder::AdvanceDecoding, py::arg("decodable"),
+           py::arg("max_num_frames") = -1)
+      .def("finalize_decoding", &LatticeFasterDecoder::FinalizeDecoding)
+      .def("get_best_path",
+           [best_path](LatticeFasterDecoder &self, bool u) { return best_path(self, u); },
+           py::arg("use_final_probs") = true)
+      .def("get_raw_lattice",
+           [raw_lattice](LatticeFasterDecoder &self, bool u) { return raw_lattice(self, u); },
+           py::arg("use_final_probs") = true);
+
+  py::class_<BatchLatticeDecoder>(m, "BatchLatticeDecoder")
+      .def(py::init<const Fst &, const LatticeFasterDecoderConfig &, int32_t, const DeviceOptions &>(),
+           py::arg("fst"), py::arg("config"), py::arg("max_batch"),
+           py::arg("device_options") = DeviceOptions(), py::keep_alive<1, 2>())
+      .def("decode", &BatchLatticeDecoder::Decode, py::arg("decodables"))
+      .def("init_decoding", &BatchLatticeDecoder::InitDecoding, py::arg("batch"))
+      .def("advance_decoding", &BatchLatticeDecoder::AdvanceDecoding, py::arg("decodables"),
+           py::arg("max_num_frames") = -1)
+      .def("finalize_decoding", &BatchLatticeDecoder::FinalizeDecoding)
+      .def("final_relative_cost", &BatchLatticeDecoder::FinalRelativeCost)
+      .def("num_frames_decoded", &BatchLatticeDecoder::NumFramesDecoded)
+      .def(
+          "get_raw_lattice",
+          [](BatchLatticeDecoder &self, bool u) {
+            std::vector<Lattice> lats;
+            std::vector<bool> ok = self.GetRawLattice(&lats, u);
+            return std::make_pair(ok, std::move(lats));
+          },
+          py::arg("use_final_probs") = true)
+      .def(
+          "get_best_path",
+          [](BatchLatticeDecoder &self, bool u) {
+            std::vector<Lattice> lats;
+            std::vector<bool> ok = self.GetBestPath(&lats, u);
+            return std::make_pair(ok, std::move(lats));
+          },
+          py::arg("use_final_probs") = true)
+      .def("stats", &BatchLatticeDecoder::Stats)
+      .def("last_kernel_ms", &BatchLatticeDecoder::LastKernelMs);
+
+  m.def(
+      "shortest_path",
+      [](const Lattice &l) {
+        Lattice out;
+        const bool ok = ShortestPath(l, &out);
+        return std::make_pair(ok, std::move(out));
+      },
+      py::arg("lattice"), "tropical shortest path through a lattice (fst::ShortestPath)");
 
   py::class_<BatchFasterDecoder>(m, "BatchFasterDecoder")
       .def(py::init<const Fst &, const FasterDecoderOptions &, int32_t, const DeviceOptions &>(),

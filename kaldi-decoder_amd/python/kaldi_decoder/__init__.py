@@ -22,6 +22,7 @@ except ImportError:  # pragma: no cover
 try:
     from .lib._kaldi_decoder import (  # noqa: F401
         BatchFasterDecoder,
+        BatchLatticeDecoder,
         DecodableCtc,
         DecodableInterface,
         DeviceOptions,
@@ -29,7 +30,12 @@ try:
         FasterDecoderOptions,
         Fst,
         Lattice,
+        LatticeFasterDecoder,
+        LatticeFasterDecoderConfig,
+        LatticeSimpleDecoder,
+        LatticeSimpleDecoderConfig,
         get_linear_symbol_sequence,
+        shortest_path,
     )
 except ImportError as e:  # pragma: no cover
     raise ImportError(

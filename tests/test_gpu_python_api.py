@@ -123,3 +123,70 @@ def test_batch_decoder_and_device_tensors(oracle):
     bd.decode([kd.DecodableCtc(lp) for lp in lps])
     _, op = _oracle_path(oracle, g, lps[0], beam=4.0)
     assert bd.get_best_path()[1][0].get_linear_symbol_sequence()[2] == op.osyms.tolist()
+
+
+def test_lattice_simple_decoder_python_flow(oracle):
+    g = synth.hlg_graph(V=30, n_words=100, n_hist=100, avg_succ=6, seed=6)
+    fst = kd.fst_from_dict(g)
+    lp = synth.make_logprobs(50, 30, 1, peak=5.0, lexicon=g["lexicon"])
+    config = kd.LatticeSimpleDecoderConfig(beam=9.0, lattice_beam=5.0)
+    dec = kd.LatticeSimpleDecoder(fst, config)
+    assert str(dec.get_config()) == str(config)
+    reached = dec.decode(kd.DecodableCtc(lp))
+    can = oracle.CanonLatticeDecoder(oracle.Graph(g), beam=9.0, lattice_beam=5.0)
+    assert reached == can.decode(lp)
+    assert dec.num_frames_decoded() == 50
+    assert dec.final_relative_cost() == can.final_relative_cost()
+    ok, raw = dec.get_raw_lattice()
+    cl = can.get_raw_lattice()
+    assert ok and raw.num_states == cl.num_states and raw.num_arcs == len(cl.src)
+    src, dst, il, ol, gc, ac = raw.arrays()
+    assert sorted(zip(il.tolist(), ol.tolist(), gc.tolist(), ac.tolist())) == \
+        sorted(zip(cl.ilabel.tolist(), cl.olabel.tolist(), cl.graph_cost.tolist(), cl.ac_cost.tolist()))
+    ok, best = dec.get_best_path()
+    pc = can.get_best_path()
+    ok2, isyms, osyms, (gcost, acost) = best.get_linear_symbol_sequence()
+    assert ok and ok2 and isyms == pc.isyms.tolist() and osyms == pc.osyms.tolist()
+    assert abs(gcost + acost - sum(pc.total_cost)) < 1e-3
+    with pytest.raises(RuntimeError, match="use_final_probs == false"):
+        dec.get_raw_lattice(False)
+    # shortest_path of the raw lattice is what get_best_path returns
+    ok3, sp = kd.shortest_path(raw)
+    assert ok3 and sp.get_linear_symbol_sequence()[1:3] == (isyms, osyms)
+    # the same best words as the 1-best decoder
+    fd = kd.FasterDecoder(fst, kd.FasterDecoderOptions(beam=9.0, min_active=0))
+    fd.decode(kd.DecodableCtc(lp))
+    assert fd.get_best_path()[1].get_linear_symbol_sequence()[2] == osyms
+
+
+def test_lattice_faster_decoder_streaming_and_batch(oracle):
+    g = synth.hl_graph(V=30, n_words=200, seed=5)
+    fst = kd.fst_from_dict(g)
+    lps = [synth.make_logprobs(40, 30, i, peak=6.0, lexicon=g["lexicon"]) for i in range(3)]
+    cfg = kd.LatticeFasterDecoderConfig(beam=10.0, lattice_beam=6.0, max_active=80, min_active=10)
+    dec = kd.LatticeFasterDecoder(fst, cfg)
+    dec.init_decoding()
+    for s in range(0, 40, 8):
+        dec.advance_decoding(kd.DecodableCtc(lps[0][s:s + 8], offset=s))
+    assert dec.num_frames_decoded() == 40
+    dec.finalize_decoding()
+    ok, raw = dec.get_raw_lattice()
+    can = oracle.CanonLatticeDecoder(oracle.Graph(g), beam=10.0, lattice_beam=6.0, max_active=80,
+                                     min_active=10)
+    can.decode(lps[0])
+    cl = can.get_raw_lattice()
+    assert ok and raw.num_states == cl.num_states and raw.num_arcs == len(cl.src)
+    bd = kd.BatchLatticeDecoder(fst, cfg, 3)
+    reached = bd.decode([kd.DecodableCtc(lp) for lp in lps])
+    okb, lats = bd.get_raw_lattice()
+    assert all(okb) and lats[0].num_arcs == raw.num_arcs and len(reached) == 3
+    okp, paths = bd.get_best_path()
+    for i in range(3):
+        c = oracle.CanonLatticeDecoder(oracle.Graph(g), beam=10.0, lattice_beam=6.0, max_active=80,
+                                       min_active=10)
+        c.decode(lps[i])
+        assert okp[i] and paths[i].get_linear_symbol_sequence()[2] == c.get_best_path().osyms.tolist()
+    with pytest.raises(RuntimeError, match="Check failed"):
+        kd.LatticeFasterDecoder(fst, kd.LatticeFasterDecoderConfig(prune_scale=2.0))
+    with pytest.raises(RuntimeError, match="Check failed"):
+        kd.LatticeSimpleDecoder(fst, kd.LatticeSimpleDecoderConfig(prune_interval=0))

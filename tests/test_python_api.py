@@ -80,3 +80,34 @@ def test_fst_and_lattice_types():
     assert lat.num_states == 0 and lat.start == -1
     ok, isyms, osyms, w = kd.get_linear_symbol_sequence(lat)
     assert ok and isyms == [] and osyms == []
+
+
+def test_lattice_configs_defaults_and_str():
+    # lattice-simple-decoder.h:37-48,68-83 ; python/csrc/lattice-simple-decoder.cc:15-32
+    c = kd.LatticeSimpleDecoderConfig()
+    assert (c.beam, c.lattice_beam, c.prune_interval, c.determinize_lattice, c.prune_lattice) == \
+        (16.0, 10.0, 25, True, True)
+    assert abs(c.beam_ratio - 0.9) < 1e-6 and abs(c.prune_scale - 0.1) < 1e-6
+    assert str(c) == ("LatticeSimpleDecoderConfig(beam=16, lattice_beam=10, prune_interval=25, "
+                      "determinize_lattice=True, prune_lattice=1, beam_ratio=0.9, prune_scale=0.1)")
+    c.lattice_beam = 8.0
+    assert "lattice_beam=8" in str(c)
+    # lattice-faster-decoder.h:48-66,106-127
+    f = kd.LatticeFasterDecoderConfig()
+    assert (f.beam, f.max_active, f.min_active, f.lattice_beam, f.prune_interval) == \
+        (16.0, 2**31 - 1, 200, 10.0, 25)
+    assert (f.memory_pool_tokens_block_size, f.memory_pool_links_block_size) == (256, 256)
+    assert str(f).startswith("LatticeFasterDecoderConfig(beam=16, max_active=2147483647, "
+                             "min_active=200, lattice_beam=10, prune_interval=25, "
+                             "determinize_lattice=True, beam_delta=0.5, hash_ratio=2, "
+                             "prune_scale=0.1, memory_pool_tokens_block_size=256")
+    for name in ("LatticeSimpleDecoder", "LatticeSimpleDecoderConfig", "LatticeFasterDecoder",
+                 "LatticeFasterDecoderConfig"):
+        assert hasattr(kd, name)
+
+
+def test_shortest_path_on_a_hand_built_lattice():
+    # no GPU involved: Lattice objects only come out of decoders, so go through
+    # the empty case and the API shape here; the numeric check is in the GPU tests
+    ok, best = kd.shortest_path(kd.Lattice())
+    assert not ok and best.num_states == 0
