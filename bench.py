@@ -4,15 +4,15 @@
     python bench.py --gpus N --steps K --warmup W
 
 A step is one pass of the hot path over one batch of synthetic utterances whose
-log-prob matrices are already resident in HBM: InitDecoding, AdvanceDecoding
-over all frames (one persistent kernel launch), GetBestPath traceback and the
-read-back of the 1-best label sequences (N > 1: plus the gather of every rank's
-results to rank 0).  Prints ONE JSON line (rank 0).
-
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
-HLG-like graph (~5e6 states / ~1.3e7 arcs, seed 2), beam 15, batch 128 per GPU,
-T = 250 decoder frames (10 s of audio at 40 ms/frame).  Audio frames = decoder
-frames x 4 (subsampling), as in BASELINE.md.
+log-prob matrices are already resident in HBM.  Default workload (BASELINE.json
+configs[2], the configuration the metric is quoted on): LatticeFasterDecoder over
+an HLG-like graph, beam 15, lattice-beam 8, batch 128 per GPU, T = 250 decoder
+frames (10 s of audio at 40 ms/frame): InitDecoding, AdvanceDecoding over all
+frames (one persistent kernel launch), FinalizeDecoding (device-side lattice
+pruning) and the export of the pruned raw lattices to host arrays; with N > 1
+also the gather of every rank's 1-best label sequences to rank 0.  Prints ONE
+JSON line (rank 0).  Audio frames = decoder frames x 4 (subsampling), as in
+BASELINE.md.
 """
 import argparse
 import json
@@ -29,32 +29,39 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
 SUBSAMPLING = 4
 
+HLG = dict(V=500, n_words=20000, n_hist=20000, avg_succ=50, seed=2)
 WORKLOADS = {
-    # name: (graph kwargs, decoder options, batch, frames, V)
-    "hlg": dict(kind="hlg", graph=dict(V=500, n_words=20000, n_hist=20000, avg_succ=50, seed=2),
-                opts=dict(beam=15.0), batch=128, frames=250, V=500,
-                desc="FasterDecoder 1-best over synthetic LibriSpeech-like HLG "
-                     "(bigram G, 20k words, V=500), beam=15, B=128/GPU, T=250"),
-    "hl": dict(kind="hl", graph=dict(V=500, n_words=20000, seed=1),
+    "hlg-lattice": dict(kind="hlg", graph=HLG, lattice=True,
+                        opts=dict(beam=15.0, lattice_beam=8.0, min_active=0),
+                        batch=128, frames=250, V=500,
+                        desc="LatticeFasterDecoder over synthetic LibriSpeech-like HLG (bigram G, "
+                             "20k words, V=500), beam=15, lattice_beam=8, B=128/GPU, T=250"),
+    "hlg-1best": dict(kind="hlg", graph=HLG, lattice=False, opts=dict(beam=15.0),
+                      batch=128, frames=250, V=500,
+                      desc="FasterDecoder 1-best over synthetic LibriSpeech-like HLG "
+                           "(bigram G, 20k words, V=500), beam=15, B=128/GPU, T=250"),
+    "hl": dict(kind="hl", graph=dict(V=500, n_words=20000, seed=1), lattice=False,
                opts=dict(beam=16.0, max_active=3000), batch=64, frames=250, V=500,
                desc="FasterDecoder 1-best over synthetic HL (20k-word trie, V=500), beam=16, "
                     "max_active=3000, B=64/GPU, T=250"),
     "small": dict(kind="hlg", graph=dict(V=100, n_words=2000, n_hist=2000, avg_succ=10, seed=2),
-                  opts=dict(beam=12.0), batch=16, frames=100, V=100,
-                  desc="small HLG-like smoke workload"),
+                  lattice=True, opts=dict(beam=12.0, lattice_beam=6.0, min_active=0),
+                  batch=16, frames=100, V=100, desc="small HLG-like lattice smoke workload"),
 }
 
 
 def algorithmic_bytes(stats, V):
-    """16*A_scan + 8*R + 12*N_in + 16*N_out + 4*V per utterance-frame."""
+    """16*A_scan + 8*R + 12*N_in + 16*N_out + 4*V (+ 20*L) per utterance-frame."""
     s = stats.sum(axis=0)
     frames, n_in, expanded, arcs, _, n_out, eps_arcs, eps_exp = (int(x) for x in s[:8])
+    links = int(s[10])
     a_scan = arcs + eps_arcs
     r = expanded + eps_exp
-    return 16 * a_scan + 8 * r + 12 * n_in + 16 * n_out + 4 * V * frames, dict(
+    return (16 * a_scan + 8 * r + 12 * n_in + 16 * n_out + 4 * V * frames + 20 * links), dict(
         arcs_scanned_per_frame=a_scan / max(frames, 1),
         tokens_in_per_frame=n_in / max(frames, 1),
         tokens_out_per_frame=n_out / max(frames, 1),
+        links_per_frame=links / max(frames, 1),
         max_tokens=int(stats[:, 8].max()), spill_frames=int(s[9]))
 
 
@@ -75,29 +82,79 @@ def profiled_traffic(workload_desc):
     return best
 
 
-def cpu_baseline(g, lps, opts, gpu_paths, budget_s=20.0):
-    """The oracle's reference-order FasterDecoder (policy 0), one thread, on a
-    bounded sample of the same utterances; also checks 1-best parity."""
+def lattice_best_path(lat):
+    """Tropical shortest path over a cabi.RawLattice (numpy): relax all arcs until
+    stable (the lattice is acyclic and shallow inside a frame)."""
+    n = lat.num_states
+    if n == 0:
+        return None
+    cost = np.full(n, np.inf)
+    cost[lat.start] = 0.0
+    w = lat.graph_cost.astype(np.float64) + lat.ac_cost.astype(np.float64)
+    for _ in range(4 * int(lat.state_frame.max()) + 64):
+        new = cost.copy()
+        np.minimum.at(new, lat.dst, cost[lat.src] + w)
+        if not (new < cost).any():
+            break
+        cost = new
+    cand = cost[lat.src] + w
+    hit = np.isfinite(cand) & (cand == cost[lat.dst])
+    back = np.full(n, -1, np.int64)
+    idx = np.nonzero(hit)[0][::-1]
+    back[lat.dst[idx]] = idx
+    fin = cost[lat.final_state] + lat.final_graph
+    if not len(fin) or not np.isfinite(fin).any():
+        return None
+    s = int(lat.final_state[int(np.argmin(fin))])
+    il, ol = [], []
+    while s != lat.start:
+        a = int(back[s])
+        il.append(int(lat.ilabel[a]))
+        ol.append(int(lat.olabel[a]))
+        s = int(lat.src[a])
+    return [x for x in il[::-1] if x], [x for x in ol[::-1] if x]
+
+
+def cpu_baseline(g, lps, wl, gpu_out, budget_s=20.0):
+    """The oracle's reference-order restatement (policy 0), one thread, on a bounded
+    sample of the same utterances; also checks 1-best parity with the GPU output."""
     from oracle import oracle
     og = oracle.Graph(g)
-    t_used, frames, n, mism = 0.0, 0, 0, 0
+    t_used, frames, n, mism, not_subset = 0.0, 0, 0, 0, 0
     for i, lp in enumerate(lps):
-        d = oracle.FasterDecoder(og, policy=0, **opts)
         t0 = time.perf_counter()
-        d.decode(lp)
-        p = d.get_best_path()
-        t_used += time.perf_counter() - t0
+        if wl["lattice"]:
+            d = oracle.LatticeSimpleDecoder(og, beam=wl["opts"]["beam"],
+                                            lattice_beam=wl["opts"]["lattice_beam"])
+            d.decode(lp)
+            raw = d.get_raw_lattice()
+            p = d.get_best_path()
+            t_used += time.perf_counter() - t0
+            best = lattice_best_path(gpu_out[i])
+            if best is None or best[0] != p.isyms.tolist() or best[1] != p.osyms.tolist():
+                mism += 1
+            if not gpu_out[i].arc_set() <= raw.arc_set():
+                not_subset += 1
+        else:
+            d = oracle.FasterDecoder(og, policy=0, **wl["opts"])
+            d.decode(lp)
+            p = d.get_best_path()
+            t_used += time.perf_counter() - t0
+            gp = gpu_out[i]
+            if p.ilabel.tolist() != gp.ilabel.tolist() or p.olabel.tolist() != gp.olabel.tolist():
+                mism += 1
         frames += lp.shape[0]
         n += 1
-        gp = gpu_paths[i]
-        if p.ilabel.tolist() != gp.ilabel.tolist() or p.olabel.tolist() != gp.olabel.tolist():
-            mism += 1
         if t_used > budget_s:
             break
+    what = ("LatticeSimpleDecoder (reference order) incl. FinalizeDecoding, GetRawLattice and "
+            "shortest path" if wl["lattice"] else "FasterDecoder policy 0 (reference order)")
+    par = dict(utts_checked=n, one_best_mismatches=mism)
+    if wl["lattice"]:
+        par["gpu_lattice_not_subset_of_reference"] = not_subset
     return dict(value=frames * SUBSAMPLING / t_used, unit="audio_frames/s", cores=1, kind="port",
-                sample=f"{n} utterances x {lps[0].shape[0]} frames of the bench batch, "
-                       "oracle FasterDecoder policy 0 (reference order), 1 thread"), \
-        dict(utts_checked=n, one_best_mismatches=mism)
+                sample=f"{n} utterances x {lps[0].shape[0]} frames of the bench batch, oracle "
+                       f"{what}, 1 thread"), par
 
 
 def main():
@@ -105,7 +162,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="hlg", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="hlg-lattice", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
@@ -136,17 +193,28 @@ def main():
     dev = torch.from_numpy(np.stack(lps)).cuda()
     ptrs = [dev[i].data_ptr() for i in range(B)]
     rows = [T] * B
-    bt = cabi.Batch(G, max_batch=B, max_frames=T, **wl["opts"])
+    if wl["lattice"]:
+        bt = cabi.LatticeBatch(G, max_batch=B, max_frames=T, **wl["opts"])
+    else:
+        bt = cabi.Batch(G, max_batch=B, max_frames=T, **wl["opts"])
     setup_s = time.time() - t0
 
     def step():
         bt.init_decoding()
         bt.advance_device(ptrs, rows, V, sync=False)
         bt.sync()
-        paths = bt.best_paths()
-        if world > 1:
-            sharded.gather_paths([(p.ilabel, p.olabel) for p in paths], dst=0)
-        return paths
+        k_ms = bt.last_kernel_ms()  # HIP events around the search kernel, on its stream
+        if wl["lattice"]:
+            bt.finalize_decoding()
+            out = bt.raw_lattices()
+            if world > 1:
+                best = [lattice_best_path(lat) or ([], []) for lat in out]
+                sharded.gather_paths(best, dst=0)
+        else:
+            out = bt.best_paths()
+            if world > 1:
+                sharded.gather_paths([(p.ilabel, p.olabel) for p in out], dst=0)
+        return out, k_ms
 
     def fence():
         if world > 1:
@@ -159,8 +227,8 @@ def main():
     fence()
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        paths = step()
-        kernel_ms.append(bt.last_kernel_ms())  # HIP events on the launch stream
+        out, k = step()
+        kernel_ms.append(k)
     fence()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -175,7 +243,7 @@ def main():
         traffic = profiled_traffic(wl["desc"])
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         frames_total = world * B * T * args.steps
-        out = {
+        res = {
             "metric": "decoded audio frames/sec (whole node), LibriSpeech HLG beam=15; "
                       "1-best WER parity",
             "value": frames_total * SUBSAMPLING / elapsed,
@@ -187,7 +255,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32" if wl["lattice"] else "f64",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "graph_states": info["states"],
                        "graph_arcs": info["arcs"], "batch_per_gpu": B, "frames": T,
@@ -200,12 +268,15 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes},
             "setup_s": setup_s,
         }
+        if wl["lattice"]:
+            res["config"]["lattice_arcs_per_utt"] = float(np.mean([len(lat.src) for lat in out]))
+            res["config"]["lattice_states_per_utt"] = float(np.mean([lat.num_states for lat in out]))
         if not args.no_cpu:
-            cb, parity = cpu_baseline(g, lps, wl["opts"], paths)
-            out["cpu_baseline"] = cb
-            out["parity"] = parity
-            out["gpu_over_cpu_1thread"] = out["value"] / cb["value"]
-        print(json.dumps(out))
+            cb, parity = cpu_baseline(g, lps, wl, out)
+            res["cpu_baseline"] = cb
+            res["parity"] = parity
+            res["gpu_over_cpu_1thread"] = res["value"] / cb["value"]
+        print(json.dumps(res))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

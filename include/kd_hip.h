@@ -179,6 +179,7 @@ enum {
   KD_STAT_EPS_EXPANSIONS,   /* token expansions in ProcessNonemitting          */
   KD_STAT_MAX_TOKENS,       /* max tokens written in one frame                 */
   KD_STAT_SPILL_FRAMES,     /* frames that fell back to the global table       */
+  KD_STAT_LINKS,            /* forward links written (lattice decoders)        */
   KD_NUM_STATS
 };
 int kd_batch_stats(kd_batch *b, int64_t *out /* [batch][KD_NUM_STATS] */);

@@ -875,6 +875,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
       ToG(p.link_eps_base)[fb + frame + 1] = lbase + s.n_emit_links;
       ToG(p.link_eps_count)[fb + frame + 1] = s.n_eps_links;
       s.link_next = lbase + s.n_emit_links + s.n_eps_links;
+      s.stat[KD_STAT_LINKS] += s.n_emit_links + s.n_eps_links;
     }
   }
   c.base_in = base_out;
@@ -1020,6 +1021,9 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
           s.overflow = 0;
           s.wl_count[0] = 0;
           s.wl_count[1] = 0;
+          s.n_emit_links = 0;
+          s.n_eps_links = 0;
+          s.n_emit_written = 0;
         }
         __syncthreads();
         // (epsilon counters of the aborted closure are dropped)

@@ -98,3 +98,23 @@ def test_lattice_error_behaviour_and_unfinalized_export(oracle):
     lb.advance_host([lp])
     lb.finalize_decoding()
     assert lb.raw_lattices()[0].arc_set() == pruned.arc_set()
+
+
+def test_lattice_frames_that_spill_to_the_global_table(oracle):
+    # frontier far beyond the LDS table: the lattice path must survive the replay
+    g = synth.random_graph(30000, 4.0, 16, 0.1, 9, max_weight=0.5)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lp = synth.make_logprobs(8, 16, 0, peak=0.0)
+    opts = dict(beam=1000.0, lattice_beam=2.0, min_active=0)
+    lb = cabi.LatticeBatch(G, max_batch=1, **opts)
+    lb.init_decoding()
+    lb.advance_host([lp])
+    assert lb.stats()[0, 9] > 0  # spill frames
+    lb.finalize_decoding()
+    gl = lb.raw_lattices()[0]
+    can = oracle.CanonLatticeDecoder(OG, **opts)
+    can.decode(lp)
+    cl = can.get_raw_lattice()
+    assert gl.state_set() == cl.state_set()
+    assert gl.arc_set() == cl.arc_set()
+    assert len(gl.src) == len(cl.src)  # no duplicate arcs
