@@ -153,6 +153,14 @@ struct Counters {
 #define KD_LAP(s, i)
 #endif
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+// every outstanding global store of the wave (s_waitcnt vmcnt(0)), which costs a
+// memory round trip whenever stores are in flight; where the next phase only
+// needs the other waves' LDS writes, this lets the stores keep draining.
+__device__ __forceinline__ void LdsBarrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---- block-wide primitives (wave64 shuffles + one LDS hop) -----------------
 __device__ __forceinline__ unsigned long long WaveMinU64(unsigned long long v) {
 #pragma unroll
@@ -167,11 +175,11 @@ __device__ __forceinline__ unsigned long long BlockMinU64(Shared &s, unsigned lo
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   v = WaveMinU64(v);
   if (lane == 0) s.red64[wave] = v;
-  __syncthreads();
+  LdsBarrier();
   unsigned long long r = s.red64[0];
 #pragma unroll
   for (int w = 1; w < kWaves; ++w) r = s.red64[w] < r ? s.red64[w] : r;
-  __syncthreads();
+  LdsBarrier();
   return r;
 }
 
@@ -328,7 +336,7 @@ __device__ __forceinline__ void Filter(const FrameCtx &c, const Table<LDS> &t, i
   const int tid = threadIdx.x, lane = tid & 63;
   int par = 0;
   if (tid == 0) { s.it_count[0] = 0; s.it_next[0] = 0; }
-  __syncthreads();
+  LdsBarrier();
   for (int chunk = 0; chunk < n_items; chunk += kBlock, par ^= 1) {
     const int i = chunk + tid;
     if (i < n_items) {
@@ -371,7 +379,7 @@ __device__ __forceinline__ void Filter(const FrameCtx &c, const Table<LDS> &t, i
         }
       }
     }
-    __syncthreads();
+    LdsBarrier();  // the big-token queue is LDS; queue stores keep draining
     KD_LAP(s, EPS ? 7 : 3);
     const int nq = s.it_count[par];
     if (tid == 0) { s.it_count[par ^ 1] = 0; s.it_next[par ^ 1] = 0; }
@@ -419,9 +427,10 @@ __device__ __forceinline__ void Filter(const FrameCtx &c, const Table<LDS> &t, i
         }
       }
     }
-    __syncthreads();
+    if (chunk + kBlock < n_items) LdsBarrier();  // it_* arrays are reused by the next chunk
     KD_LAP(s, EPS ? 8 : 4);
   }
+  __syncthreads();  // candidate-queue stores visible to the insert phase
 }
 
 // Insert phase: queue entries [q_begin, q_end), one per lane.  Relaxes the

@@ -1,24 +1,56 @@
-import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'kaldi-decoder_amd', 'python'))
-import numpy as np, torch
-from kaldi_decoder import cabi, synth
-def run(kind):
-    if kind=='hl':
-        g=synth.hl_graph(); opts=dict(beam=16.0,max_active=3000); B=64
-    else:
-        g=synth.hlg_graph(V=500,n_words=20000,n_hist=20000,avg_succ=50,seed=2); opts=dict(beam=15.0); B=128
-    T=250
-    lps=[synth.make_logprobs(T,500,i,peak=12.0,lexicon=g['lexicon']) for i in range(B)]
-    G=cabi.Graph(g); dev=torch.from_numpy(np.stack(lps)).cuda()
-    bt=cabi.Batch(G,max_batch=B,max_frames=T,**opts)
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the search kernel (diagnostic build only).
+
+    make -C kaldi-decoder_amd prof
+    KD_HIP_LIB=libkd_hip_prof.so python tools/prof_phases.py [hlg-lattice|hlg-1best|hl] [batch]
+
+Never quote this build's run time: the stamps forbid overlaps the real kernel
+has.  Read the shares."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "kaldi-decoder_amd", "python"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from kaldi_decoder import cabi, synth  # noqa: E402
+import bench  # noqa: E402
+
+NAMES = ['0 frame start/ll row', '1 GetCutoff', '2 prepass', '3 emit filter: items+small',
+         '4 emit filter: big loop', '5 emit insert', '6 eps round setup', '7 eps filter: items+small',
+         '8 eps filter: big loop', '9 eps insert', '10 resolve R1 + alloc', '11 C1 write tokens',
+         '12 R2 + links + stats', '13 clear/loop', '14 spill-mode frames', '15 aborted LDS attempts']
+
+
+def run(kind, B=None):
+    wl = bench.WORKLOADS[kind]
+    g = synth.hlg_graph(**wl["graph"]) if wl["kind"] == "hlg" else synth.hl_graph(**wl["graph"])
+    B = B or wl["batch"]
+    T, V = wl["frames"], wl["V"]
+    lps = [synth.make_logprobs(T, V, i, peak=12.0, lexicon=g["lexicon"]) for i in range(B)]
+    G = cabi.Graph(g)
+    dev = torch.from_numpy(np.stack(lps)).cuda()
+    cls = cabi.LatticeBatch if wl["lattice"] else cabi.Batch
+    bt = cls(G, max_batch=B, max_frames=T, **wl["opts"])
     for _ in range(2):
-        bt.init_decoding(); bt.advance_device([dev[i].data_ptr() for i in range(B)],[T]*B,500)
-    cyc=bt.phase_cycles(); st=bt.stats()
-    names=['0 frame start/ll row','1 GetCutoff','2 prepass','3 emit items+small','4 emit big loop','5 prune+seed',
-           '6 eps round setup','7 eps items+small','8 eps big loop','9 resolve R1 + count','10 scan+min+alloc',
-           '11 C1 write tokens','12 R2 + stats','13 clear/loop','14 spill-mode frames','15 aborted LDS attempts']
-    tot=cyc.sum(0); allc=tot.sum()
-    print(kind,'kernel_ms %.2f'%bt.last_kernel_ms(),'spill_frames',st[:,9].sum(),'cycles/utt-frame %.0f'%(allc/(B*T)))
-    for n,v in zip(names,tot): print('  %-26s %5.1f%%  %8.0f cyc/utt-frame'%(n,100*v/allc,v/(B*T)))
-    tcyc=cyc.sum(1); print('  per-utt Mcyc: min %.1f med %.1f max %.1f'%(tcyc.min()/1e6,np.median(tcyc)/1e6,tcyc.max()/1e6))
-run('hl'); run('hlg')
+        bt.init_decoding()
+        bt.advance_device([dev[i].data_ptr() for i in range(B)], [T] * B, V)
+    cyc, st = bt.phase_cycles(), bt.stats()
+    tot = cyc.sum(0)
+    allc = tot.sum()
+    print(kind, 'B', B, 'kernel_ms %.2f' % bt.last_kernel_ms(), 'spill_frames', st[:, 9].sum(),
+          'cycles/utt-frame %.0f' % (allc / (B * T)))
+    for n, v in zip(NAMES, tot):
+        print('  %-28s %5.1f%%  %8.0f cyc/utt-frame' % (n, 100 * v / allc, v / (B * T)))
+    tcyc = cyc.sum(1)
+    print('  per-utt Mcyc: min %.1f med %.1f max %.1f' % (tcyc.min() / 1e6, np.median(tcyc) / 1e6,
+                                                          tcyc.max() / 1e6))
+
+
+if __name__ == "__main__":
+    kinds = [a for a in sys.argv[1:] if not a.isdigit()] or ["hlg-lattice"]
+    nums = [int(a) for a in sys.argv[1:] if a.isdigit()]
+    for k in kinds:
+        run(k, nums[0] if nums else None)
