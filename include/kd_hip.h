@@ -184,6 +184,19 @@ enum {
 };
 int kd_batch_stats(kd_batch *b, int64_t *out /* [batch][KD_NUM_STATS] */);
 
+/* ---- SimpleDecoder ------------------------------------------------------------
+ * A kd_batch created with kd_batch_create_simple has SimpleDecoder's semantics
+ * (ref: csrc/simple-decoder.{h,cc}): plain beam on the emitting step and in the
+ * epsilon closure, tokens at or beyond best + beam dropped after the closure
+ * (PruneToks, ref: csrc/simple-decoder.cc:252-281), token cost = prev + (weight +
+ * acoustic) with the float sum first (ref: csrc/simple-decoder.h:99), best-path
+ * arcs carrying the arc's own (graph, acoustic) pair.  All kd_batch_* calls
+ * apply; kd_batch_final_relative_cost gives FinalRelativeCost (ref: :78-100).
+ */
+int kd_batch_create_simple(const kd_graph *g, float beam, int64_t arena_tokens,
+                           int32_t table_slots, int32_t max_frames, int32_t max_batch,
+                           void *stream, kd_batch **out);
+
 /* ---- lattice decoders --------------------------------------------------------
  * A kd_batch created with kd_batch_create_lattice runs the lattice-generating
  * search: LatticeSimpleDecoder's semantics (ref: csrc/lattice-simple-decoder.cc)

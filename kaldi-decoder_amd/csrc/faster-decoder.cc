@@ -28,7 +28,22 @@ BatchFasterDecoder::BatchFasterDecoder(const Fst &fst, const FasterDecoderOption
   KdCheck(kd_batch_create(fst.OnDevice(dev.device), &o, max_batch, nullptr, &b_));
 }
 
+BatchFasterDecoder::BatchFasterDecoder(const Fst &fst, float simple_beam, int32_t max_batch,
+                                       const DeviceOptions &dev)
+    : fst_(fst), config_(simple_beam, std::numeric_limits<int32_t>::max(), 0), dev_(dev),
+      max_batch_(max_batch) {
+  KdCheck(kd_batch_create_simple(fst.OnDevice(dev.device), simple_beam, dev.arena_tokens,
+                                 dev.table_slots, dev.max_frames, max_batch, nullptr, &b_));
+}
+
 BatchFasterDecoder::~BatchFasterDecoder() { kd_batch_destroy(b_); }
+
+std::vector<float> BatchFasterDecoder::FinalRelativeCost() const {
+  std::vector<float> r(std::max(batch_, 1));
+  KdCheck(kd_batch_final_relative_cost(b_, r.data()));
+  r.resize(batch_);
+  return r;
+}
 
 void BatchFasterDecoder::SetOptions(const FasterDecoderOptions &config) {
   config_ = config;

@@ -60,6 +60,8 @@ class BatchFasterDecoder {
  public:
   BatchFasterDecoder(const Fst &fst, const FasterDecoderOptions &config, int32_t max_batch,
                      const DeviceOptions &dev = DeviceOptions());
+  // SimpleDecoder semantics (plain beam); see SimpleDecoder below
+  BatchFasterDecoder(const Fst &fst, float simple_beam, int32_t max_batch, const DeviceOptions &dev);
   ~BatchFasterDecoder();
   BatchFasterDecoder(const BatchFasterDecoder &) = delete;
   BatchFasterDecoder &operator=(const BatchFasterDecoder &) = delete;
@@ -77,6 +79,7 @@ class BatchFasterDecoder {
   int32_t Batch() const { return batch_; }
   std::vector<int64_t> Stats() const;  // [batch][KD_NUM_STATS]
   float LastKernelMs() const;
+  std::vector<float> FinalRelativeCost() const;
 
  private:
   const Fst &fst_;
@@ -110,6 +113,40 @@ class FasterDecoder {
   }
   int32_t NumFramesDecoded() const { return impl_.NumFramesDecoded()[0]; }
   const BatchFasterDecoder &Impl() const { return impl_; }
+
+ private:
+  mutable BatchFasterDecoder impl_;
+};
+
+// SimpleDecoder (ref: /root/reference/kaldi-decoder/csrc/simple-decoder.h:24-85):
+// same methods -- Decode (true if any token survived), ReachedFinal, GetBestPath,
+// FinalRelativeCost, InitDecoding, AdvanceDecoding, NumFramesDecoded -- running
+// the GPU search in its plain-beam mode (kd_batch_create_simple).
+class SimpleDecoder {
+ public:
+  SimpleDecoder(const Fst &fst, float beam, const DeviceOptions &dev = DeviceOptions())
+      : impl_(fst, beam, 1, dev) {}
+  SimpleDecoder(const SimpleDecoder &) = delete;
+  SimpleDecoder &operator=(const SimpleDecoder &) = delete;
+
+  bool Decode(DecodableInterface *decodable) {  // simple-decoder.cc:24-28
+    impl_.Decode({decodable});
+    std::vector<Lattice> v;
+    return impl_.GetBestPath(&v, true)[0];  // !cur_toks_.empty()
+  }
+  bool ReachedFinal() const { return impl_.ReachedFinal()[0]; }
+  bool GetBestPath(Lattice *fst_out, bool use_final_probs = true) const {
+    std::vector<Lattice> v;
+    const bool ok = impl_.GetBestPath(&v, use_final_probs)[0];
+    *fst_out = std::move(v[0]);
+    return ok;
+  }
+  float FinalRelativeCost() const { return impl_.FinalRelativeCost()[0]; }
+  void InitDecoding() { impl_.InitDecoding(1); }
+  void AdvanceDecoding(DecodableInterface *decodable, int32_t max_num_frames = -1) {
+    impl_.AdvanceDecoding({decodable}, max_num_frames);
+  }
+  int32_t NumFramesDecoded() const { return impl_.NumFramesDecoded()[0]; }
 
  private:
   mutable BatchFasterDecoder impl_;

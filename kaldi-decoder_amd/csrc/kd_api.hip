@@ -75,6 +75,9 @@ struct kd_batch {
   DevBuf<unsigned long long> g_cost, g_log_nk;
   // lattice mode
   bool lattice = false, finalized = false, lat_stats_valid = false, lat_sizes_valid = false;
+  bool simple = false;
+  DevBuf<float> final_rel;
+  std::vector<float> h_final_rel;
   int32_t lat_use_final = -1;
   kd_lattice_options lo{};
   int64_t link_cap = 0;  // per utterance
@@ -153,6 +156,7 @@ struct kd_batch {
     p.utt = utt.p;
     p.do_init = do_init;
     p.lattice = lattice ? 1 : 0;
+    p.simple = simple ? 1 : 0;
     p.g_log_ac = g_log_ac.p;
     p.tok_extra = tok_extra.p;
     p.link_src = link_src.p;
@@ -222,6 +226,9 @@ struct kd_batch {
     p.frames_decoded = frames_decoded.p;
     p.use_final_probs = use_final;
     p.batch = batch;
+    p.simple = simple ? 1 : 0;
+    p.tok_ac = tok_extra.p;
+    p.final_rel = final_rel.p;
     p.reached_final = reached_final.p;
     p.best_tok = best_tok.p;
     p.path_len = path_len.p;
@@ -438,6 +445,7 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   A(b->best_tok.Alloc(max_batch));
   A(b->path_offset.Alloc(max_batch));
   A(b->final_weight.Alloc(2 * static_cast<size_t>(max_batch)));
+  A(b->final_rel.Alloc(max_batch));
   if (e == hipSuccess) e = hipMemset(b->g_key.p, 0xFF, b->g_key.bytes());
   if (e == hipSuccess) e = hipMemset(b->g_cost.p, 0xFF, b->g_cost.bytes());
   if (e == hipSuccess) e = hipMemset(b->g_arc.p, 0xFF, b->g_arc.bytes());
@@ -455,6 +463,7 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   b->h_path_len.assign(max_batch, -1);
   b->h_reached.assign(max_batch, 0);
   b->h_final_weight.assign(2 * static_cast<size_t>(max_batch), 0.f);
+  b->h_final_rel.assign(max_batch, 0.f);
   b->h_utt.assign(max_batch, UttDesc{});
   if (lopts) {
     b->lattice = true;
@@ -505,6 +514,33 @@ int kd_batch_create(const kd_graph *g, const kd_faster_options *opts, int32_t ma
   if (!g || !opts || max_batch <= 0) return Fail(KD_E_INVALID, "bad argument");
   if (int r = CheckOptions(*opts)) return r;
   return CreateBatch(g, opts, nullptr, max_batch, stream, out);
+}
+
+int kd_batch_create_simple(const kd_graph *g, float beam, int64_t arena_tokens,
+                           int32_t table_slots, int32_t max_frames, int32_t max_batch,
+                           void *stream, kd_batch **out) {
+  if (!out) return Fail(KD_E_INVALID, "out is NULL");
+  *out = nullptr;
+  if (!g || max_batch <= 0) return Fail(KD_E_INVALID, "bad argument");
+  kd_faster_options fo;
+  kd_faster_options_default(&fo);
+  fo.beam = beam;
+  fo.min_active = 0;
+  fo.arena_tokens = arena_tokens;
+  fo.table_slots = table_slots;
+  fo.max_frames = max_frames;
+  if (int r = CreateBatch(g, &fo, nullptr, max_batch, stream, out)) return r;
+  kd_batch *b = *out;
+  const size_t gs = static_cast<size_t>(max_batch) << b->g_log2_slots;
+  hipError_t e = b->g_log_ac.Alloc(2 * gs);
+  if (e == hipSuccess) e = b->tok_extra.Alloc(b->o.arena_tokens);
+  if (e != hipSuccess) {
+    delete b;
+    *out = nullptr;
+    return Fail(KD_E_HIP, std::string("simple batch allocation: ") + hipGetErrorString(e));
+  }
+  b->simple = true;
+  return KD_OK;
 }
 
 void kd_lattice_options_default(kd_lattice_options *o) {
@@ -680,6 +716,8 @@ static int PreparePath(kd_batch *b, int32_t use_final_probs) {
                             hipMemcpyDeviceToHost, b->stream));
   KD_HIP_TRY(hipMemcpyAsync(b->h_final_weight.data(), b->final_weight.p,
                             2 * b->batch * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  KD_HIP_TRY(hipMemcpyAsync(b->h_final_rel.data(), b->final_rel.p, b->batch * sizeof(float),
+                            hipMemcpyDeviceToHost, b->stream));
   KD_HIP_TRY(hipStreamSynchronize(b->stream));
   b->path_valid = true;
   b->path_use_final = use_final_probs;
@@ -772,6 +810,8 @@ int kd_batch_frame_tokens(kd_batch *b, int32_t utt, int32_t frame_plus_one, int3
   return KD_OK;
 }
 
+static int PreparePath(kd_batch *b, int32_t use_final_probs);
+
 static int LatticeStats(kd_batch *b) {
   if (b->lat_stats_valid) return KD_OK;
   LatticeParams p = b->LParams();
@@ -801,8 +841,12 @@ int kd_batch_finalize_decoding(kd_batch *b) {
 
 int kd_batch_final_relative_cost(kd_batch *b, float *out) {
   if (!b || !out) return Fail(KD_E_INVALID, "bad argument");
-  if (!b->lattice) return Fail(KD_E_STATE, "not a lattice batch");
   if (!b->initialized) return Fail(KD_E_STATE, "InitDecoding() has not been called");
+  if (!b->lattice) {  // SimpleDecoder::FinalRelativeCost, simple-decoder.cc:78-100
+    if (int r = PreparePath(b, b->path_valid ? b->path_use_final : 1)) return r;
+    for (int i = 0; i < b->batch; ++i) out[i] = b->h_final_rel[i];
+    return KD_OK;
+  }
   KD_HIP_TRY(hipSetDevice(b->g->device));
   if (b->pending)
     if (int r = ReadBack(b)) return r;

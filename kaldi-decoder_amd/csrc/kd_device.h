@@ -94,7 +94,7 @@ struct SearchParams {
   int32_t do_init;   // 1: run InitDecoding instead of advancing
   // lattice mode (LatticeSimpleDecoder / LatticeFasterDecoder semantics)
   int32_t lattice;           // 0: FasterDecoder (double costs), 1: lattice decoders (float costs)
-  int32_t expand_all;        // lattice: LatticeSimpleDecoder expands every token
+  int32_t simple;            // 1: SimpleDecoder semantics (plain beam, prune after closure)
   float *g_log_ac;           // queue: acoustic cost (emitting) / source cost at generation (epsilon)
   float *tok_extra;          // [arena] extra_cost of each token
   int32_t *link_src;         // link arena, utterance u owns [u*link_cap, (u+1)*link_cap)
@@ -162,6 +162,9 @@ struct PathParams {
   const int32_t *frames_decoded;
   int32_t use_final_probs;
   int32_t batch;
+  int32_t simple;            // SimpleDecoder: per-arc costs are the stored ones
+  const float *tok_ac;       // [arena] acoustic cost of the arc that made each token (simple mode)
+  float *final_rel;          // [batch] FinalRelativeCost (simple-decoder.cc:78-100)
   // outputs of the prepare step
   int32_t *reached_final;  // [batch]
   long long *best_tok;     // [batch] arena index or -1

@@ -22,9 +22,10 @@ __global__ __launch_bounds__(kPathBlock) void PathPrepareKernel(const PathParams
   __shared__ unsigned int s_state;
   __shared__ int s_final;
   __shared__ long long s_tok;
+  __shared__ unsigned long long s_bestc, s_bestwf;
   const int tid = threadIdx.x, utt = blockIdx.x;
   const int f = p.frames_decoded[utt];
-  if (tid == 0) { s_best = ~0ull; s_state = 0xFFFFFFFFu; s_final = 0; s_tok = -1; }
+  if (tid == 0) { s_best = ~0ull; s_state = 0xFFFFFFFFu; s_final = 0; s_tok = -1; s_bestc = ~0ull; s_bestwf = ~0ull; }
   __syncthreads();
   long long base = 0;
   int n = 0;
@@ -33,12 +34,14 @@ __global__ __launch_bounds__(kPathBlock) void PathPrepareKernel(const PathParams
     base = p.frame_base[fi];
     n = p.frame_count[fi];
   }
-  // ReachedFinal (:347-354)
+  // ReachedFinal (:347-354); FinalRelativeCost's two minima (simple-decoder.cc:83-91)
   int any_final = 0;
   for (int i = tid; i < n; i += kPathBlock) {
     const double c = p.tok_cost[base + i];
     const float fc = p.states[p.tok_state[base + i]].final_cost;
     if (CostKey(c) != kKeyInf && !(fc == __int_as_float(0x7F800000))) any_final = 1;
+    atomicMin(&s_bestc, CostKey(c));
+    atomicMin(&s_bestwf, CostKey(c + fc));
   }
   if (any_final) s_final = 1;
   __syncthreads();
@@ -79,6 +82,14 @@ __global__ __launch_bounds__(kPathBlock) void PathPrepareKernel(const PathParams
       for (long long t = bt; t >= 0 && p.tok_arc[t] != static_cast<int32_t>(kArcNone); t = p.tok_prev[t]) len++;
       if (is_final && p.use_final_probs) fw = p.states[p.tok_state[bt]].final_cost;  // :416-421
     }
+    {
+      float rel = __int_as_float(0x7F800000);  // no tokens: infinity (:82)
+      if (n > 0) {
+        rel = static_cast<float>(KeyCost(s_bestwf) - KeyCost(s_bestc));
+        if (rel != rel) rel = __int_as_float(0x7F800000);  // NaN (:93-97)
+      }
+      p.final_rel[utt] = rel;
+    }
     p.reached_final[utt] = is_final ? 1 : 0;
     p.best_tok[utt] = bt;
     p.path_len[utt] = len;
@@ -98,10 +109,11 @@ __global__ void PathFillKernel(const PathParams p) {
     const int32_t a = p.tok_arc[t];
     const long long pr = p.tok_prev[t];
     const ArcRec arc = p.arcs[a];
-    // :394-396: tot = float(cost - prev.cost); ac = tot - graph
+    // :394-396: tot = float(cost - prev.cost); ac = tot - graph.  SimpleDecoder keeps
+    // the arc's own (graph, acoustic) pair instead (simple-decoder.h:93-96).
     const float tot_cost = p.tok_cost[t] - (pr >= 0 ? p.tok_cost[pr] : 0.0);
     const float graph_cost = arc.weight;
-    const float ac_cost = tot_cost - graph_cost;
+    const float ac_cost = p.simple ? p.tok_ac[t] : tot_cost - graph_cost;
     p.o_ilabel[off + pos] = arc.ilabel;
     p.o_olabel[off + pos] = arc.olabel;
     p.o_state[off + pos] = static_cast<int32_t>(arc.next & kStateMask);

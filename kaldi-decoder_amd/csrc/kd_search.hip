@@ -82,6 +82,7 @@ struct Shared {
   int32_t hist[256];
   unsigned long long red64[kWaves];
   unsigned long long min_new;   // min cost key seen by the emitting filter
+  unsigned long long min_stored;  // simple mode: min stored cost after the emitting insert
   unsigned long long f_best;    // CostKey of the best cost of the frontier to expand
   unsigned long long f_best_next;
   long long arena_next;         // next free record of this utterance's arena region
@@ -94,6 +95,7 @@ struct Shared {
   int32_t n_emit_links;         // lattice: emitting entries below the final cutoff
   int32_t n_eps_links;          // lattice: epsilon links written so far
   int32_t n_emit_written;       // lattice: emitting links written so far
+  int32_t n_act, n_inact;       // simple: tokens kept / dropped by PruneToks
   long long link_next;          // lattice: next free link of this utterance
   int32_t overflow;
   int32_t wl_count[2];
@@ -267,6 +269,8 @@ struct FrameCtx {
   KD_G float *q_ac;
   int q_cap;
   bool lattice;
+  bool simple;    // SimpleDecoder semantics
+  bool min_only;  // simple: first filter pass only finds the minimum total cost
 };
 
 // Scores one arc out of a token with cost `csrc` and queues it if it survives
@@ -294,7 +298,21 @@ __device__ __forceinline__ void FilterArc(const FrameCtx &c, const ArcRec &a, ui
   } else {
     const float ll = c.ll_in_lds ? s.ll[a.ilabel - 1] : c.ll_row[a.ilabel - 1];
     seen_min = s.min_new;
-    if (c.lattice) {
+    if (c.simple) {
+      // simple-decoder.cc:167-176.  Two passes: the first only finds the minimum
+      // total cost, the second queues what is below min + beam.  The token stores
+      // prev.cost + (weight + ac) with the float sum first (simple-decoder.h:99).
+      const float acoustic_cost = -ll;
+      const double total_cost = csrc + a.weight + acoustic_cost;
+      if (c.min_only) {
+        const unsigned long long tk = CostKey(total_cost);
+        if (tk < seen_min) atomicMin(&s.min_new, tk);
+        return;
+      }
+      keep = !(total_cost >= c.cutoff);
+      nc = csrc + (a.weight + acoustic_cost);
+      aux = acoustic_cost;
+    } else if (c.lattice) {
       // lattice-simple-decoder.cc:383-390: float, cur + ac + graph
       const float ac_cost = -ll, cur_cost = static_cast<float>(csrc),
                   tot_cost = cur_cost + ac_cost + a.weight;
@@ -315,10 +333,10 @@ __device__ __forceinline__ void FilterArc(const FrameCtx &c, const ArcRec &a, ui
       c.q_arc[pos] = aidx;
       c.q_src[pos] = srcid;
       c.q_nk[pos] = nk;
-      if (c.lattice) c.q_ac[pos] = aux;
+      if (c.lattice || c.simple) c.q_ac[pos] = aux;
     }
     if constexpr (!EPS) {
-      if (nk < seen_min) atomicMin(&s.min_new, nk);
+      if (!c.simple && nk < seen_min) atomicMin(&s.min_new, nk);
     }
   }
 }
@@ -455,6 +473,7 @@ __device__ __forceinline__ void Insert(const FrameCtx &c, const Table<LDS> &t, i
         s.overflow = 1;
       } else {
         const unsigned long long old = atomicMin(t.CostP(h), nk);
+        if (!EPS && c.simple && nk < s.min_stored) atomicMin(&s.min_stored, nk);
         bool push = false;
         if (old == kCostDead) {  // the state's first token this frame
           const int pos = atomicAdd(&s.n_live, 1);
@@ -462,7 +481,13 @@ __device__ __forceinline__ void Insert(const FrameCtx &c, const Table<LDS> &t, i
           else s.overflow = 1;
           push = (k & kHasEps) != 0;  // every new token is expanded once (:63-65)
           if constexpr (EPS) {
-            if (push) atomicOr(&t.bitmask[h >> 5], 1u << (h & 31));
+            // a concurrent improver of this brand-new slot may already have queued it:
+            // whoever sets the bit first queues (a slot on the worklist twice would be
+            // expanded twice and, in the lattice decoders, emit its links twice)
+            if (push) {
+              const uint32_t bit = 1u << (h & 31);
+              push = !(atomicOr(&t.bitmask[h >> 5], bit) & bit);
+            }
           }
         } else if (EPS && old > nk && (k & kHasEps)) {  // re-queue on improvement, :97-113
           const uint32_t bit = 1u << (h & 31);
@@ -602,11 +627,17 @@ __device__ __forceinline__ void FrameFront(FrameCtx &c, Counters &cnt) {
   const SearchParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x;
-  GetCutoff(c);
+  if (c.simple) {
+    // SimpleDecoder expands every token of prev_toks_ with a plain beam
+    c.weight_cutoff = __longlong_as_double(0x7FF0000000000000ll);
+    c.adaptive_beam = p.beam;
+  } else {
+    GetCutoff(c);
+  }
   KD_LAP(s, 1);
   // Bound the next cutoff from the best token's arcs first (:176-189); it only
   // shortens the queue, the final cutoff is the same.
-  {
+  if (!c.simple) {
     unsigned long long mk = kCostInf;
     const int bdeg = s.best_deg, babeg = s.best_abeg;
     const double bcost = s.best_cost;
@@ -624,7 +655,17 @@ __device__ __forceinline__ void FrameFront(FrameCtx &c, Counters &cnt) {
   }
   KD_LAP(s, 2);
   Table<true> none{s, nullptr, nullptr, nullptr, nullptr, 0, 0};
-  Filter<true, false>(c, none, c.n_in, nullptr, cnt);
+  // SimpleDecoder: a first pass only finds min total cost, the second queues what
+  // is below min + beam (simple-decoder.cc:170-176 at the cutoff's final value)
+  for (int pass = c.simple ? 0 : 1; pass < 2; ++pass) {
+    c.min_only = pass == 0;
+    if (pass == 1 && c.simple) {
+      c.cutoff = KeyCost(s.min_new) + static_cast<double>(p.beam);
+      cnt = Counters();
+    }
+    Filter<true, false>(c, none, c.n_in, nullptr, cnt);
+  }
+  if (c.simple) return;
   if (c.lattice)  // float, lattice-simple-decoder.cc:388-390
     c.cutoff = static_cast<float>(KeyCost(s.min_new)) + c.adaptive_beam;
   else
@@ -671,7 +712,8 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
   const SearchParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x;
-  const unsigned long long cutkey = CostKey(c.cutoff);
+  // simple mode queued exactly what is below the cutoff (on the total cost)
+  const unsigned long long cutkey = c.simple ? kCostDead : CostKey(c.cutoff);
 
   if (frame < 0) {
     if (tid == 0) {  // faster-decoder.cc:49-51: dummy arc into the start state, cost 0
@@ -690,6 +732,8 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
   __syncthreads();
   KD_LAP(s, 5);
   if (s.overflow) return 1;
+  if (c.simple)  // ProcessNonemitting: best stored cost + beam (simple-decoder.cc:199-205)
+    c.cutoff = (frame < 0 ? 0.0 : KeyCost(s.min_stored)) + static_cast<double>(p.beam);
 
   // ProcessNonemitting to a fixpoint (:59-119)
   int cur = 0, q_begin = q_emit;
@@ -757,12 +801,28 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
   KD_LAP(s, 10);
   const long long base_out = s.base_out;
   if (base_out < 0) return KD_UTT_ARENA_FULL;
+  // SimpleDecoder::PruneToks (simple-decoder.cc:252-281): tokens at or beyond
+  // best + beam leave the frontier.  They keep their arena record (tokens that
+  // survive may point back at them), placed after the kept ones.
+  unsigned long long prune_key = kCostDead;
+  if (c.simple) {
+    unsigned long long mk = kCostDead;
+    for (int i = tid; i < n_out; i += kBlock) {
+      const unsigned long long ck = t.LoadCost(c.live[i]);
+      mk = ck < mk ? ck : mk;
+    }
+    mk = BlockMinU64(s, mk);
+    prune_key = CostKey(KeyCost(mk) + static_cast<double>(p.beam));
+  }
   // C1: live list -> (state, cost); a slot's key word now holds its index in the block.
   {
     unsigned long long my_min = kCostDead;
-    for (int i = tid; i < n_out; i += kBlock) {
-      const uint32_t h = c.live[i];
+    for (int i0 = tid; i0 < n_out; i0 += kBlock) {
+      const uint32_t h = c.live[i0];
       const unsigned long long ck = t.LoadCost(h);
+      int i = i0;
+      if (c.simple)
+        i = ck < prune_key ? atomicAdd(&s.n_act, 1) : n_out - 1 - atomicAdd(&s.n_inact, 1);
       const long long g = base_out + i;
       ToG(p.tok_state)[g] = static_cast<int32_t>(t.LoadKey(h) & kStateMask);
       ToG(p.tok_cost)[g] = KeyCost(ck);
@@ -779,6 +839,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
   }
   __syncthreads();
   KD_LAP(s, 11);
+  const int n_front = c.simple ? s.n_act : n_out;  // tokens the next frame starts from
   // R2: the winning entry of each slot writes the back-pointer.
   {
     auto write_bp = [&](uint32_t h, uint32_t aidx, int i) {
@@ -787,6 +848,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
       const long long prev = (sr & kSrcEps) ? base_out + t.LoadKey(sr & ~kSrcEps) : c.base_in + sr;
       ToG(p.tok_prev)[g] = static_cast<int32_t>(prev);
       ToG(p.tok_arc)[g] = static_cast<int32_t>(aidx);
+      if (c.simple) ToG(p.tok_extra)[g] = c.q_ac[i];  // the arc's stored acoustic cost
     };
 #pragma unroll
     for (int u = 0; u < kQRegs; ++u)
@@ -841,7 +903,8 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
   for (int i = tid; i < n_out; i += kBlock) {
     const uint32_t h = c.live[i];
     if (t.LoadCost(h) == best) {
-      const StateRec r = LoadState(p.states, static_cast<uint32_t>(ToG(p.tok_state)[base_out + i]));
+      const StateRec r =
+          LoadState(p.states, static_cast<uint32_t>(ToG(p.tok_state)[base_out + t.LoadKey(h)]));
       s.best_abeg = r.arc_begin;
       s.best_deg = r.emit_end - r.arc_begin;
       s.best_cost = KeyCost(best);
@@ -850,7 +913,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
   if (tid == 0) {
     const long long fi = static_cast<long long>(c.utt) * (p.max_frames + 1) + (frame + 1);
     ToG(p.frame_base)[fi] = base_out;
-    ToG(p.frame_count)[fi] = n_out;
+    ToG(p.frame_count)[fi] = n_front;
   }
   // fold this frame's counters into the launch totals
   if (cnt.tokens_expanded) atomicAdd(&s.frame_cnt[0], cnt.tokens_expanded);
@@ -888,7 +951,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
     }
   }
   c.base_in = base_out;
-  c.n_in = n_out;
+  c.n_in = n_front;
   return 0;
 }
 
@@ -904,6 +967,8 @@ __device__ __forceinline__ void InitCtx(FrameCtx &c, const SearchParams &p, int 
   c.q_nk = ToG(p.g_log_nk) + utt * 2 * gslots;
   c.q_ac = ToG(p.g_log_ac) + utt * 2 * gslots;
   c.lattice = p.lattice != 0;
+  c.simple = p.simple != 0;
+  c.min_only = false;
   c.ll_in_lds = p.num_cols <= kVmax;
 }
 
@@ -997,6 +1062,9 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
       s.n_emit_links = 0;
       s.n_eps_links = 0;
       s.n_emit_written = 0;
+      s.min_stored = kCostInf;
+      s.n_act = 0;
+      s.n_inact = 0;
     }
     if (frame >= 0) {
       c.ll_row = ToG(ud.ll) + static_cast<long long>(frame - ud.offset) * p.row_stride;
@@ -1013,6 +1081,7 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
       // faster-decoder.cc:53; the lattice decoders use best (= 0) + beam
       // (lattice-simple-decoder.cc:135-154)
       c.cutoff = p.lattice ? static_cast<double>(0.0f + p.beam) : static_cast<double>(FLT_MAX);
+      if (p.simple) c.cutoff = 0.0 + static_cast<double>(p.beam);
     }
     uint32_t r = 1;
     // the queue is a complete journal of the frame's inserts: a frame that does
@@ -1040,7 +1109,7 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
                            cnt.tokens_expanded, cnt.arcs_scanned);
         if (r == 0) {
           c.base_in = s.base_out;
-          c.n_in = s.n_live;
+          c.n_in = p.simple ? s.n_act : s.n_live;
         }
         FullClear<true>(tl, s);
         KD_LAP(s, 14);

@@ -200,6 +200,26 @@ PYBIND11_MODULE(_kaldi_decoder, m) {
            py::arg("max_num_frames") = -1)
       .def("num_frames_decoded", &FasterDecoder::NumFramesDecoded);
 
+  // ref: python/csrc/simple-decoder.cc:15-37
+  py::class_<SimpleDecoder>(m, "SimpleDecoder")
+      .def(py::init<const Fst &, float, const DeviceOptions &>(), py::arg("fst"), py::arg("beam"),
+           py::arg("device_options") = DeviceOptions(), py::keep_alive<1, 2>())
+      .def("decode", &SimpleDecoder::Decode, py::arg("decodable"))
+      .def("reached_final", &SimpleDecoder::ReachedFinal)
+      .def(
+          "get_best_path",
+          [](SimpleDecoder &self, bool use_final_probs) {
+            Lattice lat;
+            const bool ok = self.GetBestPath(&lat, use_final_probs);
+            return std::make_pair(ok, std::move(lat));
+          },
+          py::arg("use_final_probs") = true)
+      .def("final_relative_cost", &SimpleDecoder::FinalRelativeCost)
+      .def("init_decoding", &SimpleDecoder::InitDecoding)
+      .def("advance_decoding", &SimpleDecoder::AdvanceDecoding, py::arg("decodable"),
+           py::arg("max_num_frames") = -1)
+      .def("num_frames_decoded", &SimpleDecoder::NumFramesDecoded);
+
   // ---- lattice decoders (ref: python/csrc/lattice-simple-decoder.cc:15-68) ----
   py::class_<LatticeSimpleDecoderConfig>(m, "LatticeSimpleDecoderConfig")
       .def(py::init<float, float, int32_t, bool, bool, float, float>(), py::arg("beam") = 16.0,

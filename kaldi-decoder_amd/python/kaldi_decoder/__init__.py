@@ -34,6 +34,7 @@ try:
         LatticeFasterDecoderConfig,
         LatticeSimpleDecoder,
         LatticeSimpleDecoderConfig,
+        SimpleDecoder,
         get_linear_symbol_sequence,
         shortest_path,
     )

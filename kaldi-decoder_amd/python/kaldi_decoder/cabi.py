@@ -33,6 +33,7 @@ SYMBOLS = (
     "kd_batch_last_kernel_ms", "kd_batch_device_bytes", "kd_batch_phase_cycles",
     "kd_lattice_options_default", "kd_batch_create_lattice", "kd_batch_finalize_decoding",
     "kd_batch_final_relative_cost", "kd_batch_raw_lattice_prepare", "kd_batch_raw_lattice_copy",
+    "kd_batch_create_simple",
 )
 
 
@@ -112,6 +113,8 @@ def lib():
     L.kd_lattice_options_default.restype = None
     L.kd_batch_create_lattice.argtypes = [C.c_void_p, C.POINTER(LatticeOptions), C.c_int32,
                                           C.c_void_p, C.POINTER(C.c_void_p)]
+    L.kd_batch_create_simple.argtypes = [C.c_void_p, C.c_float, C.c_int64, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
     L.kd_batch_finalize_decoding.argtypes = [C.c_void_p]
     L.kd_batch_final_relative_cost.argtypes = [C.c_void_p, _f32p]
     L.kd_batch_raw_lattice_prepare.argtypes = [C.c_void_p, C.c_int32, _i32p]
@@ -391,4 +394,22 @@ class LatticeBatch(Batch):
                                   ol[a:b].copy(), gc[a:b].copy(), ac[a:b].copy(),
                                   sf[s0:s1].copy(), sg[s0:s1].copy(), fs[f0:f1].copy(),
                                   fg[f0:f1].copy()))
+        return out
+
+
+class SimpleBatch(Batch):
+    """`max_batch` SimpleDecoder instances (plain beam) over one graph."""
+
+    def __init__(self, graph: Graph, max_batch=1, beam=16.0, stream=None, arena_tokens=0,
+                 table_slots=0, max_frames=0):
+        self.graph = graph
+        self.max_batch = max_batch
+        self.h = C.c_void_p()
+        self.batch = 0
+        _check(lib().kd_batch_create_simple(graph.h, beam, arena_tokens, table_slots, max_frames,
+                                            max_batch, C.c_void_p(stream or 0), C.byref(self.h)))
+
+    def final_relative_cost(self):
+        out = np.zeros(self.batch, np.float32)
+        _check(lib().kd_batch_final_relative_cost(self.h, out))
         return out

@@ -746,6 +746,179 @@ struct SimpleDecoder {
   }
 };
 
+
+// ---------------------------------------------------------------------------
+// Canonical (order-free) SimpleDecoder: what the GPU implements for it.
+// Same values as SimpleDecoder above, without the dependence on unordered_map
+// order: the emitting cutoff is min total_cost + beam (the value the running
+// cutoff of simple-decoder.cc:170-176 ends at), ties take the lowest arc index,
+// final-state ties the lowest state.
+// ---------------------------------------------------------------------------
+struct CanonSimpleDecoder {
+  struct Token { int32_t arc, prev; float ac; double cost; };
+  const Graph &g;
+  float beam;
+  std::vector<Token> arena;
+  std::unordered_map<int32_t, int32_t> cur;  // state -> token, after PruneToks
+  int32_t num_frames_decoded = -1;
+
+  CanonSimpleDecoder(const Graph &graph, float b) : g(graph), beam(b) {}
+
+  void Closure() {  // simple-decoder.cc:195-241
+    double best_cost = kInfD;
+    for (auto &kv : cur) best_cost = std::min(best_cost, arena[kv.second].cost);
+    const double cutoff = best_cost + beam;
+    std::vector<int32_t> work;
+    for (auto &kv : cur) if (g.num_ieps[kv.first] != 0) work.push_back(kv.first);
+    while (!work.empty()) {
+      int32_t state = work.back();
+      work.pop_back();
+      int32_t ti = cur[state];
+      double tcost = arena[ti].cost;
+      for (int32_t a = g.row_ptr[state]; a < g.row_ptr[state + 1]; ++a) {
+        if (g.ilabel[a] != 0) continue;
+        double c = tcost + (g.weight[a] + 0.0f);
+        if (c > cutoff) continue;
+        auto it = cur.find(g.nextstate[a]);
+        if (it == cur.end()) {
+          arena.push_back(Token{a, ti, 0.f, c});
+          cur[g.nextstate[a]] = static_cast<int32_t>(arena.size()) - 1;
+          if (g.num_ieps[g.nextstate[a]]) work.push_back(g.nextstate[a]);
+        } else if (c < arena[it->second].cost) {
+          arena.push_back(Token{a, ti, 0.f, c});
+          it->second = static_cast<int32_t>(arena.size()) - 1;
+          if (g.num_ieps[g.nextstate[a]]) work.push_back(g.nextstate[a]);
+        }
+      }
+    }
+    for (auto &kv : cur) {  // tie-break: lowest canonical arc among achievers
+      double tcost = arena[kv.second].cost;
+      for (int32_t a = g.row_ptr[kv.first]; a < g.row_ptr[kv.first + 1]; ++a) {
+        if (g.ilabel[a] != 0) continue;
+        double c = tcost + (g.weight[a] + 0.0f);
+        if (c > cutoff) continue;
+        auto it = cur.find(g.nextstate[a]);
+        if (it == cur.end()) continue;
+        Token &dst = arena[it->second];
+        if (c == dst.cost && dst.arc >= 0 && g.canon_idx[a] < g.canon_idx[dst.arc]) {
+          dst.arc = a; dst.prev = kv.second; dst.ac = 0.f;
+        }
+      }
+    }
+  }
+  void InitDecoding() {
+    arena.clear();
+    cur.clear();
+    if (g.start < 0) throw std::runtime_error("graph has no start state");
+    arena.push_back(Token{-1, -1, 0.f, 0.0});
+    cur[g.start] = 0;
+    num_frames_decoded = 0;
+    Closure();
+  }
+  void AdvanceDecoding(const Decodable &d, int32_t max_num_frames) {
+    if (num_frames_decoded < 0)
+      throw std::runtime_error("You must call InitDecoding() before AdvanceDecoding()");
+    int32_t ready = d.NumFramesReady();
+    if (!(ready >= num_frames_decoded)) throw std::runtime_error("num_frames_ready >= num_frames_decoded_");
+    int32_t target = ready;
+    if (max_num_frames >= 0) target = std::min(target, num_frames_decoded + max_num_frames);
+    while (num_frames_decoded < target) {
+      const int32_t frame = num_frames_decoded;
+      double best_total = kInfD;
+      for (auto &kv : cur)
+        for (int32_t a = g.row_ptr[kv.first]; a < g.row_ptr[kv.first + 1]; ++a) {
+          if (g.ilabel[a] == 0) continue;
+          float ac = -d.LogLikelihood(frame, g.ilabel[a]);
+          double total = arena[kv.second].cost + g.weight[a] + ac;
+          best_total = std::min(best_total, total);
+        }
+      const double cutoff = best_total + beam;
+      struct Best { double cost; int32_t arc, prev; float ac; };
+      std::unordered_map<int32_t, Best> nxt;
+      for (auto &kv : cur)
+        for (int32_t a = g.row_ptr[kv.first]; a < g.row_ptr[kv.first + 1]; ++a) {
+          if (g.ilabel[a] == 0) continue;
+          float ac = -d.LogLikelihood(frame, g.ilabel[a]);
+          double total = arena[kv.second].cost + g.weight[a] + ac;
+          if (total >= cutoff) continue;  // :170
+          double c = arena[kv.second].cost + (g.weight[a] + ac);  // simple-decoder.h:99
+          auto it = nxt.find(g.nextstate[a]);
+          if (it == nxt.end()) nxt.emplace(g.nextstate[a], Best{c, a, kv.second, ac});
+          else if (c < it->second.cost ||
+                   (c == it->second.cost && g.canon_idx[a] < g.canon_idx[it->second.arc]))
+            it->second = Best{c, a, kv.second, ac};
+        }
+      cur.clear();
+      for (auto &kv : nxt) {
+        arena.push_back(Token{kv.second.arc, kv.second.prev, kv.second.ac, kv.second.cost});
+        cur[kv.first] = static_cast<int32_t>(arena.size()) - 1;
+      }
+      num_frames_decoded++;
+      Closure();
+      // PruneToks, :252-281
+      if (!cur.empty()) {
+        double best = kInfD;
+        for (auto &kv : cur) best = std::min(best, arena[kv.second].cost);
+        const double pc = best + beam;
+        for (auto it = cur.begin(); it != cur.end();)
+          if (arena[it->second].cost < pc) ++it; else it = cur.erase(it);
+      }
+    }
+  }
+  std::vector<std::pair<int32_t, int32_t>> Sorted() const {
+    std::vector<std::pair<int32_t, int32_t>> v(cur.begin(), cur.end());
+    std::sort(v.begin(), v.end());
+    return v;
+  }
+  bool ReachedFinal() const {
+    for (auto &kv : cur)
+      if (arena[kv.second].cost != kInfF && g.final_cost[kv.first] != kInfF) return true;
+    return false;
+  }
+  float FinalRelativeCost() const {
+    if (cur.empty()) return kInfD;
+    double best_cost = kInfD, best_wf = kInfD;
+    for (auto &kv : cur) {
+      best_cost = std::min(best_cost, arena[kv.second].cost);
+      best_wf = std::min(best_wf, arena[kv.second].cost + g.final_cost[kv.first]);
+    }
+    float extra = best_wf - best_cost;
+    if (extra != extra) return kInfD;
+    return extra;
+  }
+  Path GetBestPath(bool use_final_probs) const {
+    Path out;
+    int32_t best_tok = -1;
+    bool is_final = ReachedFinal();
+    double best_cost = kInfD;
+    for (auto &kv : Sorted()) {
+      double c = arena[kv.second].cost + (is_final ? static_cast<double>(g.final_cost[kv.first]) : 0.0);
+      if (is_final) { if (c != kInfD && c < best_cost) { best_cost = c; best_tok = kv.second; } }
+      else if (best_tok < 0 || c < best_cost) { best_cost = c; best_tok = kv.second; }
+    }
+    if (best_tok < 0) return out;
+    for (int32_t t = best_tok; t >= 0 && arena[t].arc >= 0; t = arena[t].prev) {
+      const Token &tok = arena[t];
+      out.ilabel.push_back(g.ilabel[tok.arc]);
+      out.olabel.push_back(g.olabel[tok.arc]);
+      out.state.push_back(g.nextstate[tok.arc]);
+      out.graph_cost.push_back(g.weight[tok.arc]);
+      out.ac_cost.push_back(tok.ac);
+    }
+    std::reverse(out.ilabel.begin(), out.ilabel.end());
+    std::reverse(out.olabel.begin(), out.olabel.end());
+    std::reverse(out.state.begin(), out.state.end());
+    std::reverse(out.graph_cost.begin(), out.graph_cost.end());
+    std::reverse(out.ac_cost.begin(), out.ac_cost.end());
+    if (is_final && use_final_probs) {
+      const Token &bt = arena[best_tok];
+      out.final_graph = g.final_cost[bt.arc < 0 ? g.start : g.nextstate[bt.arc]];
+    }
+    out.ok = true;
+    return out;
+  }
+};
+
 // ---------------------------------------------------------------------------
 // Lattice output (what GetRawLattice builds: fst::VectorFst<LatticeArc>)
 // ---------------------------------------------------------------------------
@@ -1579,6 +1752,33 @@ float kdo_simple_final_relative_cost(void *d) { return static_cast<SimpleDecoder
 int kdo_simple_best_path(void *d, int32_t use_final_probs, int32_t cap, int32_t *n, int32_t *il,
                          int32_t *ol, int32_t *st, float *gc, float *ac, float *final_w) {
   Path p = static_cast<SimpleDecoder *>(d)->GetBestPath(use_final_probs != 0);
+  return CopyPath(p, cap, n, il, ol, st, gc, ac, final_w);
+}
+
+
+// -- canonical SimpleDecoder (policy 1) ---------------------------------------------
+void *kdo_csimple_create(void *graph, float beam) {
+  return new CanonSimpleDecoder(*static_cast<Graph *>(graph), beam);
+}
+void kdo_csimple_free(void *d) { delete static_cast<CanonSimpleDecoder *>(d); }
+int kdo_csimple_init(void *d) { return Guard([&] { static_cast<CanonSimpleDecoder *>(d)->InitDecoding(); }); }
+int kdo_csimple_advance(void *d, const float *p, int32_t rows, int32_t cols, int32_t offset,
+                        int32_t max_num_frames) {
+  Decodable dec{p, rows, cols, offset};
+  return Guard([&] { static_cast<CanonSimpleDecoder *>(d)->AdvanceDecoding(dec, max_num_frames); });
+}
+int32_t kdo_csimple_num_frames_decoded(void *d) { return static_cast<CanonSimpleDecoder *>(d)->num_frames_decoded; }
+int32_t kdo_csimple_reached_final(void *d) { return static_cast<CanonSimpleDecoder *>(d)->ReachedFinal(); }
+int32_t kdo_csimple_num_tokens(void *d) { return static_cast<int32_t>(static_cast<CanonSimpleDecoder *>(d)->cur.size()); }
+float kdo_csimple_final_relative_cost(void *d) { return static_cast<CanonSimpleDecoder *>(d)->FinalRelativeCost(); }
+void kdo_csimple_tokens(void *dv, int32_t *states, double *costs) {
+  auto *d = static_cast<CanonSimpleDecoder *>(dv);
+  size_t i = 0;
+  for (auto &kv : d->Sorted()) { states[i] = kv.first; costs[i] = d->arena[kv.second].cost; ++i; }
+}
+int kdo_csimple_best_path(void *d, int32_t use_final_probs, int32_t cap, int32_t *n, int32_t *il,
+                          int32_t *ol, int32_t *st, float *gc, float *ac, float *final_w) {
+  Path p = static_cast<CanonSimpleDecoder *>(d)->GetBestPath(use_final_probs != 0);
   return CopyPath(p, cap, n, il, ol, st, gc, ac, final_w);
 }
 

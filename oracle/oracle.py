@@ -50,7 +50,7 @@ def lib():
     path_args = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), _i32p, _i32p, _i32p,
                  _f32p, _f32p, _f32p]
     adv_args = [C.c_void_p, _f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
-    for pre in ("faster", "simple"):
+    for pre in ("faster", "simple", "csimple"):
         getattr(L, f"kdo_{pre}_free").argtypes = [C.c_void_p]
         getattr(L, f"kdo_{pre}_init").argtypes = [C.c_void_p]
         getattr(L, f"kdo_{pre}_advance").argtypes = adv_args
@@ -64,6 +64,11 @@ def lib():
     L.kdo_simple_create.argtypes = [C.c_void_p, C.c_float]
     L.kdo_simple_final_relative_cost.restype = C.c_float
     L.kdo_simple_final_relative_cost.argtypes = [C.c_void_p]
+    L.kdo_csimple_create.restype = C.c_void_p
+    L.kdo_csimple_create.argtypes = [C.c_void_p, C.c_float]
+    L.kdo_csimple_final_relative_cost.restype = C.c_float
+    L.kdo_csimple_final_relative_cost.argtypes = [C.c_void_p]
+    L.kdo_csimple_tokens.argtypes = [C.c_void_p, _i32p, _f64p]
     L.kdo_latsimple_create.restype = C.c_void_p
     L.kdo_latsimple_create.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_float]
     L.kdo_latsimple_free.argtypes = [C.c_void_p]
@@ -282,6 +287,25 @@ class SimpleDecoder(_Decoder):
 
     def final_relative_cost(self):
         return lib().kdo_simple_final_relative_cost(self.h)
+
+
+class CanonSimpleDecoder(_Decoder):
+    """Order-free SimpleDecoder (policy 1): what the GPU computes for SimpleDecoder."""
+    _pre = "csimple"
+
+    def __init__(self, graph: Graph, beam=16.0):
+        self.graph = graph
+        self.h = C.c_void_p(lib().kdo_csimple_create(graph.h, beam))
+
+    def final_relative_cost(self):
+        return lib().kdo_csimple_final_relative_cost(self.h)
+
+    def tokens(self):
+        n = self.num_tokens()
+        s = np.zeros(n, np.int32)
+        c = np.zeros(n, np.float64)
+        lib().kdo_csimple_tokens(self.h, s, c)
+        return s, c
 
 
 class RawLattice:

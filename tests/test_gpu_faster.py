@@ -179,3 +179,43 @@ def test_error_behaviour():
     b2.advance_host([np.zeros((3, 2), np.float32)])
     p = b2.best_paths()[0]
     assert not p.ok and not b2.reached_final()[0]
+
+
+def test_simple_decoder_mode_matches_canonical_oracle(oracle):
+    # SimpleDecoder semantics (plain beam, float-first cost sum, PruneToks) on the GPU
+    cases = [(synth.ctc_topo(32), None, 32, 10.0)]
+    for seed in range(3):
+        cases.append((synth.random_graph(200 + 200 * seed, 3.0, 16, 0.25, 40 + seed), None, 16,
+                      6.0 + 2 * seed))
+    g = synth.hlg_graph(V=40, n_words=200, n_hist=200, avg_succ=8, seed=4)
+    cases.append((g, g["lexicon"], 40, 9.0))
+    for g, lex, V, beam in cases:
+        G, OG = cabi.Graph(g), oracle.Graph(g)
+        B, T = 3, 45
+        lps = [synth.make_logprobs(T - 5 * i, V, i, peak=5.0, lexicon=lex) for i in range(B)]
+        sb = cabi.SimpleBatch(G, max_batch=B, beam=beam)
+        sb.init_decoding()
+        decs = [oracle.CanonSimpleDecoder(OG, beam=beam) for _ in range(B)]
+        for d in decs:
+            d.init_decoding()
+        for t0 in range(0, T, 9):
+            sb.advance_host(lps, max_num_frames=9)
+            for i, d in enumerate(decs):
+                d.advance_decoding(lps[i], max_num_frames=9)
+                s, c = sb.frame_tokens(i, d.num_frames_decoded())
+                so, co = d.tokens()
+                assert s.tolist() == so.tolist() and c.tolist() == co.tolist(), (i, t0)
+        frc = sb.final_relative_cost()
+        rf = sb.reached_final()
+        for use_final in (True, False):
+            paths = sb.best_paths(use_final)
+            for i, d in enumerate(decs):
+                _assert_same_path(paths[i], d.get_best_path(use_final), (i, use_final))
+                assert bool(rf[i]) == d.reached_final()
+                assert frc[i] == np.float32(d.final_relative_cost()) or \
+                    (np.isinf(frc[i]) and np.isinf(d.final_relative_cost()))
+        # and against the reference-order restatement: same best words
+        for i in range(B):
+            r = oracle.SimpleDecoder(OG, beam=beam)
+            r.decode(lps[i])
+            assert r.get_best_path().osyms.tolist() == paths[i].osyms.tolist()

@@ -45,6 +45,7 @@ def test_raw_lattice_matches_canonical_oracle(oracle, case):
         assert gl.num_states == cl.num_states, (name, i)
         assert gl.state_set() == cl.state_set(), (name, i)
         assert gl.arc_set() == cl.arc_set(), (name, i)
+        assert len(gl.src) == len(cl.src), (name, i)  # and no arc twice
         assert gl.final_set() == cl.final_set(), (name, i)
         assert gl.state_graph[gl.start] == g["start"] and gl.state_frame[gl.start] == 0
         assert frc[i] == can.final_relative_cost() == frc_before[i], (name, i)

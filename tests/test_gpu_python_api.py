@@ -190,3 +190,22 @@ def test_lattice_faster_decoder_streaming_and_batch(oracle):
         kd.LatticeFasterDecoder(fst, kd.LatticeFasterDecoderConfig(prune_scale=2.0))
     with pytest.raises(RuntimeError, match="Check failed"):
         kd.LatticeSimpleDecoder(fst, kd.LatticeSimpleDecoderConfig(prune_interval=0))
+
+
+def test_simple_decoder_python_flow(oracle):
+    g = synth.hl_graph(V=40, n_words=400, seed=3)
+    fst = kd.fst_from_dict(g)
+    lp = synth.make_logprobs(50, 40, 2, peak=7.0, lexicon=g["lexicon"])
+    dec = kd.SimpleDecoder(fst, 10.0)
+    assert dec.decode(kd.DecodableCtc(lp)) is True
+    ref = oracle.CanonSimpleDecoder(oracle.Graph(g), beam=10.0)
+    ref.decode(lp)
+    assert dec.num_frames_decoded() == 50 and dec.reached_final() == ref.reached_final()
+    assert dec.final_relative_cost() == pytest.approx(ref.final_relative_cost())
+    ok, lat = dec.get_best_path()
+    _, isyms, osyms, _ = lat.get_linear_symbol_sequence()
+    rp = ref.get_best_path()
+    assert ok and isyms == rp.isyms.tolist() and osyms == rp.osyms.tolist()
+    dec.init_decoding()
+    dec.advance_decoding(kd.DecodableCtc(lp), max_num_frames=20)
+    assert dec.num_frames_decoded() == 20
