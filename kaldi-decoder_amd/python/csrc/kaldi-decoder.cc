@@ -19,6 +19,7 @@
 #include "decodable-ctc.h"
 #include "decodable-itf.h"
 #include "faster-decoder.h"
+#include "fst-io.h"
 #include "fst.h"
 #include "lattice-decoder.h"
 
@@ -120,6 +121,21 @@ PYBIND11_MODULE(_kaldi_decoder, m) {
            }),
            py::arg("start"), py::arg("row_ptr"), py::arg("ilabel"), py::arg("olabel"),
            py::arg("weight"), py::arg("nextstate"), py::arg("final"))
+      // OpenFst binary "vector" / "const" files over standard arcs (what
+      // kaldifst.StdVectorFst.read / StdConstFst.read load)
+      .def_static("read", [](const std::string &path) { return ReadFst(path).release(); },
+                  py::arg("filename"), py::return_value_policy::take_ownership)
+      .def("write",
+           [](const Fst &f, const std::string &path, const std::string &t) { WriteFst(f, path, t); },
+           py::arg("filename"), py::arg("fst_type") = "vector")
+      .def("arrays",
+           [](const Fst &f) {
+             auto I = [](const std::vector<int32_t> &v) { return py::array_t<int32_t>(v.size(), v.data()); };
+             auto F = [](const std::vector<float> &v) { return py::array_t<float>(v.size(), v.data()); };
+             return py::make_tuple(I(f.RowPtr()), I(f.Ilabel()), I(f.Olabel()), F(f.Weight()),
+                                   I(f.NextState()), F(f.FinalCosts()));
+           },
+           "(row_ptr, ilabel, olabel, weight, nextstate, final) CSR arrays")
       .def_property_readonly("start", &Fst::Start)
       .def_property_readonly("num_states", &Fst::NumStates)
       .def_property_readonly("num_arcs", &Fst::NumArcs)
