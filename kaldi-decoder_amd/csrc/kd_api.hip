@@ -81,7 +81,7 @@ struct kd_batch {
   int32_t lat_use_final = -1;
   kd_lattice_options lo{};
   int64_t link_cap = 0;  // per utterance
-  DevBuf<float> g_log_ac, tok_extra, link_ac, link_graph, lat_frc, lat_fbc;
+  DevBuf<float> g_log_ac, g_log_gr, tok_extra, link_ac, link_graph, lat_frc, lat_fbc;
   DevBuf<int32_t> link_src, link_dst, link_arc, link_emit_count, link_eps_count, tok_newid,
       lat_any_final, lat_sizes;
   DevBuf<long long> link_emit_base, link_eps_base, lat_state_off, lat_arc_off, lat_final_off;
@@ -158,6 +158,7 @@ struct kd_batch {
     p.lattice = lattice ? 1 : 0;
     p.simple = simple ? 1 : 0;
     p.g_log_ac = g_log_ac.p;
+    p.g_log_gr = g_log_gr.p;
     p.tok_extra = tok_extra.p;
     p.link_src = link_src.p;
     p.link_dst = link_dst.p;
@@ -475,6 +476,7 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
     hipError_t e2 = hipSuccess;
     auto A2 = [&](hipError_t r) { if (e2 == hipSuccess) e2 = r; };
     A2(b->g_log_ac.Alloc(2 * gs));
+    A2(b->g_log_gr.Alloc(2 * gs));
     A2(b->tok_extra.Alloc(b->o.arena_tokens));
     A2(b->tok_newid.Alloc(b->o.arena_tokens));
     A2(b->lat_scratch.Alloc(b->o.arena_tokens));

@@ -38,7 +38,7 @@ constexpr uint32_t kArcNone = 0xFFFFFFFFu;
 constexpr uint32_t kSrcEps = 0x80000000u;  // back-pointer source is a table slot
 constexpr uint32_t kSrcNone = 0xFFFFFFFFu;
 constexpr unsigned long long kCostDead = 0xFFFFFFFFFFFFFFFFull;
-constexpr int kProfSlots = 16;   // diagnostic cycle buckets (KD_PROFILE builds)
+constexpr int kProfSlots = 20;   // diagnostic cycle buckets (KD_PROFILE builds)
 constexpr int kStatStride = 32;  // KD_NUM_STATS counters + kProfSlots, padded
 
 struct UttDesc {
@@ -96,6 +96,7 @@ struct SearchParams {
   int32_t lattice;           // 0: FasterDecoder (double costs), 1: lattice decoders (float costs)
   int32_t simple;            // 1: SimpleDecoder semantics (plain beam, prune after closure)
   float *g_log_ac;           // queue: acoustic cost (emitting) / source cost at generation (epsilon)
+  float *g_log_gr;           // queue: graph cost of the arc (lattice mode)
   float *tok_extra;          // [arena] extra_cost of each token
   int32_t *link_src;         // link arena, utterance u owns [u*link_cap, (u+1)*link_cap)
   int32_t *link_dst;         // -1 once pruned

@@ -163,7 +163,23 @@ __device__ __forceinline__ void LdsBarrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Barrier for phases whose cross-wave traffic is the token table: LDS in the LDS
+// mode, global memory in the spill mode.
+template <bool LDS>
+__device__ __forceinline__ void TableBarrier() {
+  if constexpr (LDS) LdsBarrier(); else __syncthreads();
+}
+
 // ---- block-wide primitives (wave64 shuffles + one LDS hop) -----------------
+// Sum over the wave.  (An atomicAdd of a per-lane value makes hipcc serialise the
+// lanes in a waterfall loop -- thousands of cycles for sixteen waves -- so reduce
+// with shuffles first and let one lane add.)
+__device__ __forceinline__ int WaveSumInt(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
 __device__ __forceinline__ unsigned long long WaveMinU64(unsigned long long v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -238,9 +254,15 @@ struct Table {
   __device__ __forceinline__ uint32_t Claim(uint32_t k) const {
     uint32_t h = Hash(k & kStateMask);
     for (uint32_t probe = 0; probe <= mask; ++probe) {
-      const uint32_t cur = LoadKey(h);
-      if (cur == k) return h;
-      if (cur == kKeyEmpty) {
+      if constexpr (LDS) {
+        const uint32_t cur = s.key[h];
+        if (cur == k) return h;
+        if (cur == kKeyEmpty) {
+          const uint32_t old = atomicCAS(&s.key[h], kKeyEmpty, k);
+          if (old == kKeyEmpty || old == k) return h;
+        }
+      } else {
+        // one L2 round trip per probe: the compare-and-swap also answers "is it k?"
         const uint32_t old = atomicCAS(KeyP(h), kKeyEmpty, k);
         if (old == kKeyEmpty || old == k) return h;
       }
@@ -266,7 +288,7 @@ struct FrameCtx {
   // candidate queue: destination (state|flag, later its slot), arc, source, cost key
   KD_G uint32_t *q_h, *q_arc, *q_src;
   KD_G unsigned long long *q_nk;
-  KD_G float *q_ac;
+  KD_G float *q_ac, *q_gr;
   int q_cap;
   bool lattice;
   bool simple;    // SimpleDecoder semantics
@@ -334,6 +356,7 @@ __device__ __forceinline__ void FilterArc(const FrameCtx &c, const ArcRec &a, ui
       c.q_src[pos] = srcid;
       c.q_nk[pos] = nk;
       if (c.lattice || c.simple) c.q_ac[pos] = aux;
+      if (c.lattice) c.q_gr[pos] = a.weight;
     }
     if constexpr (!EPS) {
       if (!c.simple && nk < seen_min) atomicMin(&s.min_new, nk);
@@ -589,9 +612,13 @@ __device__ __forceinline__ void GetCutoff(FrameCtx &c) {
     lt += v < beam_cutoff;
     le += v <= beam_cutoff;
   }
-  if (lt) atomicAdd(&s.f_nlt, lt);
-  if (le) atomicAdd(&s.f_nle, le);
-  __syncthreads();
+  lt = WaveSumInt(lt);
+  le = WaveSumInt(le);
+  if ((tid & 63) == 0) {
+    if (lt) atomicAdd(&s.f_nlt, lt);
+    if (le) atomicAdd(&s.f_nle, le);
+  }
+  LdsBarrier();
   const int n_lt = s.f_nlt, n_le = s.f_nle;
   // tmp_array_[k] < x  <=>  #{v < x} >= k+1 ;  tmp_array_[k] > x  <=>  #{v <= x} <= k
   if (c.n_in > p.max_active && static_cast<long long>(n_lt) >= static_cast<long long>(p.max_active) + 1) {
@@ -744,7 +771,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
     const int words = LDS ? kSlots / 32 : (1 << (t.log2_slots - 5));
     for (int w = tid; w < words; w += kBlock) t.bitmask[w] = 0;
     if (tid == 0) s.wl_count[cur ^ 1] = 0;
-    __syncthreads();
+    TableBarrier<LDS>();
     KD_LAP(s, 6);
     Filter<LDS, true>(c, t, n_items, wl_a, cnt);
     const int q_end = s.q_n;
@@ -797,7 +824,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
     s.best_abeg = 0;
     s.best_cost = 0.0;
   }
-  __syncthreads();
+  TableBarrier<LDS>();
   KD_LAP(s, 10);
   const long long base_out = s.base_out;
   if (base_out < 0) return KD_UTT_ARENA_FULL;
@@ -815,8 +842,9 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
     prune_key = CostKey(KeyCost(mk) + static_cast<double>(p.beam));
   }
   // C1: live list -> (state, cost); a slot's key word now holds its index in the block.
+  unsigned long long my_min = kCostDead;
+  uint32_t my_min_state = 0;
   {
-    unsigned long long my_min = kCostDead;
     for (int i0 = tid; i0 < n_out; i0 += kBlock) {
       const uint32_t h = c.live[i0];
       const unsigned long long ck = t.LoadCost(h);
@@ -824,7 +852,8 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
       if (c.simple)
         i = ck < prune_key ? atomicAdd(&s.n_act, 1) : n_out - 1 - atomicAdd(&s.n_inact, 1);
       const long long g = base_out + i;
-      ToG(p.tok_state)[g] = static_cast<int32_t>(t.LoadKey(h) & kStateMask);
+      const uint32_t st_of_tok = t.LoadKey(h) & kStateMask;
+      ToG(p.tok_state)[g] = static_cast<int32_t>(st_of_tok);
       ToG(p.tok_cost)[g] = KeyCost(ck);
       if (c.lattice) ToG(p.tok_extra)[g] = 0.0f;  // lattice-simple-decoder.cc:91-95
       if (t.LoadArc(h) == kArcNone) {  // the start token
@@ -832,12 +861,14 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
         ToG(p.tok_arc)[g] = -1;
       }
       t.StoreKey(h, static_cast<uint32_t>(i));
-      my_min = ck < my_min ? ck : my_min;
+      if (ck < my_min) { my_min = ck; my_min_state = st_of_tok; }
     }
-    my_min = WaveMinU64(my_min);
-    if ((tid & 63) == 0 && my_min != kCostDead) atomicMin(&s.f_best_next, my_min);
+    const unsigned long long wmin = WaveMinU64(my_min);
+    if ((tid & 63) == 0 && wmin != kCostDead) atomicMin(&s.f_best_next, wmin);
   }
-  __syncthreads();
+  // the token records just stored are next read by the next frame's filter, behind
+  // the full barrier that follows the log-likelihood row load
+  TableBarrier<LDS>();
   KD_LAP(s, 11);
   const int n_front = c.simple ? s.n_act : n_out;  // tokens the next frame starts from
   // R2: the winning entry of each slot writes the back-pointer.
@@ -861,6 +892,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
       if (t.LoadCost(h) == c.q_nk[i] && t.LoadArc(h) == aidx) write_bp(h, aidx, i);
     }
   }
+  KD_LAP(s, 16);
   // Lattice decoders: every queue entry below the cutoff is a ForwardLink
   // (lattice-simple-decoder.cc:393-398, :179-180).  Emitting links leave the
   // previous frame's tokens; epsilon links stay inside this frame and are kept
@@ -895,32 +927,37 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
       ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + t.LoadKey(h));
       ToG(p.link_arc)[at] = static_cast<int32_t>(aidx);
       ToG(p.link_ac)[at] = ac;
-      ToG(p.link_graph)[at] = LoadArcRec(p.arcs, aidx).weight;
+      ToG(p.link_graph)[at] = c.q_gr[i];
     }
   }
+  KD_LAP(s, 17);
   // next frame's best token: fetch its arc range now, off the critical path
   const unsigned long long best = s.f_best_next;
-  for (int i = tid; i < n_out; i += kBlock) {
-    const uint32_t h = c.live[i];
-    if (t.LoadCost(h) == best) {
-      const StateRec r =
-          LoadState(p.states, static_cast<uint32_t>(ToG(p.tok_state)[base_out + t.LoadKey(h)]));
-      s.best_abeg = r.arc_begin;
-      s.best_deg = r.emit_end - r.arc_begin;
-      s.best_cost = KeyCost(best);
-    }
+  if (my_min == best && best != kCostDead) {
+    const StateRec r = LoadState(p.states, my_min_state);
+    s.best_abeg = r.arc_begin;
+    s.best_deg = r.emit_end - r.arc_begin;
+    s.best_cost = KeyCost(best);
   }
   if (tid == 0) {
     const long long fi = static_cast<long long>(c.utt) * (p.max_frames + 1) + (frame + 1);
     ToG(p.frame_base)[fi] = base_out;
     ToG(p.frame_count)[fi] = n_front;
   }
+  KD_LAP(s, 18);
   // fold this frame's counters into the launch totals
-  if (cnt.tokens_expanded) atomicAdd(&s.frame_cnt[0], cnt.tokens_expanded);
-  if (cnt.eps_exp) atomicAdd(&s.frame_cnt[1], cnt.eps_exp);
-  if (cnt.arcs_scanned) atomicAdd(&s.frame_cnt[2], cnt.arcs_scanned);
-  if (cnt.eps_arcs) atomicAdd(&s.frame_cnt[3], cnt.eps_arcs);
-  __syncthreads();
+  {
+    const int w0 = WaveSumInt(cnt.tokens_expanded), w1 = WaveSumInt(cnt.eps_exp),
+              w2 = WaveSumInt(cnt.arcs_scanned), w3 = WaveSumInt(cnt.eps_arcs);
+    if ((tid & 63) == 0) {
+      if (w0) atomicAdd(&s.frame_cnt[0], w0);
+      if (w1) atomicAdd(&s.frame_cnt[1], w1);
+      if (w2) atomicAdd(&s.frame_cnt[2], w2);
+      if (w3) atomicAdd(&s.frame_cnt[3], w3);
+    }
+  }
+  // back-pointer and link stores are only read by later kernels: let them drain
+  TableBarrier<LDS>();
   KD_LAP(s, 12);
   ClearLive<LDS>(c, t, n_out);
   if (tid == 0) {
@@ -966,6 +1003,7 @@ __device__ __forceinline__ void InitCtx(FrameCtx &c, const SearchParams &p, int 
   c.q_src = ToG(p.g_log_src) + utt * 2 * gslots;
   c.q_nk = ToG(p.g_log_nk) + utt * 2 * gslots;
   c.q_ac = ToG(p.g_log_ac) + utt * 2 * gslots;
+  c.q_gr = ToG(p.g_log_gr) + utt * 2 * gslots;
   c.lattice = p.lattice != 0;
   c.simple = p.simple != 0;
   c.min_only = false;
@@ -1119,7 +1157,7 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
     }
     if (r != 0) { err |= r; break; }
     frame++;
-    __syncthreads();
+    LdsBarrier();
     if (tid < 4) s.frame_cnt[tid] = 0;
   }
 

@@ -336,7 +336,7 @@ class Batch:
         return out
 
     def phase_cycles(self):
-        out = np.zeros((self.batch, 16), np.int64)
+        out = np.zeros((self.batch, 20), np.int64)
         _check(lib().kd_batch_phase_cycles(self.h, out))
         return out
 

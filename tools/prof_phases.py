@@ -21,7 +21,8 @@ import bench  # noqa: E402
 NAMES = ['0 frame start/ll row', '1 GetCutoff', '2 prepass', '3 emit filter: items+small',
          '4 emit filter: big loop', '5 emit insert', '6 eps round setup', '7 eps filter: items+small',
          '8 eps filter: big loop', '9 eps insert', '10 resolve R1 + alloc', '11 C1 write tokens',
-         '12 R2 + links + stats', '13 clear/loop', '14 spill-mode frames', '15 aborted LDS attempts']
+         '12 stats fold + barrier', '13 clear/loop', '14 spill-mode frames', '15 aborted LDS attempts',
+         '16 R2 back-pointers', '17 link records', '18 best token + frame index', '19 -']
 
 
 def run(kind, B=None):
