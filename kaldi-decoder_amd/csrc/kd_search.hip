@@ -291,6 +291,7 @@ struct FrameCtx {
   KD_G float *q_ac, *q_gr;
   int q_cap;
   bool lattice;
+  bool replay;    // spill mode after an aborted LDS attempt: queue destinations were overwritten
   bool simple;    // SimpleDecoder semantics
   bool min_only;  // simple: first filter pass only finds the minimum total cost
 };
@@ -485,7 +486,7 @@ __device__ __forceinline__ void Insert(const FrameCtx &c, const Table<LDS> &t, i
   for (int i = q_begin + threadIdx.x; i < q_end; i += kBlock) {
     // A spill frame replays emitting entries whose destination word the aborted
     // LDS attempt already replaced by a slot: take the state from the arc again.
-    const uint32_t k = (!LDS && !EPS) ? LoadArcRec(c.p.arcs, c.q_arc[i]).next : c.q_h[i];
+    const uint32_t k = (!LDS && !EPS && c.replay) ? LoadArcRec(c.p.arcs, c.q_arc[i]).next : c.q_h[i];
     const unsigned long long nk = c.q_nk[i];
     uint32_t h = kKeyEmpty;
     // emitting entries were queued under the running cutoff: apply the final one (:211);
@@ -1007,6 +1008,7 @@ __device__ __forceinline__ void InitCtx(FrameCtx &c, const SearchParams &p, int 
   c.lattice = p.lattice != 0;
   c.simple = p.simple != 0;
   c.min_only = false;
+  c.replay = false;
   c.ll_in_lds = p.num_cols <= kVmax;
 }
 
@@ -1016,13 +1018,14 @@ __device__ __forceinline__ void InitCtx(FrameCtx &c, const SearchParams &p, int 
 __device__ __forceinline__ uint32_t FrameBackSpill(const SearchParams &p, Shared *sp, int utt,
                                                 long long base_in, int n_in, double cutoff,
                                                 int frame, int q_emit, int n_expanded,
-                                                int n_arcs) {
+                                                int n_arcs, bool replay) {
   Shared &s = *sp;
   FrameCtx c{p, s, utt};
   InitCtx(c, p, utt);
   c.base_in = base_in;
   c.n_in = n_in;
   c.cutoff = cutoff;
+  c.replay = replay;
   Counters cnt;
   cnt.tokens_expanded = n_expanded;
   cnt.arcs_scanned = n_arcs;
@@ -1125,8 +1128,10 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
     // the queue is a complete journal of the frame's inserts: a frame that does
     // not fit the LDS table is replayed from it into the global table
     if (q_emit <= c.q_cap) {
-      // a frontier this large will not fit the LDS table after expansion either
-      if (c.n_in <= kLdsFillLimit) r = FrameBack<true>(c, tl, frame, q_emit, cnt);
+      // a frontier this large, or more than two candidates per slot (the queue also
+      // holds entries the exact cutoff will drop), will not fit the LDS table
+      const bool try_lds = c.n_in <= kLdsFillLimit && q_emit <= 2 * kLdsFillLimit;
+      if (try_lds) r = FrameBack<true>(c, tl, frame, q_emit, cnt);
       if (__builtin_expect(r == 1, 0)) {
         __syncthreads();
         KD_LAP(s, 15);
@@ -1144,7 +1149,7 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
         __syncthreads();
         // (epsilon counters of the aborted closure are dropped)
         r = FrameBackSpill(p, &s, utt, c.base_in, c.n_in, c.cutoff, frame, q_emit,
-                           cnt.tokens_expanded, cnt.arcs_scanned);
+                           cnt.tokens_expanded, cnt.arcs_scanned, try_lds);
         if (r == 0) {
           c.base_in = s.base_out;
           c.n_in = p.simple ? s.n_act : s.n_live;

@@ -158,8 +158,8 @@ class Graph:
         self.device = device
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().kd_graph_destroy(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.kd_graph_destroy(self.h)
             self.h = None
 
     @property
@@ -240,8 +240,8 @@ class Batch:
                                      C.c_void_p(stream or 0), C.byref(self.h)))
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().kd_batch_destroy(self.h)
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.kd_batch_destroy(self.h)
             self.h = None
 
     def set_options(self, **opts):
