@@ -210,14 +210,18 @@ def main():
         if wl["lattice"]:
             bt.finalize_decoding()
             out = bt.raw_lattices()
-            if world > 1:
-                best = [lattice_best_path(lat) or ([], []) for lat in out]
-                sharded.gather_paths(best, dst=0)
         else:
             out = bt.best_paths()
-            if world > 1:
-                sharded.gather_paths([(p.ilabel, p.olabel) for p in out], dst=0)
         return out, k_ms
+
+    def deliver(out):
+        # the only exchange between ranks: finished results go to rank 0.  Issued by
+        # the main thread in step order so every rank runs its collectives alike.
+        if world > 1:
+            if wl["lattice"]:
+                sharded.gather_lattices(out, dst=0)
+            else:
+                sharded.gather_paths([(p.ilabel, p.olabel) for p in out], dst=0)
 
     def fence():
         if world > 1:
@@ -231,7 +235,11 @@ def main():
 
     def run_steps(n):
         futs = [pool.submit(step, bts[i % n_streams]) for i in range(n)]
-        return [f.result() for f in futs]
+        res = []
+        for f in futs:
+            res.append(f.result())
+            deliver(res[-1][0])
+        return res
 
     run_steps(max(args.warmup, n_streams if args.warmup else 0))
     fence()

@@ -32,6 +32,24 @@ def pack_paths(paths):
     return np.concatenate(parts) if parts else np.zeros(1, np.int32)
 
 
+def pack_blobs(blobs):
+    """List of int32 arrays -> [n, len_0 .. len_{n-1}, blob_0, blob_1, ...]."""
+    lens = np.asarray([len(b) for b in blobs], np.int32)
+    return np.concatenate([np.asarray([len(blobs)], np.int32), lens] +
+                          [np.asarray(b, np.int32) for b in blobs])
+
+
+def unpack_blobs(buf):
+    n = int(buf[0])
+    lens = buf[1:1 + n]
+    pos = 1 + n
+    out = []
+    for k in lens:
+        out.append(buf[pos:pos + int(k)].copy())
+        pos += int(k)
+    return out
+
+
 def unpack_paths(buf):
     n = int(buf[0])
     lens = buf[1:1 + n]
@@ -44,18 +62,36 @@ def unpack_paths(buf):
     return out
 
 
-def gather_paths(paths, dst=0, group=None):
+def lattice_blob(lat):
+    """One int32 array holding a raw lattice (cabi.RawLattice): sizes, arcs, finals."""
+    head = np.asarray([lat.num_states, len(lat.src), len(lat.final_state), lat.start], np.int32)
+    return np.concatenate([head, lat.src, lat.dst, lat.ilabel, lat.olabel,
+                           lat.graph_cost.view(np.int32), lat.ac_cost.view(np.int32),
+                           lat.state_frame, lat.state_graph, lat.final_state,
+                           lat.final_graph.view(np.int32)]).astype(np.int32, copy=False)
+
+
+def gather_lattices(lats, dst=0, group=None):
+    """Gathers every rank's pruned raw lattices to `dst` (as blobs, see lattice_blob)."""
+    blobs = [(lattice_blob(lat), np.zeros(0, np.int32)) for lat in lats]
+    # pack_paths stores two arrays of one common length per item: use the blob once
+    # and an empty second array by packing the blob as ilabel with a zero-length twin
+    return gather_paths([(b, b[:0]) for b, _ in blobs], dst=dst, group=group, _single=True)
+
+
+def gather_paths(paths, dst=0, group=None, _single=False):
     """Gathers every rank's best paths to `dst` in rank order; returns the
     concatenated list there and None elsewhere."""
     import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return list(paths)
+        return [p[0] for p in paths] if _single else list(paths)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     on_gpu = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-    payload = torch.from_numpy(pack_paths(paths)).to(dev)
+    payload = torch.from_numpy(pack_blobs([p[0] for p in paths]) if _single
+                               else pack_paths(paths)).to(dev)
     size = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
     sizes = [torch.zeros_like(size) for _ in range(world)]
     dist.all_gather(sizes, size, group=group)
@@ -68,7 +104,8 @@ def gather_paths(paths, dst=0, group=None):
         dist.gather(padded, bufs, dst=dst, group=group)
         out = []
         for r in range(world):
-            out.extend(unpack_paths(bufs[r][:sizes[r]].cpu().numpy()))
+            buf = bufs[r][:sizes[r]].cpu().numpy()
+            out.extend(unpack_blobs(buf) if _single else unpack_paths(buf))
         return out
     dist.gather(padded, None, dst=dst, group=group)
     return None

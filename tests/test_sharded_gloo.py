@@ -78,3 +78,24 @@ def test_gather_paths_world2_gloo(total):
 def test_gather_without_process_group_is_identity():
     paths = [_fake_path(3), _fake_path(4)]
     assert sharded.gather_paths(paths) == paths
+
+
+def test_blob_roundtrip_and_single_process_lattice_gather():
+    rng = np.random.default_rng(1)
+    blobs = [rng.integers(-5, 5, n).astype(np.int32) for n in (0, 3, 1000)]
+    out = sharded.unpack_blobs(sharded.pack_blobs(blobs))
+    assert [b.tolist() for b in out] == [b.tolist() for b in blobs]
+
+    class Lat:  # the fields of cabi.RawLattice that lattice_blob reads
+        num_states, start = 3, 0
+        src = np.array([0, 1], np.int32); dst = np.array([1, 2], np.int32)
+        ilabel = np.array([5, 6], np.int32); olabel = np.array([0, 9], np.int32)
+        graph_cost = np.array([0.5, 1.5], np.float32); ac_cost = np.array([2.0, 3.0], np.float32)
+        state_frame = np.array([0, 1, 2], np.int32); state_graph = np.array([7, 8, 9], np.int32)
+        final_state = np.array([2], np.int32); final_graph = np.array([0.25], np.float32)
+
+    blob = sharded.lattice_blob(Lat)
+    assert blob[:4].tolist() == [3, 2, 1, 0] and blob.dtype == np.int32
+    assert blob[4 + 8:4 + 10].view(np.float32).tolist() == [0.5, 1.5]
+    got = sharded.gather_lattices([Lat, Lat])
+    assert len(got) == 2 and got[0].tolist() == blob.tolist()
