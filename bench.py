@@ -229,16 +229,33 @@ def main():
         torch.cuda.synchronize()
 
     # Steps are independent batches; with more than one stream consecutive steps
-    # overlap (one host thread per stream; ctypes releases the GIL in the library).
+    # overlap.  One host thread per stream owns that stream's batch and runs its
+    # steps (i, i + n_streams, ...) strictly in order -- a batch is never shared
+    # between threads; ctypes releases the GIL inside the library.
+    import queue
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(n_streams)
 
+    def lane(si, n, done):
+        for i in range(si, n, n_streams):
+            try:
+                done[i].put(step(bts[si]))
+            except BaseException as e:  # hand the failure to the main thread
+                done[i].put(e)
+                raise
+
     def run_steps(n):
-        futs = [pool.submit(step, bts[i % n_streams]) for i in range(n)]
+        done = [queue.Queue(1) for _ in range(n)]
+        futs = [pool.submit(lane, si, n, done) for si in range(min(n_streams, n))]
         res = []
+        for i in range(n):
+            r = done[i].get()
+            if isinstance(r, BaseException):
+                raise r
+            res.append(r)
+            deliver(r[0])
         for f in futs:
-            res.append(f.result())
-            deliver(res[-1][0])
+            f.result()
         return res
 
     # every stream's batch gets at least two untimed steps when warmup is requested

@@ -47,6 +47,8 @@
 #include <float.h>
 #include <limits.h>
 
+#include <atomic>
+
 #include "kd_device.h"
 #include "kd_hip.h"
 
@@ -272,7 +274,13 @@ struct Table {
   }
 };
 
+// MODE selects the decoder whose arithmetic the kernel instance runs, so that
+// each instance carries only its own code and registers:
+//   0 FasterDecoder   1 LatticeSimple/LatticeFaster   2 SimpleDecoder
+template <int MODE>
 struct FrameCtx {
+  static constexpr bool lattice = MODE == 1;
+  static constexpr bool simple = MODE == 2;  // SimpleDecoder semantics
   const SearchParams &p;
   Shared &s;
   int utt;
@@ -290,17 +298,15 @@ struct FrameCtx {
   KD_G unsigned long long *q_nk;
   KD_G float *q_ac, *q_gr;
   int q_cap;
-  bool lattice;
   bool replay;    // spill mode after an aborted LDS attempt: queue destinations were overwritten
-  bool simple;    // SimpleDecoder semantics
   bool min_only;  // simple: first filter pass only finds the minimum total cost
 };
 
 // Scores one arc out of a token with cost `csrc` and queues it if it survives
 // the (running) cutoff: the reference's test at faster-decoder.cc:208-211
 // (emitting) or :90-95 (epsilon).
-template <bool EPS>
-__device__ __forceinline__ void FilterArc(const FrameCtx &c, const ArcRec &a, uint32_t aidx,
+template <bool EPS, int M>
+__device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a, uint32_t aidx,
                                           double csrc, uint32_t srcid) {
   Shared &s = c.s;
   double nc;
@@ -368,8 +374,8 @@ __device__ __forceinline__ void FilterArc(const FrameCtx &c, const ArcRec &a, ui
 // Filter phase over the input frontier (EPS=false) or over the tokens on
 // worklist `wl_in` (EPS=true).  Touches the table only to read the worklist
 // tokens' state and cost.
-template <bool LDS, bool EPS>
-__device__ __forceinline__ void Filter(const FrameCtx &c, const Table<LDS> &t, int n_items,
+template <bool LDS, bool EPS, int M>
+__device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t, int n_items,
                                        const KD_G uint32_t *wl_in, Counters &cnt) {
   constexpr bool LDS_MODE = LDS;
   (void)LDS_MODE;
@@ -478,8 +484,8 @@ __device__ __forceinline__ void Filter(const FrameCtx &c, const Table<LDS> &t, i
 // Insert phase: queue entries [q_begin, q_end), one per lane.  Relaxes the
 // destination's slot; the entry's destination word is replaced by the slot (or
 // kKeyEmpty if the entry lost to the final cutoff) for the resolve passes.
-template <bool LDS, bool EPS>
-__device__ __forceinline__ void Insert(const FrameCtx &c, const Table<LDS> &t, int q_begin,
+template <bool LDS, bool EPS, int M>
+__device__ __forceinline__ void Insert(const FrameCtx<M> &c, const Table<LDS> &t, int q_begin,
                                        int q_end, unsigned long long cutkey,
                                        KD_G uint32_t *wl_out, int wl_out_idx) {
   Shared &s = c.s;
@@ -572,7 +578,8 @@ __device__ __forceinline__ float SelectKth(Shared *sp, const double *tok_cost, l
 
 // Best cost and best token of an arena block (used for the first frame of a
 // launch; later frames get them from the previous frame's compaction).
-__device__ __forceinline__ void FrontierStats(const FrameCtx &c) {
+template <int M>
+__device__ __forceinline__ void FrontierStats(const FrameCtx<M> &c) {
   const SearchParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x;
@@ -595,7 +602,8 @@ __device__ __forceinline__ void FrontierStats(const FrameCtx &c) {
 }
 
 // GetCutoff, faster-decoder.cc:244-336, by value.
-__device__ __forceinline__ void GetCutoff(FrameCtx &c) {
+template <int M>
+__device__ __forceinline__ void GetCutoff(FrameCtx<M> &c) {
   const SearchParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x;
@@ -603,7 +611,7 @@ __device__ __forceinline__ void GetCutoff(FrameCtx &c) {
   const double beam_cutoff = best_cost + p.beam;
   if (p.max_active == INT_MAX && p.min_active == 0) {  // :249-272
     // LatticeSimpleDecoder has no cutoff on the tokens it expands (:376-401)
-    c.weight_cutoff = p.lattice ? __longlong_as_double(0x7FF0000000000000ll) : beam_cutoff;
+    c.weight_cutoff = c.lattice ? __longlong_as_double(0x7FF0000000000000ll) : beam_cutoff;
     c.adaptive_beam = p.beam;
     return;
   }
@@ -629,7 +637,7 @@ __device__ __forceinline__ void GetCutoff(FrameCtx &c) {
     return;
   }
   // the lattice decoders keep the cutoff in float
-  const double beam_cutoff_r = p.lattice ? static_cast<double>(static_cast<float>(beam_cutoff)) : beam_cutoff;
+  const double beam_cutoff_r = c.lattice ? static_cast<double>(static_cast<float>(beam_cutoff)) : beam_cutoff;
   double min_active_cutoff = beam_cutoff;  // "not looser" unless proven below
   if (c.n_in > p.min_active) {             // :311-323
     if (p.min_active == 0) min_active_cutoff = best_cost;
@@ -649,7 +657,8 @@ __device__ __forceinline__ void GetCutoff(FrameCtx &c) {
 // Everything of a frame before the table is touched: cutoff, the best token's
 // bound, and the emitting filter.  Leaves the candidates in the queue
 // [0, s.q_n) and the exact cutoff in c.cutoff.
-__device__ __forceinline__ void FrameFront(FrameCtx &c, Counters &cnt) {
+template <int M>
+__device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
   constexpr bool LDS_MODE = true;
   (void)LDS_MODE;
   const SearchParams &p = c.p;
@@ -717,8 +726,8 @@ __device__ __forceinline__ void FullClear(const Table<LDS> &t, Shared &s) {
 // Clears the slots on the live list (and any claimed-but-unlisted slot is
 // impossible: a slot is listed by whoever gives it its first cost, and every
 // claimer relaxes the slot right after claiming it).
-template <bool LDS>
-__device__ __forceinline__ void ClearLive(const FrameCtx &c, const Table<LDS> &t, int n_live) {
+template <bool LDS, int M>
+__device__ __forceinline__ void ClearLive(const FrameCtx<M> &c, const Table<LDS> &t, int n_live) {
   for (int i = threadIdx.x; i < n_live; i += kBlock) {
     const uint32_t h = c.live[i];
     t.StoreKey(h, kKeyEmpty);
@@ -732,8 +741,8 @@ __device__ __forceinline__ void ClearLive(const FrameCtx &c, const Table<LDS> &t
 // resolve back-pointers and compact.  Returns 0 on success, 1 if the table,
 // the live list or the queue overflowed (nothing committed; table dirty), or a
 // KD_UTT_* bit on a fatal capacity error.
-template <bool LDS>
-__device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, int frame,
+template <bool LDS, int M>
+__device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &t, int frame,
                                               int q_emit, Counters &cnt) {
   constexpr bool LDS_MODE = LDS;
   (void)LDS_MODE;
@@ -993,7 +1002,8 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx &c, const Table<LDS> &t, 
   return 0;
 }
 
-__device__ __forceinline__ void InitCtx(FrameCtx &c, const SearchParams &p, int utt) {
+template <int M>
+__device__ __forceinline__ void InitCtx(FrameCtx<M> &c, const SearchParams &p, int utt) {
   const long long gslots = 1ll << p.g_log2_slots;
   c.wl0 = ToG(p.g_wl) + (2ll * utt) * gslots;
   c.wl1 = ToG(p.g_wl) + (2ll * utt + 1) * gslots;
@@ -1005,8 +1015,6 @@ __device__ __forceinline__ void InitCtx(FrameCtx &c, const SearchParams &p, int 
   c.q_nk = ToG(p.g_log_nk) + utt * 2 * gslots;
   c.q_ac = ToG(p.g_log_ac) + utt * 2 * gslots;
   c.q_gr = ToG(p.g_log_gr) + utt * 2 * gslots;
-  c.lattice = p.lattice != 0;
-  c.simple = p.simple != 0;
   c.min_only = false;
   c.replay = false;
   c.ll_in_lds = p.num_cols <= kVmax;
@@ -1015,12 +1023,13 @@ __device__ __forceinline__ void InitCtx(FrameCtx &c, const SearchParams &p, int 
 // Spill path.  Inlined (a call would force the caller's state through scratch
 // memory); it sits behind an unlikely branch so block placement keeps its code
 // away from the hot path's instruction-cache lines.
+template <int M>
 __device__ __forceinline__ uint32_t FrameBackSpill(const SearchParams &p, Shared *sp, int utt,
                                                 long long base_in, int n_in, double cutoff,
                                                 int frame, int q_emit, int n_expanded,
                                                 int n_arcs, bool replay) {
   Shared &s = *sp;
-  FrameCtx c{p, s, utt};
+  FrameCtx<M> c{p, s, utt};
   InitCtx(c, p, utt);
   c.base_in = base_in;
   c.n_in = n_in;
@@ -1044,6 +1053,7 @@ __device__ __forceinline__ uint32_t FrameBackSpill(const SearchParams &p, Shared
   return r == 1 ? static_cast<uint32_t>(KD_UTT_TABLE_FULL) : r;
 }
 
+template <int M>
 __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Shared &s = *reinterpret_cast<Shared *>(smem);
@@ -1052,7 +1062,7 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
   (void)LDS_MODE;
 
   Table<true> tl{s, nullptr, nullptr, nullptr, s.bitmask, kLog2Slots, kSlots - 1};
-  FrameCtx c{p, s, utt};
+  FrameCtx<M> c{p, s, utt};
   InitCtx(c, p, utt);
 
   if (tid < KD_NUM_STATS) s.stat[tid] = 0;
@@ -1076,7 +1086,7 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
   if (tid == 0) {
     s.arena_next = p.do_init ? static_cast<long long>(utt) * static_cast<long long>(p.arena_cap)
                              : static_cast<long long>(ToG(p.arena_top)[utt]);
-    if (p.lattice)
+    if (c.lattice)
       s.link_next = p.do_init ? static_cast<long long>(utt) * static_cast<long long>(p.link_cap)
                               : static_cast<long long>(ToG(p.link_top)[utt]);
   }
@@ -1121,8 +1131,8 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
     } else {
       // faster-decoder.cc:53; the lattice decoders use best (= 0) + beam
       // (lattice-simple-decoder.cc:135-154)
-      c.cutoff = p.lattice ? static_cast<double>(0.0f + p.beam) : static_cast<double>(FLT_MAX);
-      if (p.simple) c.cutoff = 0.0 + static_cast<double>(p.beam);
+      c.cutoff = c.lattice ? static_cast<double>(0.0f + p.beam) : static_cast<double>(FLT_MAX);
+      if (c.simple) c.cutoff = 0.0 + static_cast<double>(p.beam);
     }
     uint32_t r = 1;
     // the queue is a complete journal of the frame's inserts: a frame that does
@@ -1148,11 +1158,11 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
         }
         __syncthreads();
         // (epsilon counters of the aborted closure are dropped)
-        r = FrameBackSpill(p, &s, utt, c.base_in, c.n_in, c.cutoff, frame, q_emit,
+        r = FrameBackSpill<M>(p, &s, utt, c.base_in, c.n_in, c.cutoff, frame, q_emit,
                            cnt.tokens_expanded, cnt.arcs_scanned, try_lds);
         if (r == 0) {
           c.base_in = s.base_out;
-          c.n_in = p.simple ? s.n_act : s.n_live;
+          c.n_in = c.simple ? s.n_act : s.n_live;
         }
         FullClear<true>(tl, s);
         KD_LAP(s, 14);
@@ -1171,7 +1181,7 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
     ToG(p.frames_decoded)[utt] = frame < 0 ? -1 : frame;
     ToG(p.status)[utt] = err;
     ToG(p.arena_top)[utt] = static_cast<unsigned long long>(s.arena_next);
-    if (p.lattice) ToG(p.link_top)[utt] = static_cast<unsigned long long>(s.link_next);
+    if (c.lattice) ToG(p.link_top)[utt] = static_cast<unsigned long long>(s.link_next);
   }
   if (tid < KD_NUM_STATS) {
     KD_G long long *st = ToG(p.stats) + static_cast<long long>(utt) * kStatStride;
@@ -1188,17 +1198,30 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
 
 size_t SearchLdsBytes() { return sizeof(Shared); }
 
-hipError_t LaunchSearch(const SearchParams &p, int batch, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SearchKernel),
+namespace {
+template <int M>
+hipError_t LaunchMode(const SearchParams &p, int batch, hipStream_t stream) {
+  // the opt-in to > 64 KiB of dynamic LDS is per device; remember where it was done
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SearchKernel<M>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(sizeof(Shared)));
     if (e != hipSuccess) return e;
-    attr_set = true;
+    done.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL(SearchKernel, dim3(batch), dim3(kBlock), sizeof(Shared), stream, p);
+  hipLaunchKernelGGL(SearchKernel<M>, dim3(batch), dim3(kBlock), sizeof(Shared), stream, p);
   return hipGetLastError();
+}
+}  // namespace
+
+hipError_t LaunchSearch(const SearchParams &p, int batch, hipStream_t stream) {
+  if (p.lattice) return LaunchMode<1>(p, batch, stream);
+  if (p.simple) return LaunchMode<2>(p, batch, stream);
+  return LaunchMode<0>(p, batch, stream);
 }
 
 }  // namespace kd

@@ -27,7 +27,7 @@ def one(pattern):
     hits = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
     if not hits:
         raise SystemExit(f"missing gpurun_out/{pattern}")
-    return hits[0]
+    return max(hits, key=os.path.getmtime)  # a directory may hold several runs: newest
 
 
 def counter(path, name):
