@@ -180,6 +180,7 @@ enum {
   KD_STAT_MAX_TOKENS,       /* max tokens written in one frame                 */
   KD_STAT_SPILL_FRAMES,     /* frames that fell back to the global table       */
   KD_STAT_LINKS,            /* forward links written (lattice decoders)        */
+  KD_STAT_SMALL_FRAMES,     /* frames run entirely out of LDS (frontier <= 1024) */
   KD_NUM_STATS
 };
 int kd_batch_stats(kd_batch *b, int64_t *out /* [batch][KD_NUM_STATS] */);

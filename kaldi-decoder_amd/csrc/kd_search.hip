@@ -48,6 +48,7 @@
 #include <limits.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "kd_device.h"
 #include "kd_hip.h"
@@ -55,10 +56,7 @@
 namespace kd {
 namespace {
 
-#ifndef KD_BLOCK
-#define KD_BLOCK 1024
-#endif
-constexpr int kBlock = KD_BLOCK;  // threads per utterance
+constexpr int kBlock = 1024;  // threads per utterance
 constexpr int kWaves = kBlock / 64;
 constexpr int kLog2Slots = 13;
 constexpr int kSlots = 1 << kLog2Slots;
@@ -67,14 +65,29 @@ constexpr int kLdsFillLimit = kSlots * 3 / 4;
 constexpr int kVmax = 2048;   // log-likelihood row staged in LDS when V <= kVmax
 constexpr int kSmallDeg = 4;  // tokens with at most this many arcs stay on their lane
 constexpr int kGroup = 4;     // queued tokens a wave scores at a time
+// Tier 1 (frames whose frontier is at most one token per lane -- 97% of the frames
+// of an HLG decode): the lower half of the table arrays is a 4096-slot table, the
+// upper half holds the first kQL entries of the candidate queue, and the frontier
+// itself (state, cost, arc range) stays in LDS from one frame to the next.
+constexpr int kT1Log2 = 12;
+constexpr int kT1Slots = 1 << kT1Log2;
+constexpr int kT1Front = 1024;
+constexpr int kT1Narrow = 256;  // ... of which frames up to this size run on four waves
+constexpr int kQL = 2048;
+static_assert(kBlock == 1024 && kT1Front == kBlock && kSlots == 2 * kT1Slots && 2 * kQL == kT1Slots,
+              "tier-1 LDS overlay");
 constexpr unsigned long long kCostInf = 0xFFF0000000000000ull;  // CostKey(+inf)
+// Frame results besides 0 and the KD_UTT_* bits: run the table half again in the
+// next larger table / run the whole frame again in the big path.
+constexpr uint32_t kRetry = 0x100u, kRedo = 0x200u;
 
 struct Shared {
   // token table (LDS mode); in spill mode `cost` is reused as the worklist bitmask
   unsigned long long cost[kSlots];
   uint32_t key[kSlots];
   uint32_t arc[kSlots];
-  // queue of high-degree tokens of the current chunk
+  // queue of high-degree tokens of the current chunk; between tier-1 frames the
+  // same arrays hold the frontier: cost, emitting arc range, state
   double it_cost[kBlock];
   int32_t it_abeg[kBlock];
   int32_t it_deg[kBlock];
@@ -100,6 +113,10 @@ struct Shared {
   int32_t n_act, n_inact;       // simple: tokens kept / dropped by PruneToks
   long long link_next;          // lattice: next free link of this utterance
   int32_t overflow;
+  int32_t soft_bar;             // team barrier arrivals since the launch began
+  uint32_t ctl_r;               // tier-1 frame result, for the waves that sat it out
+  int32_t ctl_q_emit;           // ... and what a replay in the big table needs
+  double ctl_cutoff;
   int32_t wl_count[2];
   int32_t it_count[2], it_next[2];
   int32_t sel_bin, sel_k;
@@ -112,10 +129,34 @@ struct Shared {
 };
 static_assert(sizeof(Shared) <= 163840, "LDS budget");
 
+// The workgroup's LDS block.  Functions that are not inlined into the kernel reach
+// it through this (an LDS pointer passed as an argument would become a flat one).
+extern __shared__ __attribute__((aligned(16))) unsigned char kd_smem[];
+__device__ __forceinline__ Shared &Lds() { return *reinterpret_cast<Shared *>(kd_smem); }
+
+// Tier-1 views of the upper table halves: candidate queue entries [0, kQL) and
+// the emitting filter's queue of high-degree frontier tokens.
+__device__ __forceinline__ unsigned long long *T1QNk(Shared &s) { return &s.cost[kT1Slots]; }
+__device__ __forceinline__ float *T1QAc(Shared &s) { return reinterpret_cast<float *>(&s.cost[kT1Slots + kQL]); }
+__device__ __forceinline__ float *T1QGr(Shared &s) { return reinterpret_cast<float *>(&s.cost[kT1Slots + kQL]) + kQL; }
+__device__ __forceinline__ uint32_t *T1QH(Shared &s) { return &s.key[kT1Slots]; }
+__device__ __forceinline__ uint32_t *T1QArc(Shared &s) { return &s.key[kT1Slots + kQL]; }
+__device__ __forceinline__ uint32_t *T1QSrc(Shared &s) { return &s.arc[kT1Slots]; }
+// ... the live list (slots holding a token, in arena order) and the filter's work items
+constexpr int kT1Items = 512;
+constexpr uint32_t kNullItem = 0xFFFFFFFFu;
+__device__ __forceinline__ uint16_t *T1Live(Shared &s) { return reinterpret_cast<uint16_t *>(&s.arc[kT1Slots + kQL]); }
+__device__ __forceinline__ uint32_t *T1Items(Shared &s) { return &s.arc[kSlots - kT1Items]; }
+static_assert(2 * (kT1Slots * 3 / 4) + 4 * kT1Items <= 4 * kQL, "tier-1 spare region");
+
+
 // Pointers that arrive inside the by-value parameter struct are generic
 // ("flat") to the compiler; casting them to the global address space at the use
 // site turns flat_load/flat_atomic into global_load/global_atomic.
 #define KD_G __attribute__((address_space(1)))
+// The launch parameters are read in place from the kernel-argument segment
+// (constant address space: scalar loads on demand, no copy held in registers).
+typedef const __attribute__((address_space(4))) SearchParams CParams;
 template <class T>
 __device__ __forceinline__ KD_G T *ToG(T *p) { return (KD_G T *)p; }
 template <class T>
@@ -144,12 +185,19 @@ struct Counters {
 // Diagnostic build only (make prof): a lap timer on lane 0.  KD_LAP(s, i) adds
 // the shader-clock cycles since the previous lap to bucket i.  The shipping
 // build executes no stamps.
+// -DKD_PROF_T1 details the LDS-resident small frames and lumps the others into
+// bucket 14; the default details the others and lumps the small frames into 19.
+#ifdef KD_PROF_T1
+constexpr int kBucketSmall = -1, kBucketBig = 14;
+#else
+constexpr int kBucketSmall = 19, kBucketBig = -1;
+#endif
 #ifdef KD_PROFILE
 #define KD_LAP(s, i)                                                              \
   do {                                                                            \
     if (threadIdx.x == 0) {                                                       \
       const long long now_ = static_cast<long long>(__builtin_amdgcn_s_memtime()); \
-      (s).cyc[(LDS_MODE) ? (i) : 14] += now_ - (s).lap_last;                      \
+      (s).cyc[KD_BUCKET < 0 ? (i) : KD_BUCKET] += now_ - (s).lap_last;                       \
       (s).lap_last = now_;                                                        \
     }                                                                             \
   } while (0)
@@ -171,6 +219,29 @@ template <bool LDS>
 __device__ __forceinline__ void TableBarrier() {
   if constexpr (LDS) LdsBarrier(); else __syncthreads();
 }
+
+// The threads that run a phase: the whole workgroup (hardware barrier), or its
+// first waves only (a counter in LDS; the rest of the workgroup is parked at the
+// frame-end barrier, so s_barrier is not available to the team).
+struct Team {
+  int nt;    // threads tid < nt take part; a multiple of 64
+  int &gen;  // this wave's count of team barriers passed (small teams)
+  // LDS traffic only, or (with_global) global stores too
+  __device__ __forceinline__ void Sync(bool with_global) const {
+    if (nt == kBlock) {
+      if (with_global) __syncthreads(); else LdsBarrier();
+      return;
+    }
+    Shared &s = Lds();
+    if (with_global) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    gen += nt >> 6;
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s.soft_bar, 1);
+    while (__hip_atomic_load(&s.soft_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - gen < 0)
+      __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  }
+};
 
 // ---- block-wide primitives (wave64 shuffles + one LDS hop) -----------------
 // Sum over the wave.  (An atomicAdd of a per-lane value makes hipcc serialise the
@@ -248,7 +319,7 @@ struct Table {
     return (state * 2654435761u) >> (32 - log2_slots);
   }
   __device__ __forceinline__ uint32_t FillLimit() const {
-    return LDS ? kLdsFillLimit : (3u << (log2_slots - 2));
+    return 3u << (log2_slots - 2);
   }
 
   // Finds or claims the slot of `k` (state | has-eps flag); kKeyEmpty if the
@@ -281,7 +352,7 @@ template <int MODE>
 struct FrameCtx {
   static constexpr bool lattice = MODE == 1;
   static constexpr bool simple = MODE == 2;  // SimpleDecoder semantics
-  const SearchParams &p;
+  CParams &p;
   Shared &s;
   int utt;
   long long base_in;
@@ -305,7 +376,7 @@ struct FrameCtx {
 // Scores one arc out of a token with cost `csrc` and queues it if it survives
 // the (running) cutoff: the reference's test at faster-decoder.cc:208-211
 // (emitting) or :90-95 (epsilon).
-template <bool EPS, int M>
+template <bool EPS, bool T1 = false, int M>
 __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a, uint32_t aidx,
                                           double csrc, uint32_t srcid) {
   Shared &s = c.s;
@@ -357,7 +428,14 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
   if (keep) {
     const unsigned long long nk = CostKey(nc);
     const int pos = atomicAdd(&s.q_n, 1);
-    if (pos < c.q_cap) {
+    if (T1 && pos < kQL) {
+      T1QH(s)[pos] = a.next;
+      T1QArc(s)[pos] = aidx;
+      T1QSrc(s)[pos] = srcid;
+      T1QNk(s)[pos] = nk;
+      T1QAc(s)[pos] = aux;
+      if (c.lattice) T1QGr(s)[pos] = a.weight;
+    } else if (pos < c.q_cap) {
       c.q_h[pos] = a.next;
       c.q_arc[pos] = aidx;
       c.q_src[pos] = srcid;
@@ -371,15 +449,71 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
   }
 }
 
+// High-degree tokens queued by a filter pass: a wave takes kGroup of them at a
+// time, lanes over consecutive arcs; the first 64 arcs of all kGroup tokens are
+// loaded before any is scored so their latencies overlap.  `range(q, abeg, deg)`
+// and `source(q, cost, srcid)` describe queue item q.
+template <bool EPS, bool T1, int M, class Range, class Source>
+__device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int par, int nq, Range range,
+                                        Source source) {
+  CParams &p = c.p;
+  Shared &s = c.s;
+  const int lane = threadIdx.x & 63;
+  while (true) {
+    int q0 = 0;
+    if (lane == 0) q0 = atomicAdd(&s.it_next[par], kGroup);
+    q0 = __builtin_amdgcn_readfirstlane(q0);
+    if (q0 >= nq) break;
+    ArcRec ar[kGroup];
+    int abeg[kGroup], deg[kGroup];
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g) {
+      deg[g] = 0;
+      abeg[g] = 0;
+      if (q0 + g < nq) {
+        range(q0 + g, abeg[g], deg[g]);
+        if (lane < deg[g]) ar[g] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg[g] + lane));
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g)
+      if (lane < deg[g]) {
+        double cst;
+        uint32_t srcid;
+        source(q0 + g, cst, srcid);
+        FilterArc<EPS, T1>(c, ar[g], static_cast<uint32_t>(abeg[g] + lane), cst, srcid);
+      }
+    // tails of tokens with more than 64 arcs, four wave-rows in flight
+#pragma unroll 1
+    for (int g = 0; g < kGroup; ++g) {
+      if (deg[g] <= 64) continue;
+      double cst;
+      uint32_t srcid;
+      source(q0 + g, cst, srcid);
+      for (int a0 = 64 + lane; a0 < deg[g]; a0 += 256) {
+        ArcRec tr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (a0 + 64 * u < deg[g])
+            tr[u] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg[g] + a0 + 64 * u));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (a0 + 64 * u < deg[g])
+            FilterArc<EPS, T1>(c, tr[u], static_cast<uint32_t>(abeg[g] + a0 + 64 * u), cst, srcid);
+      }
+    }
+  }
+}
+
 // Filter phase over the input frontier (EPS=false) or over the tokens on
 // worklist `wl_in` (EPS=true).  Touches the table only to read the worklist
 // tokens' state and cost.
 template <bool LDS, bool EPS, int M>
 __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t, int n_items,
                                        const KD_G uint32_t *wl_in, Counters &cnt) {
-  constexpr bool LDS_MODE = LDS;
-  (void)LDS_MODE;
-  const SearchParams &p = c.p;
+  constexpr int KD_BUCKET = LDS ? kBucketBig : 14;
+  (void)KD_BUCKET;
+  CParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x, lane = tid & 63;
   int par = 0;
@@ -431,50 +565,13 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
     KD_LAP(s, EPS ? 7 : 3);
     const int nq = s.it_count[par];
     if (tid == 0) { s.it_count[par ^ 1] = 0; s.it_next[par ^ 1] = 0; }
-    // high-degree tokens: a wave takes kGroup of them at a time, lanes over
-    // consecutive arcs; the first 64 arcs of all kGroup tokens are loaded
-    // before any is scored so their latencies overlap
-    while (true) {
-      int q0 = 0;
-      if (lane == 0) q0 = atomicAdd(&s.it_next[par], kGroup);
-      q0 = __builtin_amdgcn_readfirstlane(q0);
-      if (q0 >= nq) break;
-      ArcRec ar[kGroup];
-      int abeg[kGroup], deg[kGroup];
-#pragma unroll
-      for (int g = 0; g < kGroup; ++g) {
-        deg[g] = 0;
-        abeg[g] = 0;
-        if (q0 + g < nq) {
-          abeg[g] = s.it_abeg[q0 + g];
-          deg[g] = s.it_deg[q0 + g];
-          if (lane < deg[g]) ar[g] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg[g] + lane));
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < kGroup; ++g)
-        if (lane < deg[g])
-          FilterArc<EPS>(c, ar[g], static_cast<uint32_t>(abeg[g] + lane), s.it_cost[q0 + g],
-                         s.it_src[q0 + g]);
-      // tails of tokens with more than 64 arcs, four wave-rows in flight
-#pragma unroll 1
-      for (int g = 0; g < kGroup; ++g) {
-        if (deg[g] <= 64) continue;
-        const double cst = s.it_cost[q0 + g];
-        const uint32_t srcid = s.it_src[q0 + g];
-        for (int a0 = 64 + lane; a0 < deg[g]; a0 += 256) {
-          ArcRec tr[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (a0 + 64 * u < deg[g])
-              tr[u] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg[g] + a0 + 64 * u));
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (a0 + 64 * u < deg[g])
-              FilterArc<EPS>(c, tr[u], static_cast<uint32_t>(abeg[g] + a0 + 64 * u), cst, srcid);
-        }
-      }
-    }
+    BigLoop<EPS, false>(c, par, nq, [&](int q, int &abeg, int &deg) {
+      abeg = s.it_abeg[q];
+      deg = s.it_deg[q];
+    }, [&](int q, double &cst, uint32_t &srcid) {
+      cst = s.it_cost[q];
+      srcid = s.it_src[q];
+    });
     if (chunk + kBlock < n_items) LdsBarrier();  // it_* arrays are reused by the next chunk
     KD_LAP(s, EPS ? 8 : 4);
   }
@@ -490,9 +587,9 @@ __device__ __forceinline__ void Insert(const FrameCtx<M> &c, const Table<LDS> &t
                                        KD_G uint32_t *wl_out, int wl_out_idx) {
   Shared &s = c.s;
   for (int i = q_begin + threadIdx.x; i < q_end; i += kBlock) {
-    // A spill frame replays emitting entries whose destination word the aborted
-    // LDS attempt already replaced by a slot: take the state from the arc again.
-    const uint32_t k = (!LDS && !EPS && c.replay) ? LoadArcRec(c.p.arcs, c.q_arc[i]).next : c.q_h[i];
+    // A retry in a larger table replays emitting entries whose destination word the
+    // aborted attempt already replaced by a slot: take the state from the arc again.
+    const uint32_t k = (!EPS && c.replay) ? LoadArcRec(c.p.arcs, c.q_arc[i]).next : c.q_h[i];
     const unsigned long long nk = c.q_nk[i];
     uint32_t h = kKeyEmpty;
     // emitting entries were queued under the running cutoff: apply the final one (:211);
@@ -535,20 +632,22 @@ __device__ __forceinline__ void Insert(const FrameCtx<M> &c, const Table<LDS> &t
 // byte-wise radix select on order-preserving keys (std::nth_element in
 // faster-decoder.cc:298-321; tmp_array_ is std::vector<float>, :278).
 // Rare (only when max_active / min_active bind).
+template <bool FRONT_LDS>
 __device__ __forceinline__ float SelectKth(Shared *sp, const double *tok_cost, long long base_in,
-                                        int n_in, int k) {
+                                        int n_in, int k, const Team &tm) {
   Shared &s = *sp;
   const int tid = threadIdx.x, lane = tid & 63;
   uint32_t prefix = 0, pmask = 0;
   int kk = k;
   for (int shift = 24; shift >= 0; shift -= 8) {
     if (tid < 256) s.hist[tid] = 0;
-    __syncthreads();
-    for (int i = tid; i < n_in; i += kBlock) {
-      const uint32_t key = FloatKey(static_cast<float>(ToG(tok_cost)[base_in + i]));
+    tm.Sync(false);
+    for (int i = tid; i < n_in; i += tm.nt) {
+      const uint32_t key =
+          FloatKey(static_cast<float>(FRONT_LDS ? s.it_cost[i] : ToG(tok_cost)[base_in + i]));
       if ((key & pmask) == prefix) atomicAdd(&s.hist[(key >> shift) & 255], 1);
     }
-    __syncthreads();
+    tm.Sync(false);
     if (tid < 64) {
       const int c0 = s.hist[4 * lane], c1 = s.hist[4 * lane + 1], c2 = s.hist[4 * lane + 2],
                 c3 = s.hist[4 * lane + 3];
@@ -567,11 +666,11 @@ __device__ __forceinline__ float SelectKth(Shared *sp, const double *tok_cost, l
         s.sel_k = r;
       }
     }
-    __syncthreads();
+    tm.Sync(false);
     prefix |= static_cast<uint32_t>(s.sel_bin) << shift;
     pmask |= 255u << shift;
     kk = s.sel_k;
-    __syncthreads();
+    tm.Sync(false);
   }
   return KeyFloat(prefix);
 }
@@ -580,7 +679,7 @@ __device__ __forceinline__ float SelectKth(Shared *sp, const double *tok_cost, l
 // launch; later frames get them from the previous frame's compaction).
 template <int M>
 __device__ __forceinline__ void FrontierStats(const FrameCtx<M> &c) {
-  const SearchParams &p = c.p;
+  CParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x;
   unsigned long long mk = kCostDead;
@@ -602,9 +701,9 @@ __device__ __forceinline__ void FrontierStats(const FrameCtx<M> &c) {
 }
 
 // GetCutoff, faster-decoder.cc:244-336, by value.
-template <int M>
-__device__ __forceinline__ void GetCutoff(FrameCtx<M> &c) {
-  const SearchParams &p = c.p;
+template <bool FRONT_LDS, int M>
+__device__ __forceinline__ void GetCutoff(FrameCtx<M> &c, const Team &tm) {
+  CParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x;
   const double best_cost = KeyCost(s.f_best);
@@ -616,8 +715,9 @@ __device__ __forceinline__ void GetCutoff(FrameCtx<M> &c) {
     return;
   }
   int lt = 0, le = 0;
-  for (int i = tid; i < c.n_in; i += kBlock) {
-    const double v = static_cast<float>(ToG(p.tok_cost)[c.base_in + i]);  // narrowed, :278
+  for (int i = tid; i < c.n_in; i += tm.nt) {
+    const double v =  // narrowed, :278
+        static_cast<float>(FRONT_LDS ? s.it_cost[i] : ToG(p.tok_cost)[c.base_in + i]);
     lt += v < beam_cutoff;
     le += v <= beam_cutoff;
   }
@@ -627,11 +727,11 @@ __device__ __forceinline__ void GetCutoff(FrameCtx<M> &c) {
     if (lt) atomicAdd(&s.f_nlt, lt);
     if (le) atomicAdd(&s.f_nle, le);
   }
-  LdsBarrier();
+  tm.Sync(false);
   const int n_lt = s.f_nlt, n_le = s.f_nle;
   // tmp_array_[k] < x  <=>  #{v < x} >= k+1 ;  tmp_array_[k] > x  <=>  #{v <= x} <= k
   if (c.n_in > p.max_active && static_cast<long long>(n_lt) >= static_cast<long long>(p.max_active) + 1) {
-    const double max_active_cutoff = SelectKth(&s, p.tok_cost, c.base_in, c.n_in, p.max_active);  // :297-309
+    const double max_active_cutoff = SelectKth<FRONT_LDS>(&s, p.tok_cost, c.base_in, c.n_in, p.max_active, tm);  // :297-309
     c.adaptive_beam = max_active_cutoff - best_cost + p.beam_delta;
     c.weight_cutoff = max_active_cutoff;
     return;
@@ -641,7 +741,7 @@ __device__ __forceinline__ void GetCutoff(FrameCtx<M> &c) {
   double min_active_cutoff = beam_cutoff;  // "not looser" unless proven below
   if (c.n_in > p.min_active) {             // :311-323
     if (p.min_active == 0) min_active_cutoff = best_cost;
-    else if (n_le <= p.min_active) min_active_cutoff = SelectKth(&s, p.tok_cost, c.base_in, c.n_in, p.min_active);
+    else if (n_le <= p.min_active) min_active_cutoff = SelectKth<FRONT_LDS>(&s, p.tok_cost, c.base_in, c.n_in, p.min_active, tm);
   } else {
     min_active_cutoff = __longlong_as_double(0x7FF0000000000000ll);
   }
@@ -659,9 +759,9 @@ __device__ __forceinline__ void GetCutoff(FrameCtx<M> &c) {
 // [0, s.q_n) and the exact cutoff in c.cutoff.
 template <int M>
 __device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
-  constexpr bool LDS_MODE = true;
-  (void)LDS_MODE;
-  const SearchParams &p = c.p;
+  constexpr int KD_BUCKET = kBucketBig;
+  (void)KD_BUCKET;
+  CParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x;
   if (c.simple) {
@@ -669,7 +769,8 @@ __device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
     c.weight_cutoff = __longlong_as_double(0x7FF0000000000000ll);
     c.adaptive_beam = p.beam;
   } else {
-    GetCutoff(c);
+    int whole_gen = 0;
+    GetCutoff<false>(c, Team{kBlock, whole_gen});
   }
   KD_LAP(s, 1);
   // Bound the next cutoff from the best token's arcs first (:176-189); it only
@@ -694,11 +795,21 @@ __device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
   Table<true> none{s, nullptr, nullptr, nullptr, nullptr, 0, 0};
   // SimpleDecoder: a first pass only finds min total cost, the second queues what
   // is below min + beam (simple-decoder.cc:170-176 at the cutoff's final value)
-  for (int pass = c.simple ? 0 : 1; pass < 2; ++pass) {
+#pragma unroll 1
+  for (int pass = c.simple ? 0 : 1; pass < 3; ++pass) {
     c.min_only = pass == 0;
     if (pass == 1 && c.simple) {
       c.cutoff = KeyCost(s.min_new) + static_cast<double>(p.beam);
       cnt = Counters();
+    }
+    if (pass == 2) {
+      // The queue overflowed under the running cutoff.  The minimum is final now,
+      // so one more scan queues exactly the arcs below the final cutoff.
+      if (c.simple || s.q_n <= c.q_cap) break;
+      __syncthreads();
+      if (tid == 0) s.q_n = 0;
+      cnt = Counters();
+      __syncthreads();
     }
     Filter<true, false>(c, none, c.n_in, nullptr, cnt);
   }
@@ -744,9 +855,9 @@ __device__ __forceinline__ void ClearLive(const FrameCtx<M> &c, const Table<LDS>
 template <bool LDS, int M>
 __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &t, int frame,
                                               int q_emit, Counters &cnt) {
-  constexpr bool LDS_MODE = LDS;
-  (void)LDS_MODE;
-  const SearchParams &p = c.p;
+  constexpr int KD_BUCKET = LDS ? kBucketBig : 14;
+  (void)KD_BUCKET;
+  CParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x;
   // simple mode queued exactly what is below the cutoff (on the total cost)
@@ -768,7 +879,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
   }
   __syncthreads();
   KD_LAP(s, 5);
-  if (s.overflow) return 1;
+  if (s.overflow) return kRetry;
   if (c.simple)  // ProcessNonemitting: best stored cost + beam (simple-decoder.cc:199-205)
     c.cutoff = (frame < 0 ? 0.0 : KeyCost(s.min_stored)) + static_cast<double>(p.beam);
 
@@ -785,11 +896,11 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
     KD_LAP(s, 6);
     Filter<LDS, true>(c, t, n_items, wl_a, cnt);
     const int q_end = s.q_n;
-    if (q_end > c.q_cap) return 1;
+    if (q_end > c.q_cap) return kRetry;
     Insert<LDS, true>(c, t, q_begin, q_end, 0, wl_b, cur ^ 1);
     __syncthreads();
     KD_LAP(s, 9);
-    if (s.overflow) return 1;
+    if (s.overflow) return kRetry;
     q_begin = q_end;
     cur ^= 1;
     KD_G uint32_t *tmp = wl_a;
@@ -1002,8 +1113,404 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
   return 0;
 }
 
+// ---- tier 1 ------------------------------------------------------------------
+// A frame whose frontier is at most kT1Front tokens.  The frontier is in LDS
+// (it_cost / it_abeg / it_deg / it_src, left there by the previous frame's
+// compaction), the table is the 4096-slot lower half of the table arrays, the
+// first kQL queue entries, the live list and the work items are in the upper
+// half, and epsilon worklists are slot bitmasks -- so the only global reads of the
+// frame are the arcs (and the state records of tokens with epsilon arcs).
+//
+// Such a frame is bound by instruction issue, not by memory: sixteen waves that
+// mostly step over empty loops still share four SIMDs.  A frame of at most
+// kT1Narrow tokens is therefore run by a team of four waves (one per SIMD) that
+// synchronise through an LDS counter while the other twelve wait at the
+// frame-end barrier; larger ones use the whole workgroup.
+//
+// Same results as FrameFront + FrameBack<true>.  Returns 0, 1 (does not fit:
+// the caller replays the queue in the big table), 2 (the queue overflowed: the
+// caller runs the whole frame in the big path) or a fatal KD_UTT_* bit; the new
+// frontier is described by s.base_out / s.n_live.
 template <int M>
-__device__ __forceinline__ void InitCtx(FrameCtx<M> &c, const SearchParams &p, int utt) {
+__device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true> &t, int frame,
+                                               Counters &cnt, const Team &tm) {
+  constexpr int KD_BUCKET = kBucketSmall;
+  (void)KD_BUCKET;
+  CParams &p = c.p;
+  Shared &s = c.s;
+  const int tid = threadIdx.x, lane = tid & 63, nt = tm.nt;
+  const int n_in = c.n_in;
+  uint32_t *wlmask = s.bitmask;  // two masks of kT1Slots bits
+  constexpr int kMaskWords = kT1Slots / 32;
+
+  auto q_h = [&](int i) -> uint32_t { return i < kQL ? T1QH(s)[i] : c.q_h[i]; };
+  auto q_nk = [&](int i) -> unsigned long long { return i < kQL ? T1QNk(s)[i] : c.q_nk[i]; };
+  auto q_arc = [&](int i) -> uint32_t { return i < kQL ? T1QArc(s)[i] : c.q_arc[i]; };
+  auto q_src = [&](int i) -> uint32_t { return i < kQL ? T1QSrc(s)[i] : c.q_src[i]; };
+  auto q_ac = [&](int i) -> float { return i < kQL ? T1QAc(s)[i] : c.q_ac[i]; };
+  auto q_gr = [&](int i) -> float { return i < kQL ? T1QGr(s)[i] : c.q_gr[i]; };
+  // queue entries past kQL are in global memory: their stores must have landed
+  auto queue_sync = [&]() {
+    tm.Sync(false);
+    if (s.q_n > kQL) tm.Sync(true);
+  };
+  // Scores the arcs [abeg, abeg + deg) of one token on this lane, kSmallDeg loads in flight.
+  auto lane_arcs = [&](auto eps_tag, int abeg, int deg, double cst, uint32_t srcid) {
+    constexpr bool EPS = decltype(eps_tag)::value;
+    for (int a0 = 0; a0 < deg; a0 += kSmallDeg) {
+      ArcRec ar[kSmallDeg];
+#pragma unroll
+      for (int a = 0; a < kSmallDeg; ++a)
+        if (a0 + a < deg) ar[a] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg + a0 + a));
+#pragma unroll
+      for (int a = 0; a < kSmallDeg; ++a)
+        if (a0 + a < deg)
+          FilterArc<EPS, true>(c, ar[a], static_cast<uint32_t>(abeg + a0 + a), cst, srcid);
+    }
+  };
+  // A token with more than kSmallDeg arcs becomes work items of 64 consecutive arcs
+  // (token reference, chunk); returns false if the item list is full.
+  auto push_items = [&](int ref, int deg) -> bool {
+    const int n = (deg + 63) >> 6;
+    const int at = atomicAdd(&s.it_count[0], n);
+    if (at + n > kT1Items) {  // no room: void the part of the reservation inside the list
+      for (int k = at; k < kT1Items; ++k) T1Items(s)[k] = kNullItem;
+      return false;
+    }
+    for (int k = 0; k < n; ++k) T1Items(s)[at + k] = static_cast<uint32_t>(ref) << 16 | k;
+    return true;
+  };
+  // Work items: a wave takes kGroup at a time, lanes over the item's arcs.
+  auto item_loop = [&](auto eps_tag) {
+    constexpr bool EPS = decltype(eps_tag)::value;
+    const int nq = s.it_count[0] < kT1Items ? s.it_count[0] : kT1Items;
+    while (true) {
+      int q0 = 0;
+      if (lane == 0) q0 = atomicAdd(&s.it_next[0], kGroup);
+      q0 = __builtin_amdgcn_readfirstlane(q0);
+      if (q0 >= nq) break;
+      ArcRec ar[kGroup];
+      int aidx[kGroup], ref[kGroup];
+      bool on[kGroup];
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g) {
+        on[g] = false;
+        const uint32_t it = q0 + g < nq ? T1Items(s)[q0 + g] : kNullItem;
+        if (it != kNullItem) {
+          ref[g] = static_cast<int>(it >> 16);
+          const int off = static_cast<int>(it & 0xFFFFu) * 64 + lane;
+          on[g] = off < s.it_deg[ref[g]];
+          aidx[g] = s.it_abeg[ref[g]] + off;
+          if (on[g]) ar[g] = LoadArcRec(p.arcs, static_cast<uint32_t>(aidx[g]));
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g)
+        if (on[g])
+          FilterArc<EPS, true>(c, ar[g], static_cast<uint32_t>(aidx[g]), s.it_cost[ref[g]],
+                               EPS ? s.it_src[ref[g]] : static_cast<uint32_t>(ref[g]));
+    }
+  };
+  using EpsNo = std::false_type;
+  using EpsYes = std::true_type;
+
+  if (tid < kMaskWords) wlmask[tid] = 0;  // worklist 0 collects the emitting insert's tokens
+  GetCutoff<true>(c, tm);
+  KD_LAP(s, 1);
+
+  // ---- emitting filter over the LDS frontier (faster-decoder.cc:195-236)
+  for (int i = tid; i < n_in; i += nt) {
+    const double cst = s.it_cost[i];
+    if (!(cst < c.weight_cutoff)) continue;  // :202
+    const int abeg = s.it_abeg[i], deg = s.it_deg[i];
+    cnt.tokens_expanded += 1;
+    cnt.arcs_scanned += deg;
+    if (deg <= kSmallDeg || !push_items(i, deg))
+      lane_arcs(EpsNo{}, abeg, deg, cst, static_cast<uint32_t>(i));
+  }
+  tm.Sync(false);
+  KD_LAP(s, 3);
+  item_loop(EpsNo{});
+  queue_sync();
+  KD_LAP(s, 4);
+  const int q_emit = s.q_n;
+  if (c.lattice)  // float, lattice-simple-decoder.cc:388-390
+    c.cutoff = static_cast<float>(KeyCost(s.min_new)) + c.adaptive_beam;
+  else
+    c.cutoff = KeyCost(s.min_new) + static_cast<double>(c.adaptive_beam);  // value of :240
+  if (tid == 0) {  // what a replay in the big table needs
+    s.ctl_q_emit = q_emit;
+    s.ctl_cutoff = c.cutoff;
+  }
+  if (q_emit > c.q_cap) return kRedo;  // the big path scans again under the final cutoff
+  const unsigned long long cutkey = CostKey(c.cutoff);
+
+  // Insert queue entries [b, e): claim + relax; a token that is new, or (epsilon
+  // rounds) improved, and has epsilon arcs is flagged in worklist mask `out`.
+  auto insert = [&](auto eps_tag, int b, int e, int out) {
+    constexpr bool EPS = decltype(eps_tag)::value;
+    for (int i = b + tid; i < e; i += nt) {
+      const uint32_t k = q_h(i);
+      const unsigned long long nk = q_nk(i);
+      uint32_t h = kKeyEmpty;
+      if ((EPS || nk < cutkey) && !s.overflow) {
+        h = t.Claim(k);
+        if (h == kKeyEmpty) {
+          s.overflow = 1;
+        } else {
+          const unsigned long long old = atomicMin(&s.cost[h], nk);
+          bool push = false;
+          if (old == kCostDead) {  // the state's first token this frame
+            const int pos = atomicAdd(&s.n_live, 1);
+            if (pos < static_cast<int>(t.FillLimit())) T1Live(s)[pos] = static_cast<uint16_t>(h);
+            else s.overflow = 1;
+            push = (k & kHasEps) != 0;  // every new token is expanded once (:63-65)
+          } else if (EPS && old > nk && (k & kHasEps)) {  // re-queue on improvement, :97-113
+            push = true;
+          }
+          if (push) {
+            atomicOr(&wlmask[out * kMaskWords + (h >> 5)], 1u << (h & 31));
+            s.wl_count[out] = 1;
+          }
+          if (!EPS && c.lattice) atomicAdd(&s.n_emit_links, 1);
+        }
+      }
+      if (i < kQL) T1QH(s)[i] = h; else c.q_h[i] = h;
+    }
+  };
+
+  insert(EpsNo{}, 0, q_emit, 0);
+  tm.Sync(false);
+  KD_LAP(s, 5);
+  if (s.overflow) return kRetry;
+
+  // ---- ProcessNonemitting to a fixpoint (:59-119)
+  int cur = 0, q_begin = q_emit;
+  while (s.wl_count[cur] != 0) {
+    if (tid < kMaskWords) wlmask[(cur ^ 1) * kMaskWords + tid] = 0;
+    if (tid == 0) { s.wl_count[cur ^ 1] = 0; s.it_count[0] = 0; s.it_next[0] = 0; s.it_count[1] = 0; }
+    tm.Sync(false);
+    KD_LAP(s, 6);
+    // every team thread scans its share of the worklist mask, 16 slots at a time
+    for (int w16 = tid; w16 < kT1Slots / 16; w16 += nt) {
+      uint32_t m = (wlmask[cur * kMaskWords + (w16 >> 1)] >> ((w16 & 1) * 16)) & 0xFFFFu;
+      while (m) {
+        const int bit = __builtin_ctz(m);
+        m &= m - 1;
+        const uint32_t h = static_cast<uint32_t>(w16 * 16 + bit);
+        const double cst = KeyCost(s.cost[h]);
+        if (cst > c.cutoff) continue;  // :74
+        const StateRec r = LoadState(p.states, s.key[h] & kStateMask);
+        const int abeg = r.emit_end, deg = r.arc_end - r.emit_end;
+        cnt.eps_exp += 1;
+        cnt.eps_arcs += deg;
+        const uint32_t srcid = h | kSrcEps;
+        bool queued = false;
+        if (deg > kSmallDeg) {
+          const int q = atomicAdd(&s.it_count[1], 1);  // descriptor slot in it_*
+          if (q < kBlock) {
+            s.it_abeg[q] = abeg;
+            s.it_deg[q] = deg;
+            s.it_cost[q] = cst;
+            s.it_src[q] = srcid;
+            queued = push_items(q, deg);
+          }
+        }
+        if (!queued) lane_arcs(EpsYes{}, abeg, deg, cst, srcid);
+      }
+    }
+    tm.Sync(false);
+    KD_LAP(s, 7);
+    item_loop(EpsYes{});
+    queue_sync();
+    KD_LAP(s, 8);
+    const int q_end = s.q_n;
+    if (q_end > c.q_cap) return kRetry;
+    insert(EpsYes{}, q_begin, q_end, cur ^ 1);
+    tm.Sync(false);
+    KD_LAP(s, 9);
+    if (s.overflow) return kRetry;
+    q_begin = q_end;
+    cur ^= 1;
+  }
+
+  // ---- resolve R1: entries that hold their slot's final cost compete for the
+  // lowest arc index
+  const int n_q = q_begin;
+  const int n_out = s.n_live;
+  for (int i = tid; i < n_q; i += nt) {
+    const uint32_t h = q_h(i);
+    if (h != kKeyEmpty && s.cost[h] == q_nk(i)) atomicMin(&s.arc[h], q_arc(i));
+  }
+  long long base_out;
+  {
+    // each utterance owns arena[utt * arena_cap, (utt + 1) * arena_cap)
+    const long long b = s.arena_next;
+    const bool full =
+        b + n_out > static_cast<long long>(c.utt + 1) * static_cast<long long>(p.arena_cap);
+    base_out = full ? -1 : b;
+  }
+  if (base_out < 0) return KD_UTT_ARENA_FULL;
+  // ---- C1: live list -> token records; a slot's key word now holds its index in
+  // the block.  Each token's state record is fetched now for the next frame's filter.
+  const bool next_small = n_out <= kT1Front;
+  constexpr int kKeep = kT1Front / 256;  // tokens per thread of the smallest team
+  unsigned long long my_min = kCostDead;
+  int nb[kKeep], nd[kKeep];
+#pragma unroll
+  for (int k = 0; k < kKeep; ++k) { nb[k] = 0; nd[k] = -1; }
+  {
+    int k = 0;
+    for (int i = tid; i < n_out; i += nt, ++k) {
+      const int h = T1Live(s)[i];
+      const unsigned long long ck = s.cost[h];
+      const uint32_t st = s.key[h] & kStateMask;
+      const long long g = base_out + i;
+      ToG(p.tok_state)[g] = static_cast<int32_t>(st);
+      ToG(p.tok_cost)[g] = KeyCost(ck);
+      if (c.lattice) ToG(p.tok_extra)[g] = 0.0f;  // lattice-simple-decoder.cc:91-95
+      my_min = ck < my_min ? ck : my_min;
+      s.key[h] = static_cast<uint32_t>(i);
+      if (next_small) {
+        s.it_cost[i] = KeyCost(ck);
+        s.it_src[i] = st;
+        const StateRec r = LoadState(p.states, st);
+#pragma unroll
+        for (int kk = 0; kk < kKeep; ++kk)
+          if (kk == k) { nb[kk] = r.arc_begin; nd[kk] = r.emit_end - r.arc_begin; }
+      }
+    }
+  }
+  {
+    const unsigned long long wmin = WaveMinU64(my_min);
+    if (lane == 0 && wmin != kCostDead) atomicMin(&s.f_best_next, wmin);
+  }
+  tm.Sync(false);  // R1's arc words and the slots' index words are final
+  KD_LAP(s, 10);
+  if (tid == 0) {
+    s.base_out = base_out;
+    s.arena_next = base_out + n_out;
+  }
+  KD_LAP(s, 11);
+  // ---- R2: the winning entry of each slot writes the back-pointer
+  for (int i = tid; i < n_q; i += nt) {
+    const uint32_t h = q_h(i);
+    if (h == kKeyEmpty) continue;
+    const uint32_t aidx = q_arc(i);
+    if (s.cost[h] == q_nk(i) && s.arc[h] == aidx) {
+      const long long g = base_out + s.key[h];
+      const uint32_t sr = q_src(i);
+      const long long prev = (sr & kSrcEps) ? base_out + s.key[sr & ~kSrcEps] : c.base_in + sr;
+      ToG(p.tok_prev)[g] = static_cast<int32_t>(prev);
+      ToG(p.tok_arc)[g] = static_cast<int32_t>(aidx);
+    }
+  }
+  KD_LAP(s, 16);
+  // ---- forward links (see FrameBack)
+  if (c.lattice) {
+    const long long lbase = s.link_next;
+    const int n_emit = s.n_emit_links;
+    const bool full = lbase + n_emit + (n_q - q_emit) >
+                      static_cast<long long>(c.utt + 1) * static_cast<long long>(p.link_cap);
+    if (full) return KD_UTT_ARENA_FULL;
+    for (int i = tid; i < n_q; i += nt) {
+      const uint32_t h = q_h(i);
+      if (h == kKeyEmpty) continue;
+      const uint32_t sr = q_src(i);
+      long long at, src_tok;
+      float ac;
+      if (i < q_emit) {
+        src_tok = c.base_in + sr;
+        ac = q_ac(i);
+        at = lbase + atomicAdd(&s.n_emit_written, 1);
+      } else {
+        const uint32_t hs = sr & ~kSrcEps;
+        if (q_ac(i) != static_cast<float>(KeyCost(s.cost[hs]))) continue;
+        src_tok = base_out + s.key[hs];
+        ac = 0.0f;
+        at = lbase + n_emit + atomicAdd(&s.n_eps_links, 1);
+      }
+      ToG(p.link_src)[at] = static_cast<int32_t>(src_tok);
+      ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + s.key[h]);
+      ToG(p.link_arc)[at] = static_cast<int32_t>(q_arc(i));
+      ToG(p.link_ac)[at] = ac;
+      ToG(p.link_graph)[at] = q_gr(i);
+    }
+  }
+  KD_LAP(s, 17);
+  {
+    const int w0 = WaveSumInt(cnt.tokens_expanded), w1 = WaveSumInt(cnt.eps_exp),
+              w2 = WaveSumInt(cnt.arcs_scanned), w3 = WaveSumInt(cnt.eps_arcs);
+    if (lane == 0) {
+      if (w0) atomicAdd(&s.frame_cnt[0], w0);
+      if (w1) atomicAdd(&s.frame_cnt[1], w1);
+      if (w2) atomicAdd(&s.frame_cnt[2], w2);
+      if (w3) atomicAdd(&s.frame_cnt[3], w3);
+    }
+  }
+  tm.Sync(false);
+  KD_LAP(s, 12);
+  // ---- clear the table; publish the next frontier's arc ranges
+  {
+    int k = 0;
+    for (int i = tid; i < n_out; i += nt, ++k) {
+      const int h = T1Live(s)[i];
+      s.key[h] = kKeyEmpty;
+      s.cost[h] = kCostDead;
+      s.arc[h] = kArcNone;
+#pragma unroll
+      for (int kk = 0; kk < kKeep; ++kk)
+        if (kk == k && nd[kk] >= 0) { s.it_abeg[i] = nb[kk]; s.it_deg[i] = nd[kk]; }
+    }
+  }
+  if (tid == 0) {
+    const long long fi = static_cast<long long>(c.utt) * (p.max_frames + 1) + (frame + 1);
+    ToG(p.frame_base)[fi] = base_out;
+    ToG(p.frame_count)[fi] = n_out;
+    s.stat[KD_STAT_TOKENS_EXPANDED] += s.frame_cnt[0];
+    s.stat[KD_STAT_EPS_EXPANSIONS] += s.frame_cnt[1];
+    s.stat[KD_STAT_ARCS_SCANNED] += s.frame_cnt[2];
+    s.stat[KD_STAT_EPS_ARCS_SCANNED] += s.frame_cnt[3];
+    s.stat[KD_STAT_ARCS_KEPT] += q_emit;
+    s.stat[KD_STAT_TOKENS_OUT] += n_out;
+    if (n_out > s.stat[KD_STAT_MAX_TOKENS]) s.stat[KD_STAT_MAX_TOKENS] = n_out;
+    s.stat[KD_STAT_FRAMES] += 1;
+    s.stat[KD_STAT_SMALL_FRAMES] += 1;
+    s.stat[KD_STAT_TOKENS_IN] += n_in;
+    s.f_best = s.f_best_next;
+    if (c.lattice) {
+      const long long lbase = s.link_next;
+      const long long fb = static_cast<long long>(c.utt) * (p.max_frames + 1);
+      ToG(p.link_emit_base)[fb + frame] = lbase;
+      ToG(p.link_emit_count)[fb + frame] = s.n_emit_links;
+      ToG(p.link_eps_base)[fb + frame + 1] = lbase + s.n_emit_links;
+      ToG(p.link_eps_count)[fb + frame + 1] = s.n_eps_links;
+      s.link_next = lbase + s.n_emit_links + s.n_eps_links;
+      s.stat[KD_STAT_LINKS] += s.n_emit_links + s.n_eps_links;
+    }
+  }
+  return 0;
+}
+
+// Frontier of a tier-1 frame that follows a frame of another tier (or the start
+// of a launch): arena -> LDS.
+template <int M>
+__device__ __forceinline__ void LoadFront(const FrameCtx<M> &c, const Team &tm) {
+  CParams &p = c.p;
+  Shared &s = c.s;
+  for (int i = threadIdx.x; i < c.n_in; i += tm.nt) {
+    const uint32_t st = static_cast<uint32_t>(ToG(p.tok_state)[c.base_in + i]);
+    const StateRec r = LoadState(p.states, st);
+    s.it_cost[i] = ToG(p.tok_cost)[c.base_in + i];
+    s.it_src[i] = st;
+    s.it_abeg[i] = r.arc_begin;
+    s.it_deg[i] = r.emit_end - r.arc_begin;
+  }
+  tm.Sync(false);
+}
+
+template <int M>
+__device__ __forceinline__ void InitCtx(FrameCtx<M> &c, CParams &p, int utt) {
   const long long gslots = 1ll << p.g_log2_slots;
   c.wl0 = ToG(p.g_wl) + (2ll * utt) * gslots;
   c.wl1 = ToG(p.g_wl) + (2ll * utt + 1) * gslots;
@@ -1020,15 +1527,14 @@ __device__ __forceinline__ void InitCtx(FrameCtx<M> &c, const SearchParams &p, i
   c.ll_in_lds = p.num_cols <= kVmax;
 }
 
-// Spill path.  Inlined (a call would force the caller's state through scratch
-// memory); it sits behind an unlikely branch so block placement keeps its code
-// away from the hot path's instruction-cache lines.
+// Spill path: a function of its own, so that its registers are allocated apart
+// from the hot path's.  Everything it needs comes as scalars or from LDS.
 template <int M>
-__device__ __forceinline__ uint32_t FrameBackSpill(const SearchParams &p, Shared *sp, int utt,
-                                                long long base_in, int n_in, double cutoff,
-                                                int frame, int q_emit, int n_expanded,
-                                                int n_arcs, bool replay) {
-  Shared &s = *sp;
+__device__ __noinline__ uint32_t FrameBackSpill(CParams *pp, int utt, long long base_in, int n_in,
+                                                double cutoff, int frame, int q_emit,
+                                                int n_expanded, int n_arcs, bool replay) {
+  CParams &p = *pp;
+  Shared &s = Lds();
   FrameCtx<M> c{p, s, utt};
   InitCtx(c, p, utt);
   c.base_in = base_in;
@@ -1050,16 +1556,103 @@ __device__ __forceinline__ uint32_t FrameBackSpill(const SearchParams &p, Shared
     ClearLive<false>(c, tg, used);
   }
   __syncthreads();
-  return r == 1 ? static_cast<uint32_t>(KD_UTT_TABLE_FULL) : r;
+  return r == kRetry ? static_cast<uint32_t>(KD_UTT_TABLE_FULL) : r;
+}
+
+// Tiers 2 and 3: a frame whose frontier is larger than one token per lane, a
+// tier-1 frame that outgrew its table (flags & 1: its queue is replayed), and
+// InitDecoding (frame == -1).  Not inlined: these frames are 4% of an HLG decode
+// and must not cost the small frames registers.  The new frontier is returned in
+// LDS (base_out, n_live / n_act).
+template <int M>
+__device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long long base_in,
+                                          int n_in, double cutoff, int q_emit, int flags,
+                                          int n_expanded, int n_arcs) {
+  constexpr int KD_BUCKET = kBucketBig;
+  (void)KD_BUCKET;
+  CParams &p = *pp;
+  Shared &s = Lds();
+  const int tid = threadIdx.x;
+  const bool filtered = flags & 1, upper_dirty = flags & 2, best_stale = flags & 4;
+  Table<true> tl{s, nullptr, nullptr, nullptr, s.bitmask, kLog2Slots, kSlots - 1};
+  FrameCtx<M> c{p, s, utt};
+  InitCtx(c, p, utt);
+  c.base_in = base_in;
+  c.n_in = n_in;
+  c.cutoff = cutoff;
+  Counters cnt;
+  cnt.tokens_expanded = n_expanded;
+  cnt.arcs_scanned = n_arcs;
+  if (frame >= 0)
+    c.ll_row = ToG(ToG(p.utt)[utt].ll) +
+               static_cast<long long>(frame - ToG(p.utt)[utt].offset) * p.row_stride;
+  if (upper_dirty) {
+    __syncthreads();
+    FullClear<true>(tl, s);
+  }
+  if (filtered) {
+    if (tid == 0) {
+      s.q_n = q_emit;
+      s.n_live = 0;
+      s.overflow = 0;
+      s.wl_count[0] = 0;
+      s.wl_count[1] = 0;
+      s.n_emit_links = 0;
+      s.n_eps_links = 0;
+      s.n_emit_written = 0;
+    }
+    __syncthreads();
+  } else if (frame >= 0) {
+    if (best_stale) FrontierStats(c);
+    FrameFront(c, cnt);
+    q_emit = s.q_n;
+  } else {
+    // faster-decoder.cc:53; the lattice decoders use best (= 0) + beam
+    // (lattice-simple-decoder.cc:135-154)
+    c.cutoff = c.lattice ? static_cast<double>(0.0f + p.beam) : static_cast<double>(FLT_MAX);
+    if (c.simple) c.cutoff = 0.0 + static_cast<double>(p.beam);
+  }
+  c.replay = filtered;
+  // the queue is a complete journal of the frame's inserts: a frame that does
+  // not fit the LDS table is replayed from it into the global table
+  if (q_emit > c.q_cap) return KD_UTT_TABLE_FULL;
+  // a frontier this large, or more than two candidates per slot (the queue also
+  // holds entries the exact cutoff will drop), will not fit the LDS table
+  const bool try_lds = c.n_in <= kLdsFillLimit && q_emit <= 2 * kLdsFillLimit;
+  uint32_t r = kRetry;
+  if (try_lds) r = FrameBack<true>(c, tl, frame, q_emit, cnt);
+  if (r == kRetry) {
+    __syncthreads();
+    KD_LAP(s, 15);
+    FullClear<true>(tl, s);  // s.cost becomes the spill bitmask
+    if (tid == 0) {
+      s.q_n = q_emit;
+      s.n_live = 0;
+      s.overflow = 0;
+      s.wl_count[0] = 0;
+      s.wl_count[1] = 0;
+      s.n_emit_links = 0;
+      s.n_eps_links = 0;
+      s.n_emit_written = 0;
+    }
+    __syncthreads();
+    // (epsilon counters of the aborted closure are dropped)
+    r = FrameBackSpill<M>(pp, utt, c.base_in, c.n_in, c.cutoff, frame, q_emit,
+                          cnt.tokens_expanded, cnt.arcs_scanned, try_lds || filtered);
+    FullClear<true>(tl, s);
+    KD_LAP(s, 14);
+  }
+  return r;
 }
 
 template <int M>
-__global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Shared &s = *reinterpret_cast<Shared *>(smem);
+__global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p_by_value) {
+  Shared &s = Lds();
+  (void)p_by_value;  // the only argument: it is the kernel-argument segment
+  CParams &p = *(CParams *)__builtin_amdgcn_kernarg_segment_ptr();
   const int tid = threadIdx.x, utt = blockIdx.x;
-  constexpr bool LDS_MODE = true;
-  (void)LDS_MODE;
+  constexpr int KD_BUCKET = kBucketBig;
+  (void)KD_BUCKET;
 
   Table<true> tl{s, nullptr, nullptr, nullptr, s.bitmask, kLog2Slots, kSlots - 1};
   FrameCtx<M> c{p, s, utt};
@@ -1067,6 +1660,7 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
 
   if (tid < KD_NUM_STATS) s.stat[tid] = 0;
   if (tid < 4) s.frame_cnt[tid] = 0;
+  if (tid == 0) s.soft_bar = 0;
 #ifdef KD_PROFILE
   if (tid < kProfSlots) s.cyc[tid] = 0;
   if (tid == 0) s.lap_last = static_cast<long long>(__builtin_amdgcn_s_memtime());
@@ -1098,77 +1692,122 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p) {
   }
   __syncthreads();
 
+  // Tier bookkeeping (all workgroup-uniform): is the frontier in LDS (left there by
+  // a tier-1 frame), do the upper table halves hold tier-1 data, and is the best
+  // token's arc range (the tier-2 prepass input) out of date.
+  Table<true> t1{s, nullptr, nullptr, nullptr, s.bitmask, kT1Log2, kT1Slots - 1};
+  bool front_lds = false, upper_dirty = false, best_stale = false;
+  const int wave = tid >> 6;
+  int gen = 0;  // team barriers this wave has passed
+  // The next frame's log-likelihood row travels in registers across the frame,
+  // in the first four waves (they take part in every frame).
+  constexpr int kLlLanes = 256, kLlRegs = kVmax / kLlLanes;
+  float ll_pf[kLlRegs];
+  auto prefetch_row = [&](int f) {
+    if (!c.ll_in_lds || tid >= kLlLanes || f < 0 || f >= target) return;
+    const KD_G float *row = ToG(ud.ll) + static_cast<long long>(f - ud.offset) * p.row_stride;
+#pragma unroll
+    for (int k = 0; k < kLlRegs; ++k) {
+      const int v = tid + k * kLlLanes;
+      ll_pf[k] = v < p.num_cols ? row[v] : 0.0f;
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < kLlRegs; ++k) ll_pf[k] = 0.0f;
+  if (err == 0) prefetch_row(frame);
+
   while (err == 0 && frame < target) {
     KD_LAP(s, 13);
     Counters cnt;
-    if (tid == 0) {
-      s.min_new = kCostInf;
-      s.wl_count[0] = 0;
-      s.wl_count[1] = 0;
-      s.q_n = 0;
-      s.n_live = 0;
-      s.overflow = 0;
-      s.f_nlt = 0;
-      s.f_nle = 0;
-      s.n_emit_links = 0;
-      s.n_eps_links = 0;
-      s.n_emit_written = 0;
-      s.min_stored = kCostInf;
-      s.n_act = 0;
-      s.n_inact = 0;
-    }
-    if (frame >= 0) {
-      c.ll_row = ToG(ud.ll) + static_cast<long long>(frame - ud.offset) * p.row_stride;
-      if (c.ll_in_lds)
-        for (int v = tid; v < p.num_cols; v += kBlock) s.ll[v] = c.ll_row[v];
-    }
-    __syncthreads();
-    KD_LAP(s, 0);
-    int q_emit = 0;
-    if (frame >= 0) {
-      FrameFront(c, cnt);
-      q_emit = s.q_n;
-    } else {
-      // faster-decoder.cc:53; the lattice decoders use best (= 0) + beam
-      // (lattice-simple-decoder.cc:135-154)
-      c.cutoff = c.lattice ? static_cast<double>(0.0f + p.beam) : static_cast<double>(FLT_MAX);
-      if (c.simple) c.cutoff = 0.0 + static_cast<double>(p.beam);
-    }
-    uint32_t r = 1;
-    // the queue is a complete journal of the frame's inserts: a frame that does
-    // not fit the LDS table is replayed from it into the global table
-    if (q_emit <= c.q_cap) {
-      // a frontier this large, or more than two candidates per slot (the queue also
-      // holds entries the exact cutoff will drop), will not fit the LDS table
-      const bool try_lds = c.n_in <= kLdsFillLimit && q_emit <= 2 * kLdsFillLimit;
-      if (try_lds) r = FrameBack<true>(c, tl, frame, q_emit, cnt);
-      if (__builtin_expect(r == 1, 0)) {
-        __syncthreads();
-        KD_LAP(s, 15);
-        FullClear<true>(tl, s);  // s.cost becomes the spill bitmask
-        if (tid == 0) {
-          s.q_n = q_emit;
-          s.n_live = 0;
-          s.overflow = 0;
-          s.wl_count[0] = 0;
-          s.wl_count[1] = 0;
-          s.n_emit_links = 0;
-          s.n_eps_links = 0;
-          s.n_emit_written = 0;
-        }
-        __syncthreads();
-        // (epsilon counters of the aborted closure are dropped)
-        r = FrameBackSpill<M>(p, &s, utt, c.base_in, c.n_in, c.cutoff, frame, q_emit,
-                           cnt.tokens_expanded, cnt.arcs_scanned, try_lds);
-        if (r == 0) {
-          c.base_in = s.base_out;
-          c.n_in = c.simple ? s.n_act : s.n_live;
-        }
-        FullClear<true>(tl, s);
-        KD_LAP(s, 14);
+    bool small = false;
+    if constexpr (!c.simple) small = frame >= 0 && c.n_in <= kT1Front;
+    // a small frame of few tokens is run by the first four waves alone
+    const Team tm{small && c.n_in <= kT1Narrow ? 256 : kBlock, gen};
+    uint32_t r = kRetry;
+    if (tid < tm.nt) {
+      if (tid == 0) {
+        s.min_new = kCostInf;
+        s.wl_count[0] = 0;
+        s.wl_count[1] = 0;
+        s.q_n = 0;
+        s.n_live = 0;
+        s.overflow = 0;
+        s.f_nlt = 0;
+        s.f_nle = 0;
+        s.n_emit_links = 0;
+        s.n_eps_links = 0;
+        s.n_emit_written = 0;
+        s.min_stored = kCostInf;
+        s.n_act = 0;
+        s.n_inact = 0;
+        s.it_count[0] = 0;
+        s.it_next[0] = 0;
+        s.f_best_next = kCostDead;
       }
-    } else {
-      r = KD_UTT_TABLE_FULL;
+      if (frame >= 0) {
+        c.ll_row = ToG(ud.ll) + static_cast<long long>(frame - ud.offset) * p.row_stride;
+        if (c.ll_in_lds && tid < kLlLanes) {
+#pragma unroll
+          for (int k = 0; k < kLlRegs; ++k) {
+            const int v = tid + k * kLlLanes;
+            if (v < p.num_cols) s.ll[v] = ll_pf[k];
+          }
+          prefetch_row(frame + 1);
+        }
+      }
+      // (with_global: the previous frame's token records, for LoadFront / the big tiers)
+      tm.Sync(true);
+      KD_LAP(s, 0);
+      if (small) {
+        if (!front_lds) LoadFront(c, tm);
+        r = SmallFrame(c, t1, frame, cnt, tm);
+        if (tid == 0) s.ctl_r = r;
+      }
+    }
+    int q_emit = 0;
+    bool filtered = false;  // the emitting filter already ran (tier 1 did not fit)
+    if (small) {
+      __syncthreads();  // the whole workgroup again
+      r = s.ctl_r;
+      upper_dirty = true;
+      best_stale = true;
+      if (r == 0) {
+        c.base_in = s.base_out;
+        c.n_in = s.n_live;
+        front_lds = c.n_in <= kT1Front;
+      } else if (r == kRedo) {
+        r = kRetry;
+      } else if (r == kRetry) {
+        // more states than the small table holds: move the LDS part of the queue
+        // next to the rest and replay all of it in the big table
+        q_emit = s.ctl_q_emit;
+        c.cutoff = s.ctl_cutoff;
+        const int nl = q_emit < kQL ? q_emit : kQL;
+        for (int i = tid; i < nl; i += kBlock) {
+          c.q_arc[i] = T1QArc(s)[i];
+          c.q_src[i] = T1QSrc(s)[i];
+          c.q_nk[i] = T1QNk(s)[i];
+          if (c.lattice) c.q_ac[i] = T1QAc(s)[i];  // (allocated for the lattice decoders only)
+          if (c.lattice) c.q_gr[i] = T1QGr(s)[i];
+        }
+        filtered = true;
+        cnt.eps_exp = 0;
+        cnt.eps_arcs = 0;
+      }
+    }
+    if (r == kRetry) {
+      // frames that need the big tables run in a function of their own
+      r = BigFrame<M>(&p, utt, frame, c.base_in, c.n_in, c.cutoff, q_emit,
+                      (filtered ? 1 : 0) | (upper_dirty ? 2 : 0) | (best_stale ? 4 : 0),
+                      cnt.tokens_expanded, cnt.arcs_scanned);
+      front_lds = false;
+      upper_dirty = false;
+      best_stale = false;
+      if (r == 0) {
+        c.base_in = s.base_out;
+        c.n_in = c.simple ? s.n_act : s.n_live;
+      }
+      __syncthreads();  // every wave's token stores have landed before a small team reads them
     }
     if (r != 0) { err |= r; break; }
     frame++;

@@ -19,7 +19,7 @@ INT_MAX = 2**31 - 1
 KD_MEM_HOST, KD_MEM_DEVICE = 0, 1
 STAT_NAMES = ("frames", "tokens_in", "tokens_expanded", "arcs_scanned", "arcs_kept",
               "tokens_out", "eps_arcs_scanned", "eps_expansions", "max_tokens", "spill_frames",
-              "links")
+              "links", "small_frames")
 
 # every symbol include/kd_hip.h declares
 SYMBOLS = (

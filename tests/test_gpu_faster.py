@@ -117,8 +117,51 @@ def test_spill_to_global_table(oracle):
     so, co = d.tokens()
     assert len(so) > 8192
     assert s.tolist() == so.tolist() and c.tolist() == co.tolist()
-    assert bt.stats()[0, 9] > 0  # spill frames
+    st = dict(zip(cabi.STAT_NAMES, bt.stats()[0].tolist()))
+    # all three tiers ran: LDS-resident small frames, the big LDS table, the global table
+    assert st["spill_frames"] > 0 and st["small_frames"] > 0
     _assert_same_path(bt.best_paths()[0], d.get_best_path(), "spill")
+
+
+def test_small_frame_outgrows_its_table(oracle):
+    # a frontier of at most 1024 tokens whose successors do not fit the 4096-slot table of the
+    # LDS-resident tier: its candidate queue is replayed in the big table
+    g = synth.random_graph(30000, 8.0, 16, 0.1, 11, max_weight=0.5)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lp = synth.make_logprobs(5, 16, 0, peak=0.0)
+    opts = dict(beam=1000.0, min_active=0)
+    bt = cabi.Batch(G, max_batch=1, **opts)
+    bt.init_decoding()
+    bt.advance_host([lp])
+    d = oracle.FasterDecoder(OG, policy=1, **opts)
+    d.decode(lp)
+    n = [len(bt.frame_tokens(0, f)[0]) for f in range(6)]
+    assert any(n[f] <= 1024 and n[f + 1] > 3072 for f in range(5)), n
+    s, c = bt.frame_tokens(0, 5)
+    so, co = d.tokens()
+    assert s.tolist() == so.tolist() and c.tolist() == co.tolist()
+    _assert_same_path(bt.best_paths()[0], d.get_best_path(), "outgrown")
+
+
+def test_big_lds_table_tier(oracle):
+    # frontiers between 1024 and 6144 tokens run in the 8192-slot LDS table; V > 2048 also
+    # takes the log-likelihood row from global memory instead of LDS
+    g = synth.random_graph(3000, 3.0, 3000, 0.1, 5, max_weight=0.5)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lp = synth.make_logprobs(10, 3000, 0, peak=0.0)
+    opts = dict(beam=1000.0, min_active=0)
+    bt = cabi.Batch(G, max_batch=1, **opts)
+    bt.init_decoding()
+    bt.advance_host([lp])
+    d = oracle.FasterDecoder(OG, policy=1, **opts)
+    d.decode(lp)
+    s, c = bt.frame_tokens(0, 10)
+    so, co = d.tokens()
+    assert 1024 < len(so) <= 6144
+    assert s.tolist() == so.tolist() and c.tolist() == co.tolist()
+    st = dict(zip(cabi.STAT_NAMES, bt.stats()[0].tolist()))
+    assert st["frames"] - st["small_frames"] - st["spill_frames"] > 0, st
+    _assert_same_path(bt.best_paths()[0], d.get_best_path(), "big table")
 
 
 def test_streaming_with_decodable_offset(oracle):

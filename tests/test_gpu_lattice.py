@@ -110,7 +110,8 @@ def test_lattice_frames_that_spill_to_the_global_table(oracle):
     lb = cabi.LatticeBatch(G, max_batch=1, **opts)
     lb.init_decoding()
     lb.advance_host([lp])
-    assert lb.stats()[0, 9] > 0  # spill frames
+    st = dict(zip(cabi.STAT_NAMES, lb.stats()[0].tolist()))
+    assert st["spill_frames"] > 0 and st["small_frames"] > 0
     lb.finalize_decoding()
     gl = lb.raw_lattices()[0]
     can = oracle.CanonLatticeDecoder(OG, **opts)

@@ -22,7 +22,8 @@ NAMES = ['0 frame start/ll row', '1 GetCutoff', '2 prepass', '3 emit filter: ite
          '4 emit filter: big loop', '5 emit insert', '6 eps round setup', '7 eps filter: items+small',
          '8 eps filter: big loop', '9 eps insert', '10 resolve R1 + alloc', '11 C1 write tokens',
          '12 stats fold + barrier', '13 clear/loop', '14 spill-mode frames', '15 aborted LDS attempts',
-         '16 R2 back-pointers', '17 link records', '18 best token + frame index', '19 -']
+         '16 R2 back-pointers', '17 link records', '18 best token + frame index',
+         '19 small (LDS-resident) frames']
 
 
 def run(kind, B=None):
@@ -42,7 +43,11 @@ def run(kind, B=None):
     tot = cyc.sum(0)
     allc = tot.sum()
     print(kind, 'B', B, 'kernel_ms %.2f' % bt.last_kernel_ms(), 'spill_frames', st[:, 9].sum(),
+          'small_frames', st[:, 11].sum(), 'of', st[:, 0].sum(),
           'cycles/utt-frame %.0f' % (allc / (B * T)))
+    if st[:, 11].sum():
+        print('  cycles per small frame (bucket 19, or all but 14 with the _t1 build): %.0f | %.0f'
+              % (tot[19] / st[:, 11].sum(), (allc - tot[14]) / st[:, 11].sum()))
     for n, v in zip(NAMES, tot):
         print('  %-28s %5.1f%%  %8.0f cyc/utt-frame' % (n, 100 * v / allc, v / (B * T)))
     tcyc = cyc.sum(1)
