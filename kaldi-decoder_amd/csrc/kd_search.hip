@@ -56,13 +56,22 @@
 namespace kd {
 namespace {
 
-constexpr int kBlock = 1024;  // threads per utterance
+#ifndef KD_BLOCK
+#define KD_BLOCK 768
+#endif
+// Threads per utterance.  768 = three waves per SIMD gives each thread 168 vector
+// registers; at 1024 (128 registers) the search spills to scratch memory in its hot
+// loops, and every reload there is an exposed memory round trip.
+constexpr int kBlock = KD_BLOCK;
 constexpr int kWaves = kBlock / 64;
 constexpr int kLog2Slots = 13;
 constexpr int kSlots = 1 << kLog2Slots;
-constexpr int kSlotsPerThread = kSlots / kBlock;
 constexpr int kLdsFillLimit = kSlots * 3 / 4;
 constexpr int kVmax = 2048;   // log-likelihood row staged in LDS when V <= kVmax
+// the waves a four-wave team leaves idle fetch the next frame's row meanwhile
+constexpr int kLlLanes = KD_BLOCK - 256, kLlRegs = (kVmax + kLlLanes - 1) / kLlLanes;
+// ... a whole-workgroup team carries it in registers through the emitting filter
+constexpr int kPfRegs = (kVmax + KD_BLOCK - 1) / KD_BLOCK;
 constexpr int kSmallDeg = 4;  // tokens with at most this many arcs stay on their lane
 constexpr int kGroup = 4;     // queued tokens a wave scores at a time
 // Tier 1 (frames whose frontier is at most one token per lane -- 97% of the frames
@@ -72,9 +81,11 @@ constexpr int kGroup = 4;     // queued tokens a wave scores at a time
 constexpr int kT1Log2 = 12;
 constexpr int kT1Slots = 1 << kT1Log2;
 constexpr int kT1Front = 1024;
-constexpr int kT1Narrow = 256;  // ... of which frames up to this size run on four waves
+constexpr int kT1Narrow = 0;  // ... of which frames up to this size run on four waves (0: never;
+                               // measured slower on MI355X: fewer loads in flight per round trip)
 constexpr int kQL = 2048;
-static_assert(kBlock == 1024 && kT1Front == kBlock && kSlots == 2 * kT1Slots && 2 * kQL == kT1Slots,
+constexpr int kT1W16 = 512;    // tokens of at most 16 arcs (in Shared::hist)
+static_assert(kBlock >= 512 && kT1Front >= kBlock && kSlots == 2 * kT1Slots && 2 * kQL == kT1Slots,
               "tier-1 LDS overlay");
 constexpr unsigned long long kCostInf = 0xFFF0000000000000ull;  // CostKey(+inf)
 // Frame results besides 0 and the KD_UTT_* bits: run the table half again in the
@@ -88,10 +99,10 @@ struct Shared {
   uint32_t arc[kSlots];
   // queue of high-degree tokens of the current chunk; between tier-1 frames the
   // same arrays hold the frontier: cost, emitting arc range, state
-  double it_cost[kBlock];
-  int32_t it_abeg[kBlock];
-  int32_t it_deg[kBlock];
-  uint32_t it_src[kBlock];
+  double it_cost[kT1Front];
+  int32_t it_abeg[kT1Front];
+  int32_t it_deg[kT1Front];
+  uint32_t it_src[kT1Front];
   float ll[kVmax];
   uint32_t bitmask[kSlots / 32];
   int32_t hist[256];
@@ -114,14 +125,26 @@ struct Shared {
   long long link_next;          // lattice: next free link of this utterance
   int32_t overflow;
   int32_t soft_bar;             // team barrier arrivals since the launch began
-  uint32_t ctl_r;               // tier-1 frame result, for the waves that sat it out
-  int32_t ctl_q_emit;           // ... and what a replay in the big table needs
-  double ctl_cutoff;
+  // what a tier-1 frame leaves for the waves that sat it out, by frame parity:
+  // result, new frontier (size, arena base), and what a replay in the big table needs
+  struct {
+    double cutoff;
+    long long base_out;
+    uint32_t r;
+    int32_t n_in;
+    int32_t q_emit;
+    int32_t pad;
+  } ctl[2];
   int32_t wl_count[2];
   int32_t it_count[2], it_next[2];
+  int32_t it_n32, it_n16;       // tier 1: tokens in the 32-lane and 16-lane lists
+  int32_t it_next32, it_next16;
   int32_t sel_bin, sel_k;
   int32_t frame_cnt[4];         // this frame: expanded, eps_exp, arcs, eps_arcs
-  long long stat[KD_NUM_STATS];  // whole launch
+  union {  // whole launch (all values are non-negative)
+    long long stat[KD_NUM_STATS];
+    unsigned long long ustat[KD_NUM_STATS];
+  };
 #ifdef KD_PROFILE
   long long cyc[kProfSlots];
   long long lap_last;
@@ -143,11 +166,10 @@ __device__ __forceinline__ uint32_t *T1QH(Shared &s) { return &s.key[kT1Slots]; 
 __device__ __forceinline__ uint32_t *T1QArc(Shared &s) { return &s.key[kT1Slots + kQL]; }
 __device__ __forceinline__ uint32_t *T1QSrc(Shared &s) { return &s.arc[kT1Slots]; }
 // ... the live list (slots holding a token, in arena order) and the filter's work items
-constexpr int kT1Items = 512;
-constexpr uint32_t kNullItem = 0xFFFFFFFFu;
 __device__ __forceinline__ uint16_t *T1Live(Shared &s) { return reinterpret_cast<uint16_t *>(&s.arc[kT1Slots + kQL]); }
-__device__ __forceinline__ uint32_t *T1Items(Shared &s) { return &s.arc[kSlots - kT1Items]; }
-static_assert(2 * (kT1Slots * 3 / 4) + 4 * kT1Items <= 4 * kQL, "tier-1 spare region");
+__device__ __forceinline__ uint16_t *T1Heads(Shared &s) { return reinterpret_cast<uint16_t *>(&s.arc[kSlots - kT1Front / 2]); }
+static_assert(2 * (kT1Slots * 3 / 4) + 2 * kT1Front <= 4 * kQL, "tier-1 spare region");
+__device__ __forceinline__ uint16_t *T1W16(Shared &s) { return reinterpret_cast<uint16_t *>(s.hist); }
 
 
 // Pointers that arrive inside the by-value parameter struct are generic
@@ -237,11 +259,55 @@ struct Team {
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     gen += nt >> 6;
     if ((threadIdx.x & 63) == 0) atomicAdd(&s.soft_bar, 1);
-    while (__hip_atomic_load(&s.soft_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - gen < 0)
-      __builtin_amdgcn_s_sleep(1);
+    // (each team wave has a SIMD to itself: spinning costs nobody an issue slot)
+    while (__hip_atomic_load(&s.soft_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - gen < 0) {}
     asm volatile("" ::: "memory");
   }
 };
+
+// Values that are the same in every lane (read from LDS, say) live in vector
+// registers unless told otherwise.  Uni() moves them to scalar registers, whose
+// spills go to lanes of a vector register instead of scratch memory.
+__device__ __forceinline__ int Uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t Uni(uint32_t v) {
+  return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+}
+__device__ __forceinline__ unsigned long long Uni(unsigned long long v) {
+  const uint32_t lo = Uni(static_cast<uint32_t>(v)), hi = Uni(static_cast<uint32_t>(v >> 32));
+  return static_cast<unsigned long long>(hi) << 32 | lo;
+}
+__device__ __forceinline__ long long Uni(long long v) {
+  return static_cast<long long>(Uni(static_cast<unsigned long long>(v)));
+}
+__device__ __forceinline__ double Uni(double v) {
+  return __longlong_as_double(Uni(__double_as_longlong(v)));
+}
+__device__ __forceinline__ float Uni(float v) { return __int_as_float(Uni(__float_as_int(v))); }
+
+// Per-frame counters, reset by one thread at the end of a frame for the next one.
+__device__ __forceinline__ void ResetFrame(Shared &s) {
+  s.min_new = kCostInf;
+  s.wl_count[0] = 0;
+  s.wl_count[1] = 0;
+  s.q_n = 0;
+  s.n_live = 0;
+  s.overflow = 0;
+  s.f_nlt = 0;
+  s.f_nle = 0;
+  s.n_emit_links = 0;
+  s.n_eps_links = 0;
+  s.n_emit_written = 0;
+  s.min_stored = kCostInf;
+  s.n_act = 0;
+  s.n_inact = 0;
+  s.it_count[0] = 0;
+  s.it_next[0] = 0;
+  s.it_n32 = 0;
+  s.it_n16 = 0;
+  s.it_next32 = 0;
+  s.it_next16 = 0;
+  s.f_best_next = kCostDead;
+}
 
 // ---- block-wide primitives (wave64 shuffles + one LDS hop) -----------------
 // Sum over the wave.  (An atomicAdd of a per-lane value makes hipcc serialise the
@@ -260,6 +326,34 @@ __device__ __forceinline__ unsigned long long WaveMinU64(unsigned long long v) {
     v = y < v ? y : v;
   }
   return v;
+}
+
+// atomicMin(p, v) from the lanes with `on`, to one LDS word.  hipcc turns such a
+// same-address atomic of per-lane values into a loop over the lanes (some fifteen
+// instructions each); reduce over the wave first and let one lane go to LDS.  The
+// wave takes the short way out when no lane has anything to contribute.
+__device__ __forceinline__ void LaneMin(unsigned long long *p, unsigned long long v, bool on) {
+  if (__ballot(on) == 0) return;
+  const unsigned long long w = WaveMinU64(on ? v : ~0ull);
+  if ((threadIdx.x & 63) == 0) atomicMin(p, w);
+}
+
+// counter++ by every lane that is active here: one LDS atomic for the wave (the
+// build runs without the compiler's atomic optimizer, see the Makefile).  AggInc
+// returns each lane's own old value, AggAdd1 nothing.
+__device__ __forceinline__ int AggInc(int32_t *ctr) {
+  const unsigned long long m = __ballot(1);
+  const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+  int base = 0;
+  if (rank == 0) base = atomicAdd(ctr, __popcll(m));
+  return __builtin_amdgcn_readfirstlane(base) + rank;
+}
+__device__ __forceinline__ void AggAdd1(int32_t *ctr) {
+  const unsigned long long m = __ballot(1);
+  const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+  if (rank == 0) atomicAdd(ctr, __popcll(m));
 }
 
 __device__ __forceinline__ unsigned long long BlockMinU64(Shared &s, unsigned long long v) {
@@ -370,6 +464,11 @@ struct FrameCtx {
   KD_G float *q_ac, *q_gr;
   int q_cap;
   bool replay;    // spill mode after an aborted LDS attempt: queue destinations were overwritten
+  // This lane's lowest new cost so far in the emitting filter.  The shared running
+  // minimum (s.min_new) is only updated where the wave is converged (PublishMin):
+  // a same-address atomic of per-lane values inside divergent code is compiled to a
+  // loop over the lanes.  A looser running cutoff only lengthens the queue.
+  mutable unsigned long long run_min;
   bool min_only;  // simple: first filter pass only finds the minimum total cost
 };
 
@@ -398,6 +497,7 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
   } else {
     const float ll = c.ll_in_lds ? s.ll[a.ilabel - 1] : c.ll_row[a.ilabel - 1];
     seen_min = s.min_new;
+    seen_min = c.run_min < seen_min ? c.run_min : seen_min;
     if (c.simple) {
       // simple-decoder.cc:167-176.  Two passes: the first only finds the minimum
       // total cost, the second queues what is below min + beam.  The token stores
@@ -406,7 +506,7 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
       const double total_cost = csrc + a.weight + acoustic_cost;
       if (c.min_only) {
         const unsigned long long tk = CostKey(total_cost);
-        if (tk < seen_min) atomicMin(&s.min_new, tk);
+        if (tk < seen_min) c.run_min = tk;
         return;
       }
       keep = !(total_cost >= c.cutoff);
@@ -427,7 +527,7 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
   }
   if (keep) {
     const unsigned long long nk = CostKey(nc);
-    const int pos = atomicAdd(&s.q_n, 1);
+    const int pos = AggInc(&s.q_n);
     if (T1 && pos < kQL) {
       T1QH(s)[pos] = a.next;
       T1QArc(s)[pos] = aidx;
@@ -444,9 +544,15 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
       if (c.lattice) c.q_gr[pos] = a.weight;
     }
     if constexpr (!EPS) {
-      if (!c.simple && nk < seen_min) atomicMin(&s.min_new, nk);
+      if (!c.simple && nk < seen_min) c.run_min = nk;
     }
   }
+}
+
+// Folds the lanes' running minima into s.min_new.  Call where the wave is converged.
+template <int M>
+__device__ __forceinline__ void PublishMin(const FrameCtx<M> &c) {
+  if (c.run_min < c.s.min_new) atomicMin(&c.s.min_new, c.run_min);
 }
 
 // High-degree tokens queued by a filter pass: a wave takes kGroup of them at a
@@ -483,6 +589,7 @@ __device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int par, int nq, R
         source(q0 + g, cst, srcid);
         FilterArc<EPS, T1>(c, ar[g], static_cast<uint32_t>(abeg[g] + lane), cst, srcid);
       }
+    if constexpr (!EPS) PublishMin(c);
     // tails of tokens with more than 64 arcs, four wave-rows in flight
 #pragma unroll 1
     for (int g = 0; g < kGroup; ++g) {
@@ -502,6 +609,7 @@ __device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int par, int nq, R
             FilterArc<EPS, T1>(c, tr[u], static_cast<uint32_t>(abeg[g] + a0 + 64 * u), cst, srcid);
       }
     }
+    if constexpr (!EPS) PublishMin(c);
   }
 }
 
@@ -544,7 +652,7 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
         if (EPS) { cnt.eps_exp += 1; cnt.eps_arcs += deg; }
         else { cnt.tokens_expanded += 1; cnt.arcs_scanned += deg; }
         if (deg > kSmallDeg) {
-          const int q = atomicAdd(&s.it_count[par], 1);
+          const int q = AggInc(&s.it_count[par]);
           s.it_abeg[q] = abeg;
           s.it_deg[q] = deg;
           s.it_cost[q] = cst;
@@ -561,6 +669,7 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
         }
       }
     }
+    if constexpr (!EPS) PublishMin(c);
     LdsBarrier();  // the big-token queue is LDS; queue stores keep draining
     KD_LAP(s, EPS ? 7 : 3);
     const int nq = s.it_count[par];
@@ -603,7 +712,7 @@ __device__ __forceinline__ void Insert(const FrameCtx<M> &c, const Table<LDS> &t
         if (!EPS && c.simple && nk < s.min_stored) atomicMin(&s.min_stored, nk);
         bool push = false;
         if (old == kCostDead) {  // the state's first token this frame
-          const int pos = atomicAdd(&s.n_live, 1);
+          const int pos = AggInc(&s.n_live);
           if (static_cast<uint32_t>(pos) < t.FillLimit()) c.live[pos] = h;
           else s.overflow = 1;
           push = (k & kHasEps) != 0;  // every new token is expanded once (:63-65)
@@ -620,8 +729,8 @@ __device__ __forceinline__ void Insert(const FrameCtx<M> &c, const Table<LDS> &t
           const uint32_t bit = 1u << (h & 31);
           push = !(atomicOr(&t.bitmask[h >> 5], bit) & bit);
         }
-        if (push) wl_out[atomicAdd(&s.wl_count[wl_out_idx], 1)] = h;
-        if (!EPS && c.lattice) atomicAdd(&s.n_emit_links, 1);
+        if (push) wl_out[AggInc(&s.wl_count[wl_out_idx])] = h;
+        if (!EPS && c.lattice) AggAdd1(&s.n_emit_links);
       }
     }
     c.q_h[i] = h;
@@ -706,12 +815,19 @@ __device__ __forceinline__ void GetCutoff(FrameCtx<M> &c, const Team &tm) {
   CParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x;
-  const double best_cost = KeyCost(s.f_best);
+  const double best_cost = Uni(KeyCost(s.f_best));
   const double beam_cutoff = best_cost + p.beam;
   if (p.max_active == INT_MAX && p.min_active == 0) {  // :249-272
     // LatticeSimpleDecoder has no cutoff on the tokens it expands (:376-401)
     c.weight_cutoff = c.lattice ? __longlong_as_double(0x7FF0000000000000ll) : beam_cutoff;
     c.adaptive_beam = p.beam;
+    return;
+  }
+  if (c.n_in <= p.max_active && c.n_in <= p.min_active) {
+    // neither limit can bind (:289, :311-323 with "min_active_cutoff = infinity")
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    c.adaptive_beam = static_cast<float>(inf - best_cost + p.beam_delta);
+    c.weight_cutoff = inf;
     return;
   }
   int lt = 0, le = 0;
@@ -728,7 +844,7 @@ __device__ __forceinline__ void GetCutoff(FrameCtx<M> &c, const Team &tm) {
     if (le) atomicAdd(&s.f_nle, le);
   }
   tm.Sync(false);
-  const int n_lt = s.f_nlt, n_le = s.f_nle;
+  const int n_lt = Uni(s.f_nlt), n_le = Uni(s.f_nle);
   // tmp_array_[k] < x  <=>  #{v < x} >= k+1 ;  tmp_array_[k] > x  <=>  #{v <= x} <= k
   if (c.n_in > p.max_active && static_cast<long long>(n_lt) >= static_cast<long long>(p.max_active) + 1) {
     const double max_active_cutoff = SelectKth<FRONT_LDS>(&s, p.tok_cost, c.base_in, c.n_in, p.max_active, tm);  // :297-309
@@ -824,9 +940,7 @@ template <bool LDS>
 __device__ __forceinline__ void FullClear(const Table<LDS> &t, Shared &s) {
   // only the LDS table is ever cleared wholesale (launch start, aborted frames)
   const int tid = threadIdx.x;
-#pragma unroll
-  for (int k = 0; k < kSlotsPerThread; ++k) {
-    const int h = k * kBlock + tid;
+  for (int h = tid; h < kSlots; h += kBlock) {
     s.key[h] = kKeyEmpty;
     s.cost[h] = kCostDead;
     s.arc[h] = kArcNone;
@@ -971,7 +1085,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
       const unsigned long long ck = t.LoadCost(h);
       int i = i0;
       if (c.simple)
-        i = ck < prune_key ? atomicAdd(&s.n_act, 1) : n_out - 1 - atomicAdd(&s.n_inact, 1);
+        i = ck < prune_key ? AggInc(&s.n_act) : n_out - 1 - AggInc(&s.n_inact);
       const long long g = base_out + i;
       const uint32_t st_of_tok = t.LoadKey(h) & kStateMask;
       ToG(p.tok_state)[g] = static_cast<int32_t>(st_of_tok);
@@ -1034,14 +1148,14 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
       if (i < q_emit) {
         src_tok = c.base_in + sr;
         ac = c.q_ac[i];
-        at = lbase + atomicAdd(&s.n_emit_written, 1);
+        at = lbase + AggInc(&s.n_emit_written);
       } else {
         const uint32_t hs = sr & ~kSrcEps;
         // source cost at generation vs its final cost (its slot's cost word is intact)
         if (c.q_ac[i] != static_cast<float>(KeyCost(t.LoadCost(hs)))) continue;
         src_tok = base_out + t.LoadKey(hs);
         ac = 0.0f;
-        at = lbase + n_emit + atomicAdd(&s.n_eps_links, 1);
+        at = lbase + n_emit + AggInc(&s.n_eps_links);
       }
       const uint32_t aidx = c.q_arc[i];
       ToG(p.link_src)[at] = static_cast<int32_t>(src_tok);
@@ -1133,7 +1247,8 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
 // frontier is described by s.base_out / s.n_live.
 template <int M>
 __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true> &t, int frame,
-                                               Counters &cnt, const Team &tm) {
+                                               Counters &cnt, const Team &tm,
+                                               const float (&ll_next)[kPfRegs], bool have_next) {
   constexpr int KD_BUCKET = kBucketSmall;
   (void)KD_BUCKET;
   CParams &p = c.p;
@@ -1168,25 +1283,32 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
           FilterArc<EPS, true>(c, ar[a], static_cast<uint32_t>(abeg + a0 + a), cst, srcid);
     }
   };
-  // A token with more than kSmallDeg arcs becomes work items of 64 consecutive arcs
-  // (token reference, chunk); returns false if the item list is full.
-  auto push_items = [&](int ref, int deg) -> bool {
-    const int n = (deg + 63) >> 6;
-    const int at = atomicAdd(&s.it_count[0], n);
-    if (at + n > kT1Items) {  // no room: void the part of the reservation inside the list
-      for (int k = at; k < kT1Items; ++k) T1Items(s)[k] = kNullItem;
-      return false;
+  // A token with more than kSmallDeg arcs becomes work items of 64 consecutive arcs:
+  // one head entry (its first 64) and, beyond that, tail entries (token, chunk).
+  // `ref` indexes the it_* arrays.  Tails that find their list full are scored here.
+  auto push_items = [&](auto eps_tag, int ref, int abeg, int deg, double cst, uint32_t srcid) {
+    // by width class: 16-lane and 32-lane slots pack several tokens into a wave row
+    if (deg <= 16) {
+      const int at = AggInc(&s.it_n16);
+      if (at < kT1W16) {
+        T1W16(s)[at] = static_cast<uint16_t>(ref);
+        return;
+      }
     }
-    for (int k = 0; k < n; ++k) T1Items(s)[at + k] = static_cast<uint32_t>(ref) << 16 | k;
-    return true;
+    if (deg <= 32) {  // (and the 16-lane tokens that found their list full)
+      T1Heads(s)[kT1Front - 1 - AggInc(&s.it_n32)] = static_cast<uint16_t>(ref);
+      return;
+    }
+    T1Heads(s)[AggInc(&s.it_count[0])] = static_cast<uint16_t>(ref);
   };
-  // Work items: a wave takes kGroup at a time, lanes over the item's arcs.
-  auto item_loop = [&](auto eps_tag) {
+  // One pass over a list of work items of width W lanes: a wave takes kGroup rows
+  // (kGroup * 64 / W items) at a time.  `item(q, ref, chunk)` describes item q.
+  auto rows = [&](auto eps_tag, auto width_tag, int nq, int32_t *next, auto item_ref) {
     constexpr bool EPS = decltype(eps_tag)::value;
-    const int nq = s.it_count[0] < kT1Items ? s.it_count[0] : kT1Items;
+    constexpr int W = decltype(width_tag)::value, kPer = 64 / W;
     while (true) {
       int q0 = 0;
-      if (lane == 0) q0 = atomicAdd(&s.it_next[0], kGroup);
+      if (lane == 0) q0 = atomicAdd(next, kGroup * kPer);
       q0 = __builtin_amdgcn_readfirstlane(q0);
       if (q0 >= nq) break;
       ArcRec ar[kGroup];
@@ -1195,10 +1317,11 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
 #pragma unroll
       for (int g = 0; g < kGroup; ++g) {
         on[g] = false;
-        const uint32_t it = q0 + g < nq ? T1Items(s)[q0 + g] : kNullItem;
-        if (it != kNullItem) {
-          ref[g] = static_cast<int>(it >> 16);
-          const int off = static_cast<int>(it & 0xFFFFu) * 64 + lane;
+        const int q = q0 + g * kPer + lane / W;
+        ref[g] = -1;
+        if (q < nq) {
+          ref[g] = item_ref(q);
+          const int off = lane % W;
           on[g] = off < s.it_deg[ref[g]];
           aidx[g] = s.it_abeg[ref[g]] + off;
           if (on[g]) ar[g] = LoadArcRec(p.arcs, static_cast<uint32_t>(aidx[g]));
@@ -1209,12 +1332,47 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
         if (on[g])
           FilterArc<EPS, true>(c, ar[g], static_cast<uint32_t>(aidx[g]), s.it_cost[ref[g]],
                                EPS ? s.it_src[ref[g]] : static_cast<uint32_t>(ref[g]));
+      if constexpr (W == 64) {
+        // tokens with more than 64 arcs: the rest, four wave-rows in flight
+#pragma unroll 1
+        for (int g = 0; g < kGroup; ++g) {
+          if (ref[g] < 0) continue;
+          const int deg = s.it_deg[ref[g]];
+          if (deg <= 64) continue;
+          const int abeg = s.it_abeg[ref[g]];
+          const double cst = s.it_cost[ref[g]];
+          const uint32_t srcid = EPS ? s.it_src[ref[g]] : static_cast<uint32_t>(ref[g]);
+          for (int a0 = 64 + lane; a0 < deg; a0 += 256) {
+            ArcRec tr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (a0 + 64 * u < deg)
+                tr[u] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg + a0 + 64 * u));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (a0 + 64 * u < deg)
+                FilterArc<EPS, true>(c, tr[u], static_cast<uint32_t>(abeg + a0 + 64 * u), cst, srcid);
+          }
+        }
+      }
+      if constexpr (!EPS) PublishMin(c);
     }
+  };
+  auto item_loop = [&](auto eps_tag) {
+    const int n64 = Uni(s.it_count[0]), n32 = Uni(s.it_n32), n16r = Uni(s.it_n16);
+    const int n16 = n16r < kT1W16 ? n16r : kT1W16;
+    rows(eps_tag, std::integral_constant<int, 64>{}, n64, &s.it_next[0],
+         [&](int q) -> int { return T1Heads(s)[q]; });
+    rows(eps_tag, std::integral_constant<int, 32>{}, n32, &s.it_next32,
+         [&](int q) -> int { return T1Heads(s)[kT1Front - 1 - q]; });
+    rows(eps_tag, std::integral_constant<int, 16>{}, n16, &s.it_next16,
+         [&](int q) -> int { return T1W16(s)[q]; });
   };
   using EpsNo = std::false_type;
   using EpsYes = std::true_type;
 
   if (tid < kMaskWords) wlmask[tid] = 0;  // worklist 0 collects the emitting insert's tokens
+  c.run_min = kCostInf;
   GetCutoff<true>(c, tm);
   KD_LAP(s, 1);
 
@@ -1225,22 +1383,33 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     const int abeg = s.it_abeg[i], deg = s.it_deg[i];
     cnt.tokens_expanded += 1;
     cnt.arcs_scanned += deg;
-    if (deg <= kSmallDeg || !push_items(i, deg))
-      lane_arcs(EpsNo{}, abeg, deg, cst, static_cast<uint32_t>(i));
+    if (deg <= kSmallDeg) lane_arcs(EpsNo{}, abeg, deg, cst, static_cast<uint32_t>(i));
+    else push_items(EpsNo{}, i, abeg, deg, cst, static_cast<uint32_t>(i));
   }
+  PublishMin(c);
   tm.Sync(false);
   KD_LAP(s, 3);
   item_loop(EpsNo{});
   queue_sync();
   KD_LAP(s, 4);
-  const int q_emit = s.q_n;
+  // the emitting filter is done with this frame's log-likelihood row: the next
+  // frame's row (fetched into registers when this frame began) takes its place
+  if (have_next && nt == kBlock) {
+#pragma unroll
+    for (int k = 0; k < kPfRegs; ++k) {
+      const int v = tid + k * kBlock;
+      if (v < p.num_cols) s.ll[v] = ll_next[k];
+    }
+  }
+  const int q_emit = Uni(s.q_n);
   if (c.lattice)  // float, lattice-simple-decoder.cc:388-390
     c.cutoff = static_cast<float>(KeyCost(s.min_new)) + c.adaptive_beam;
   else
     c.cutoff = KeyCost(s.min_new) + static_cast<double>(c.adaptive_beam);  // value of :240
+  c.cutoff = Uni(c.cutoff);
   if (tid == 0) {  // what a replay in the big table needs
-    s.ctl_q_emit = q_emit;
-    s.ctl_cutoff = c.cutoff;
+    s.ctl[frame & 1].q_emit = q_emit;
+    s.ctl[frame & 1].cutoff = c.cutoff;
   }
   if (q_emit > c.q_cap) return kRedo;  // the big path scans again under the final cutoff
   const unsigned long long cutkey = CostKey(c.cutoff);
@@ -1261,7 +1430,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
           const unsigned long long old = atomicMin(&s.cost[h], nk);
           bool push = false;
           if (old == kCostDead) {  // the state's first token this frame
-            const int pos = atomicAdd(&s.n_live, 1);
+            const int pos = AggInc(&s.n_live);
             if (pos < static_cast<int>(t.FillLimit())) T1Live(s)[pos] = static_cast<uint16_t>(h);
             else s.overflow = 1;
             push = (k & kHasEps) != 0;  // every new token is expanded once (:63-65)
@@ -1272,7 +1441,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
             atomicOr(&wlmask[out * kMaskWords + (h >> 5)], 1u << (h & 31));
             s.wl_count[out] = 1;
           }
-          if (!EPS && c.lattice) atomicAdd(&s.n_emit_links, 1);
+          if (!EPS && c.lattice) AggAdd1(&s.n_emit_links);
         }
       }
       if (i < kQL) T1QH(s)[i] = h; else c.q_h[i] = h;
@@ -1282,13 +1451,22 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   insert(EpsNo{}, 0, q_emit, 0);
   tm.Sync(false);
   KD_LAP(s, 5);
-  if (s.overflow) return kRetry;
+  if (Uni(s.overflow)) return kRetry;
 
   // ---- ProcessNonemitting to a fixpoint (:59-119)
   int cur = 0, q_begin = q_emit;
-  while (s.wl_count[cur] != 0) {
+  while (Uni(s.wl_count[cur]) != 0) {
     if (tid < kMaskWords) wlmask[(cur ^ 1) * kMaskWords + tid] = 0;
-    if (tid == 0) { s.wl_count[cur ^ 1] = 0; s.it_count[0] = 0; s.it_next[0] = 0; s.it_count[1] = 0; }
+    if (tid == 0) {
+      s.wl_count[cur ^ 1] = 0;
+      s.it_count[0] = 0;
+      s.it_next[0] = 0;
+      s.it_count[1] = 0;
+      s.it_n32 = 0;
+      s.it_n16 = 0;
+      s.it_next32 = 0;
+      s.it_next16 = 0;
+    }
     tm.Sync(false);
     KD_LAP(s, 6);
     // every team thread scans its share of the worklist mask, 16 slots at a time
@@ -1307,13 +1485,14 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
         const uint32_t srcid = h | kSrcEps;
         bool queued = false;
         if (deg > kSmallDeg) {
-          const int q = atomicAdd(&s.it_count[1], 1);  // descriptor slot in it_*
-          if (q < kBlock) {
+          const int q = AggInc(&s.it_count[1]);  // descriptor slot in it_*
+          if (q < kT1Front) {
             s.it_abeg[q] = abeg;
             s.it_deg[q] = deg;
             s.it_cost[q] = cst;
             s.it_src[q] = srcid;
-            queued = push_items(q, deg);
+            push_items(EpsYes{}, q, abeg, deg, cst, srcid);
+            queued = true;
           }
         }
         if (!queued) lane_arcs(EpsYes{}, abeg, deg, cst, srcid);
@@ -1324,12 +1503,12 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     item_loop(EpsYes{});
     queue_sync();
     KD_LAP(s, 8);
-    const int q_end = s.q_n;
+    const int q_end = Uni(s.q_n);
     if (q_end > c.q_cap) return kRetry;
     insert(EpsYes{}, q_begin, q_end, cur ^ 1);
     tm.Sync(false);
     KD_LAP(s, 9);
-    if (s.overflow) return kRetry;
+    if (Uni(s.overflow)) return kRetry;
     q_begin = q_end;
     cur ^= 1;
   }
@@ -1337,7 +1516,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // ---- resolve R1: entries that hold their slot's final cost compete for the
   // lowest arc index
   const int n_q = q_begin;
-  const int n_out = s.n_live;
+  const int n_out = Uni(s.n_live);
   for (int i = tid; i < n_q; i += nt) {
     const uint32_t h = q_h(i);
     if (h != kKeyEmpty && s.cost[h] == q_nk(i)) atomicMin(&s.arc[h], q_arc(i));
@@ -1345,7 +1524,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   long long base_out;
   {
     // each utterance owns arena[utt * arena_cap, (utt + 1) * arena_cap)
-    const long long b = s.arena_next;
+    const long long b = Uni(s.arena_next);
     const bool full =
         b + n_out > static_cast<long long>(c.utt + 1) * static_cast<long long>(p.arena_cap);
     base_out = full ? -1 : b;
@@ -1381,10 +1560,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       }
     }
   }
-  {
-    const unsigned long long wmin = WaveMinU64(my_min);
-    if (lane == 0 && wmin != kCostDead) atomicMin(&s.f_best_next, wmin);
-  }
+  if (my_min != kCostDead && my_min < s.f_best_next) atomicMin(&s.f_best_next, my_min);
   tm.Sync(false);  // R1's arc words and the slots' index words are final
   KD_LAP(s, 10);
   if (tid == 0) {
@@ -1408,8 +1584,8 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   KD_LAP(s, 16);
   // ---- forward links (see FrameBack)
   if (c.lattice) {
-    const long long lbase = s.link_next;
-    const int n_emit = s.n_emit_links;
+    const long long lbase = Uni(s.link_next);
+    const int n_emit = Uni(s.n_emit_links);
     const bool full = lbase + n_emit + (n_q - q_emit) >
                       static_cast<long long>(c.utt + 1) * static_cast<long long>(p.link_cap);
     if (full) return KD_UTT_ARENA_FULL;
@@ -1422,13 +1598,13 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       if (i < q_emit) {
         src_tok = c.base_in + sr;
         ac = q_ac(i);
-        at = lbase + atomicAdd(&s.n_emit_written, 1);
+        at = lbase + AggInc(&s.n_emit_written);
       } else {
         const uint32_t hs = sr & ~kSrcEps;
         if (q_ac(i) != static_cast<float>(KeyCost(s.cost[hs]))) continue;
         src_tok = base_out + s.key[hs];
         ac = 0.0f;
-        at = lbase + n_emit + atomicAdd(&s.n_eps_links, 1);
+        at = lbase + n_emit + AggInc(&s.n_eps_links);
       }
       ToG(p.link_src)[at] = static_cast<int32_t>(src_tok);
       ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + s.key[h]);
@@ -1438,16 +1614,6 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     }
   }
   KD_LAP(s, 17);
-  {
-    const int w0 = WaveSumInt(cnt.tokens_expanded), w1 = WaveSumInt(cnt.eps_exp),
-              w2 = WaveSumInt(cnt.arcs_scanned), w3 = WaveSumInt(cnt.eps_arcs);
-    if (lane == 0) {
-      if (w0) atomicAdd(&s.frame_cnt[0], w0);
-      if (w1) atomicAdd(&s.frame_cnt[1], w1);
-      if (w2) atomicAdd(&s.frame_cnt[2], w2);
-      if (w3) atomicAdd(&s.frame_cnt[3], w3);
-    }
-  }
   tm.Sync(false);
   KD_LAP(s, 12);
   // ---- clear the table; publish the next frontier's arc ranges
@@ -1464,30 +1630,33 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     }
   }
   if (tid == 0) {
+    // frame index, launch counters (fire-and-forget LDS adds; the per-lane work
+    // counters are folded once, when the launch ends) and the next frame's start state
     const long long fi = static_cast<long long>(c.utt) * (p.max_frames + 1) + (frame + 1);
     ToG(p.frame_base)[fi] = base_out;
     ToG(p.frame_count)[fi] = n_out;
-    s.stat[KD_STAT_TOKENS_EXPANDED] += s.frame_cnt[0];
-    s.stat[KD_STAT_EPS_EXPANSIONS] += s.frame_cnt[1];
-    s.stat[KD_STAT_ARCS_SCANNED] += s.frame_cnt[2];
-    s.stat[KD_STAT_EPS_ARCS_SCANNED] += s.frame_cnt[3];
-    s.stat[KD_STAT_ARCS_KEPT] += q_emit;
-    s.stat[KD_STAT_TOKENS_OUT] += n_out;
-    if (n_out > s.stat[KD_STAT_MAX_TOKENS]) s.stat[KD_STAT_MAX_TOKENS] = n_out;
-    s.stat[KD_STAT_FRAMES] += 1;
-    s.stat[KD_STAT_SMALL_FRAMES] += 1;
-    s.stat[KD_STAT_TOKENS_IN] += n_in;
-    s.f_best = s.f_best_next;
+    atomicAdd(&s.ustat[KD_STAT_ARCS_KEPT], static_cast<unsigned long long>(q_emit));
+    atomicAdd(&s.ustat[KD_STAT_TOKENS_OUT], static_cast<unsigned long long>(n_out));
+    atomicMax(&s.ustat[KD_STAT_MAX_TOKENS], static_cast<unsigned long long>(n_out));
+    atomicAdd(&s.ustat[KD_STAT_FRAMES], 1ull);
+    atomicAdd(&s.ustat[KD_STAT_SMALL_FRAMES], 1ull);
+    atomicAdd(&s.ustat[KD_STAT_TOKENS_IN], static_cast<unsigned long long>(n_in));
+    const unsigned long long best = s.f_best_next;
+    const int n_emit = s.n_emit_links, n_eps = s.n_eps_links;
     if (c.lattice) {
       const long long lbase = s.link_next;
       const long long fb = static_cast<long long>(c.utt) * (p.max_frames + 1);
       ToG(p.link_emit_base)[fb + frame] = lbase;
-      ToG(p.link_emit_count)[fb + frame] = s.n_emit_links;
-      ToG(p.link_eps_base)[fb + frame + 1] = lbase + s.n_emit_links;
-      ToG(p.link_eps_count)[fb + frame + 1] = s.n_eps_links;
-      s.link_next = lbase + s.n_emit_links + s.n_eps_links;
-      s.stat[KD_STAT_LINKS] += s.n_emit_links + s.n_eps_links;
+      ToG(p.link_emit_count)[fb + frame] = n_emit;
+      ToG(p.link_eps_base)[fb + frame + 1] = lbase + n_emit;
+      ToG(p.link_eps_count)[fb + frame + 1] = n_eps;
+      s.link_next = lbase + n_emit + n_eps;
+      atomicAdd(&s.ustat[KD_STAT_LINKS], static_cast<unsigned long long>(n_emit + n_eps));
     }
+    ResetFrame(s);
+    s.f_best = best;
+    s.ctl[frame & 1].n_in = n_out;
+    s.ctl[frame & 1].base_out = base_out;
   }
   return 0;
 }
@@ -1523,6 +1692,7 @@ __device__ __forceinline__ void InitCtx(FrameCtx<M> &c, CParams &p, int utt) {
   c.q_ac = ToG(p.g_log_ac) + utt * 2 * gslots;
   c.q_gr = ToG(p.g_log_gr) + utt * 2 * gslots;
   c.min_only = false;
+  c.run_min = kCostInf;
   c.replay = false;
   c.ll_in_lds = p.num_cols <= kVmax;
 }
@@ -1586,10 +1756,8 @@ __device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long 
   if (frame >= 0)
     c.ll_row = ToG(ToG(p.utt)[utt].ll) +
                static_cast<long long>(frame - ToG(p.utt)[utt].offset) * p.row_stride;
-  if (upper_dirty) {
-    __syncthreads();
-    FullClear<true>(tl, s);
-  }
+  __syncthreads();  // token records stored by a small team are visible to every wave
+  if (upper_dirty) FullClear<true>(tl, s);
   if (filtered) {
     if (tid == 0) {
       s.q_n = q_emit;
@@ -1668,11 +1836,11 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p_by_v
   FullClear<true>(tl, s);
 
   UttDesc ud;
-  ud.ll = ToG(p.utt)[utt].ll;
-  ud.offset = ToG(p.utt)[utt].offset;
-  ud.target = ToG(p.utt)[utt].target;
-  uint32_t err = ToG(p.status)[utt];
-  int frame = p.do_init ? -1 : ToG(p.frames_decoded)[utt];
+  ud.ll = reinterpret_cast<const float *>(Uni(reinterpret_cast<unsigned long long>(ToG(p.utt)[utt].ll)));
+  ud.offset = Uni(ToG(p.utt)[utt].offset);
+  ud.target = Uni(ToG(p.utt)[utt].target);
+  uint32_t err = Uni(ToG(p.status)[utt]);
+  int frame = p.do_init ? -1 : Uni(ToG(p.frames_decoded)[utt]);
   const int target = p.do_init ? 0 : ud.target;
 
   c.base_in = 0;
@@ -1686,8 +1854,8 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p_by_v
   }
   if (frame >= 0 && frame < target) {
     const long long fi = static_cast<long long>(utt) * (p.max_frames + 1) + frame;
-    c.base_in = ToG(p.frame_base)[fi];
-    c.n_in = ToG(p.frame_count)[fi];
+    c.base_in = Uni(static_cast<long long>(ToG(p.frame_base)[fi]));
+    c.n_in = Uni(static_cast<int>(ToG(p.frame_count)[fi]));
     FrontierStats(c);
   }
   __syncthreads();
@@ -1697,91 +1865,94 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p_by_v
   // token's arc range (the tier-2 prepass input) out of date.
   Table<true> t1{s, nullptr, nullptr, nullptr, s.bitmask, kT1Log2, kT1Slots - 1};
   bool front_lds = false, upper_dirty = false, best_stale = false;
-  const int wave = tid >> 6;
   int gen = 0;  // team barriers this wave has passed
-  // The next frame's log-likelihood row travels in registers across the frame,
-  // in the first four waves (they take part in every frame).
-  constexpr int kLlLanes = 256, kLlRegs = kVmax / kLlLanes;
-  float ll_pf[kLlRegs];
-  auto prefetch_row = [&](int f) {
-    if (!c.ll_in_lds || tid >= kLlLanes || f < 0 || f >= target) return;
-    const KD_G float *row = ToG(ud.ll) + static_cast<long long>(f - ud.offset) * p.row_stride;
-#pragma unroll
-    for (int k = 0; k < kLlRegs; ++k) {
-      const int v = tid + k * kLlLanes;
-      ll_pf[k] = v < p.num_cols ? row[v] : 0.0f;
-    }
+  auto row_of = [&](int f) {
+    return ToG(ud.ll) + static_cast<long long>(f - ud.offset) * p.row_stride;
   };
-#pragma unroll
-  for (int k = 0; k < kLlRegs; ++k) ll_pf[k] = 0.0f;
-  if (err == 0) prefetch_row(frame);
+  auto row_to_lds = [&](int f) {  // whole workgroup; the caller synchronises
+    if (!c.ll_in_lds || f < 0 || f >= target) return;
+    const KD_G float *row = row_of(f);
+    for (int v = tid; v < p.num_cols; v += kBlock) s.ll[v] = row[v];
+  };
+  // At the top of the loop the per-frame counters are reset and s.ll holds the
+  // frame's log-likelihood row: a frame boundary costs one barrier.
+  if (tid == 0) ResetFrame(s);
+  if (err == 0) row_to_lds(frame);
+  __syncthreads();
+  Counters tot;  // per-lane work counters of the small frames, folded when the launch ends
 
   while (err == 0 && frame < target) {
     KD_LAP(s, 13);
     Counters cnt;
     bool small = false;
     if constexpr (!c.simple) small = frame >= 0 && c.n_in <= kT1Front;
-    // a small frame of few tokens is run by the first four waves alone
-    const Team tm{small && c.n_in <= kT1Narrow ? 256 : kBlock, gen};
     uint32_t r = kRetry;
-    if (tid < tm.nt) {
-      if (tid == 0) {
-        s.min_new = kCostInf;
-        s.wl_count[0] = 0;
-        s.wl_count[1] = 0;
-        s.q_n = 0;
-        s.n_live = 0;
-        s.overflow = 0;
-        s.f_nlt = 0;
-        s.f_nle = 0;
-        s.n_emit_links = 0;
-        s.n_eps_links = 0;
-        s.n_emit_written = 0;
-        s.min_stored = kCostInf;
-        s.n_act = 0;
-        s.n_inact = 0;
-        s.it_count[0] = 0;
-        s.it_next[0] = 0;
-        s.f_best_next = kCostDead;
-      }
-      if (frame >= 0) {
-        c.ll_row = ToG(ud.ll) + static_cast<long long>(frame - ud.offset) * p.row_stride;
-        if (c.ll_in_lds && tid < kLlLanes) {
-#pragma unroll
-          for (int k = 0; k < kLlRegs; ++k) {
-            const int v = tid + k * kLlLanes;
-            if (v < p.num_cols) s.ll[v] = ll_pf[k];
-          }
-          prefetch_row(frame + 1);
-        }
-      }
-      // (with_global: the previous frame's token records, for LoadFront / the big tiers)
-      tm.Sync(true);
-      KD_LAP(s, 0);
-      if (small) {
-        if (!front_lds) LoadFront(c, tm);
-        r = SmallFrame(c, t1, frame, cnt, tm);
-        if (tid == 0) s.ctl_r = r;
-      }
-    }
     int q_emit = 0;
     bool filtered = false;  // the emitting filter already ran (tier 1 did not fit)
     if (small) {
-      __syncthreads();  // the whole workgroup again
-      r = s.ctl_r;
+      // a small frame of few tokens is run by the first four waves alone
+      const Team tm{c.n_in <= kT1Narrow ? 256 : kBlock, gen};
+      const bool have_next = c.ll_in_lds && frame + 1 < target;
+      if (tid < tm.nt) {
+        float ll_next[kPfRegs];
+#pragma unroll
+        for (int k = 0; k < kPfRegs; ++k) ll_next[k] = 0.0f;
+        if (have_next && tm.nt == kBlock) {
+          const KD_G float *row = row_of(frame + 1);
+#pragma unroll
+          for (int k = 0; k < kPfRegs; ++k) {
+            const int v = tid + k * kBlock;
+            if (v < p.num_cols) ll_next[k] = row[v];
+          }
+        }
+        c.ll_row = row_of(frame);
+        if (!front_lds) LoadFront(c, tm);
+        r = SmallFrame(c, t1, frame, cnt, tm, ll_next, have_next);
+        if (tid == 0) s.ctl[frame & 1].r = r;
+        LdsBarrier();  // the whole workgroup again: nobody reads this frame's row any more
+      } else {
+        // the idle waves hold the next frame's row in registers until the frame is over
+        float ll_next[kLlRegs];
+        const KD_G float *row = row_of(have_next ? frame + 1 : frame);
+#pragma unroll
+        for (int k = 0; k < kLlRegs; ++k) {
+          const int v = tid - (kBlock - kLlLanes) + k * kLlLanes;
+          ll_next[k] = have_next && v < p.num_cols ? row[v] : 0.0f;
+        }
+        LdsBarrier();
+        if (have_next) {
+#pragma unroll
+          for (int k = 0; k < kLlRegs; ++k) {
+            const int v = tid - (kBlock - kLlLanes) + k * kLlLanes;
+            if (v < p.num_cols) s.ll[v] = ll_next[k];
+          }
+        }
+      }
+      if (tm.nt != kBlock) LdsBarrier();  // the next frame's row is in place
+      r = Uni(s.ctl[frame & 1].r);
       upper_dirty = true;
       best_stale = true;
       if (r == 0) {
-        c.base_in = s.base_out;
-        c.n_in = s.n_live;
+        c.base_in = Uni(s.ctl[frame & 1].base_out);
+        c.n_in = Uni(s.ctl[frame & 1].n_in);
         front_lds = c.n_in <= kT1Front;
+        tot.tokens_expanded += cnt.tokens_expanded;
+        tot.eps_exp += cnt.eps_exp;
+        tot.arcs_scanned += cnt.arcs_scanned;
+        tot.eps_arcs += cnt.eps_arcs;
       } else if (r == kRedo) {
+        // the queue overflowed: all of the frame again in the big path, which
+        // needs this frame's row back (its place was taken by the next frame's)
         r = kRetry;
+        cnt = Counters();
+        if (tid == 0) ResetFrame(s);
+        row_to_lds(frame);
+        __syncthreads();
       } else if (r == kRetry) {
         // more states than the small table holds: move the LDS part of the queue
         // next to the rest and replay all of it in the big table
-        q_emit = s.ctl_q_emit;
-        c.cutoff = s.ctl_cutoff;
+        q_emit = Uni(s.ctl[frame & 1].q_emit);
+        c.cutoff = Uni(s.ctl[frame & 1].cutoff);
         const int nl = q_emit < kQL ? q_emit : kQL;
         for (int i = tid; i < nl; i += kBlock) {
           c.q_arc[i] = T1QArc(s)[i];
@@ -1803,18 +1974,34 @@ __global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p_by_v
       front_lds = false;
       upper_dirty = false;
       best_stale = false;
+      r = Uni(r);
       if (r == 0) {
-        c.base_in = s.base_out;
-        c.n_in = c.simple ? s.n_act : s.n_live;
+        c.base_in = Uni(s.base_out);
+        c.n_in = Uni(c.simple ? s.n_act : s.n_live);
       }
-      __syncthreads();  // every wave's token stores have landed before a small team reads them
+      // the next frame's start state; every wave's token stores have landed before a
+      // small team reads them
+      __syncthreads();
+      if (tid == 0) ResetFrame(s);
+      if (tid < 4) s.frame_cnt[tid] = 0;
+      row_to_lds(frame + 1);
+      __syncthreads();
     }
     if (r != 0) { err |= r; break; }
     frame++;
-    LdsBarrier();
-    if (tid < 4) s.frame_cnt[tid] = 0;
   }
 
+  // fold the small frames' per-lane work counters into the launch totals
+  {
+    const int w0 = WaveSumInt(tot.tokens_expanded), w1 = WaveSumInt(tot.eps_exp),
+              w2 = WaveSumInt(tot.arcs_scanned), w3 = WaveSumInt(tot.eps_arcs);
+    if ((tid & 63) == 0) {
+      atomicAdd(&s.ustat[KD_STAT_TOKENS_EXPANDED], static_cast<unsigned long long>(w0));
+      atomicAdd(&s.ustat[KD_STAT_EPS_EXPANSIONS], static_cast<unsigned long long>(w1));
+      atomicAdd(&s.ustat[KD_STAT_ARCS_SCANNED], static_cast<unsigned long long>(w2));
+      atomicAdd(&s.ustat[KD_STAT_EPS_ARCS_SCANNED], static_cast<unsigned long long>(w3));
+    }
+  }
   __syncthreads();
   if (tid == 0) {
     ToG(p.frames_decoded)[utt] = frame < 0 ? -1 : frame;
