@@ -64,10 +64,27 @@ namespace {
 // loops, and every reload there is an exposed memory round trip.
 constexpr int kBlock = KD_BLOCK;
 constexpr int kWaves = kBlock / 64;
-constexpr int kLog2Slots = 13;
+// Geometry knobs (the defaults are the shipped configuration; tools/ builds others):
+//   KD_LOG2_SLOTS  slots of the LDS token table (tier 2); tier 1 uses half of them
+//   KD_T1_FRONT    largest frontier the LDS-resident tier takes
+//   KD_VMAX        widest log-likelihood row staged in LDS
+//   KD_WG_PER_CU   workgroups that must fit a CU together (LDS and registers)
+#ifndef KD_LOG2_SLOTS
+#define KD_LOG2_SLOTS 13
+#endif
+#ifndef KD_T1_FRONT
+#define KD_T1_FRONT 1024
+#endif
+#ifndef KD_VMAX
+#define KD_VMAX 2048
+#endif
+#ifndef KD_WG_PER_CU
+#define KD_WG_PER_CU 1
+#endif
+constexpr int kLog2Slots = KD_LOG2_SLOTS;
 constexpr int kSlots = 1 << kLog2Slots;
 constexpr int kLdsFillLimit = kSlots * 3 / 4;
-constexpr int kVmax = 2048;   // log-likelihood row staged in LDS when V <= kVmax
+constexpr int kVmax = KD_VMAX;  // log-likelihood row staged in LDS when V <= kVmax
 // the waves a four-wave team leaves idle fetch the next frame's row meanwhile
 constexpr int kLlLanes = KD_BLOCK - 256, kLlRegs = (kVmax + kLlLanes - 1) / kLlLanes;
 // ... a whole-workgroup team carries it in registers through the emitting filter
@@ -78,14 +95,14 @@ constexpr int kGroup = 4;     // queued tokens a wave scores at a time
 // of an HLG decode): the lower half of the table arrays is a 4096-slot table, the
 // upper half holds the first kQL entries of the candidate queue, and the frontier
 // itself (state, cost, arc range) stays in LDS from one frame to the next.
-constexpr int kT1Log2 = 12;
+constexpr int kT1Log2 = kLog2Slots - 1;
 constexpr int kT1Slots = 1 << kT1Log2;
-constexpr int kT1Front = 1024;
+constexpr int kT1Front = KD_T1_FRONT;
 constexpr int kT1Narrow = 0;  // ... of which frames up to this size run on four waves (0: never;
                                // measured slower on MI355X: fewer loads in flight per round trip)
-constexpr int kQL = 2048;
+constexpr int kQL = kT1Slots / 2;
 constexpr int kT1W16 = 512;    // tokens of at most 16 arcs (in Shared::hist)
-static_assert(kBlock >= 512 && kT1Front >= kBlock && kSlots == 2 * kT1Slots && 2 * kQL == kT1Slots,
+static_assert(kBlock >= 256 && kT1Front >= kBlock && kSlots == 2 * kT1Slots && 2 * kQL == kT1Slots,
               "tier-1 LDS overlay");
 constexpr unsigned long long kCostInf = 0xFFF0000000000000ull;  // CostKey(+inf)
 // Frame results besides 0 and the KD_UTT_* bits: run the table half again in the
@@ -150,7 +167,7 @@ struct Shared {
   long long lap_last;
 #endif
 };
-static_assert(sizeof(Shared) <= 163840, "LDS budget");
+static_assert(sizeof(Shared) <= 163840 / KD_WG_PER_CU, "LDS budget");
 
 // The workgroup's LDS block.  Functions that are not inlined into the kernel reach
 // it through this (an LDS pointer passed as an argument would become a flat one).
@@ -1814,7 +1831,8 @@ __device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long 
 }
 
 template <int M>
-__global__ __launch_bounds__(kBlock) void SearchKernel(const SearchParams p_by_value) {
+// (HIP's second bound is waves per SIMD: the workgroups sharing a CU spread over four)
+__global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) void SearchKernel(const SearchParams p_by_value) {
   Shared &s = Lds();
   (void)p_by_value;  // the only argument: it is the kernel-argument segment
   CParams &p = *(CParams *)__builtin_amdgcn_kernarg_segment_ptr();
