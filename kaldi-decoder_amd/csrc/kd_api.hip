@@ -228,6 +228,7 @@ struct kd_batch {
     p.use_final_probs = use_final;
     p.batch = batch;
     p.simple = simple ? 1 : 0;
+    p.no_backptr = lattice ? 1 : 0;
     p.tok_ac = tok_extra.p;
     p.final_rel = final_rel.p;
     p.reached_final = reached_final.p;
@@ -735,6 +736,10 @@ int kd_batch_reached_final(kd_batch *b, int32_t *out) {
 
 int kd_batch_best_path_prepare(kd_batch *b, int32_t use_final_probs, int32_t *path_len) {
   if (!b || !path_len) return Fail(KD_E_INVALID, "bad argument");
+  // lattice-simple-decoder.cc:574-580: the lattice decoders' best path is the shortest
+  // path through the raw lattice; their tokens carry forward links, not back-pointers
+  if (b->lattice)
+    return Fail(KD_E_STATE, "a lattice batch has no back-pointers: use kd_batch_raw_lattice_*");
   if (int r = PreparePath(b, use_final_probs ? 1 : 0)) return r;
   for (int i = 0; i < b->batch; ++i) path_len[i] = b->h_path_len[i];
   return KD_OK;

@@ -164,6 +164,7 @@ struct PathParams {
   int32_t use_final_probs;
   int32_t batch;
   int32_t simple;            // SimpleDecoder: per-arc costs are the stored ones
+  int32_t no_backptr;        // lattice batches keep forward links, not back-pointers: no walk
   const float *tok_ac;       // [arena] acoustic cost of the arc that made each token (simple mode)
   float *final_rel;          // [batch] FinalRelativeCost (simple-decoder.cc:78-100)
   // outputs of the prepare step

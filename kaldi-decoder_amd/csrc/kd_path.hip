@@ -79,7 +79,8 @@ __global__ __launch_bounds__(kPathBlock) void PathPrepareKernel(const PathParams
     float fw = 0.f;
     if (bt >= 0) {
       len = 0;
-      for (long long t = bt; t >= 0 && p.tok_arc[t] != static_cast<int32_t>(kArcNone); t = p.tok_prev[t]) len++;
+      if (!p.no_backptr)
+        for (long long t = bt; t >= 0 && p.tok_arc[t] != static_cast<int32_t>(kArcNone); t = p.tok_prev[t]) len++;
       if (is_final && p.use_final_probs) fw = p.states[p.tok_state[bt]].final_cost;  // :416-421
     }
     {

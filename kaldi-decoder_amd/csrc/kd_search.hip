@@ -1047,22 +1047,27 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
   uint32_t lg_h[kQRegs], lg_arc[kQRegs];
 #pragma unroll
   for (int u = 0; u < kQRegs; ++u) {
-    const int i = u * kBlock + tid;
     lg_h[u] = kKeyEmpty;
     lg_arc[u] = 0;
-    if (i < n_q) {
-      const uint32_t h = c.q_h[i];
-      if (h != kKeyEmpty && t.LoadCost(h) == c.q_nk[i]) {
-        const uint32_t aidx = c.q_arc[i];
-        atomicMin(t.ArcP(h), aidx);
-        lg_h[u] = h;
-        lg_arc[u] = aidx;
+  }
+  if constexpr (M != 1) {  // (lattice tokens keep forward links, not back-pointers)
+#pragma unroll
+    for (int u = 0; u < kQRegs; ++u) {
+      const int i = u * kBlock + tid;
+      if (i < n_q) {
+        const uint32_t h = c.q_h[i];
+        if (h != kKeyEmpty && t.LoadCost(h) == c.q_nk[i]) {
+          const uint32_t aidx = c.q_arc[i];
+          atomicMin(t.ArcP(h), aidx);
+          lg_h[u] = h;
+          lg_arc[u] = aidx;
+        }
       }
     }
-  }
-  for (int i = kQRegs * kBlock + tid; i < n_q; i += kBlock) {
-    const uint32_t h = c.q_h[i];
-    if (h != kKeyEmpty && t.LoadCost(h) == c.q_nk[i]) atomicMin(t.ArcP(h), c.q_arc[i]);
+    for (int i = kQRegs * kBlock + tid; i < n_q; i += kBlock) {
+      const uint32_t h = c.q_h[i];
+      if (h != kKeyEmpty && t.LoadCost(h) == c.q_nk[i]) atomicMin(t.ArcP(h), c.q_arc[i]);
+    }
   }
   if (tid == 0) {
     // each utterance owns arena[utt * arena_cap, (utt + 1) * arena_cap)
@@ -1133,15 +1138,17 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
       ToG(p.tok_arc)[g] = static_cast<int32_t>(aidx);
       if (c.simple) ToG(p.tok_extra)[g] = c.q_ac[i];  // the arc's stored acoustic cost
     };
+    if constexpr (M != 1) {
 #pragma unroll
-    for (int u = 0; u < kQRegs; ++u)
-      if (lg_h[u] != kKeyEmpty && t.LoadArc(lg_h[u]) == lg_arc[u])
-        write_bp(lg_h[u], lg_arc[u], u * kBlock + tid);
-    for (int i = kQRegs * kBlock + tid; i < n_q; i += kBlock) {
-      const uint32_t h = c.q_h[i];
-      if (h == kKeyEmpty) continue;
-      const uint32_t aidx = c.q_arc[i];
-      if (t.LoadCost(h) == c.q_nk[i] && t.LoadArc(h) == aidx) write_bp(h, aidx, i);
+      for (int u = 0; u < kQRegs; ++u)
+        if (lg_h[u] != kKeyEmpty && t.LoadArc(lg_h[u]) == lg_arc[u])
+          write_bp(lg_h[u], lg_arc[u], u * kBlock + tid);
+      for (int i = kQRegs * kBlock + tid; i < n_q; i += kBlock) {
+        const uint32_t h = c.q_h[i];
+        if (h == kKeyEmpty) continue;
+        const uint32_t aidx = c.q_arc[i];
+        if (t.LoadCost(h) == c.q_nk[i] && t.LoadArc(h) == aidx) write_bp(h, aidx, i);
+      }
     }
   }
   KD_LAP(s, 16);
@@ -1534,9 +1541,11 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // lowest arc index
   const int n_q = q_begin;
   const int n_out = Uni(s.n_live);
-  for (int i = tid; i < n_q; i += nt) {
-    const uint32_t h = q_h(i);
-    if (h != kKeyEmpty && s.cost[h] == q_nk(i)) atomicMin(&s.arc[h], q_arc(i));
+  if constexpr (M != 1) {  // (lattice tokens keep forward links, not back-pointers)
+    for (int i = tid; i < n_q; i += nt) {
+      const uint32_t h = q_h(i);
+      if (h != kKeyEmpty && s.cost[h] == q_nk(i)) atomicMin(&s.arc[h], q_arc(i));
+    }
   }
   long long base_out;
   {
@@ -1586,16 +1595,18 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   }
   KD_LAP(s, 11);
   // ---- R2: the winning entry of each slot writes the back-pointer
-  for (int i = tid; i < n_q; i += nt) {
-    const uint32_t h = q_h(i);
-    if (h == kKeyEmpty) continue;
-    const uint32_t aidx = q_arc(i);
-    if (s.cost[h] == q_nk(i) && s.arc[h] == aidx) {
-      const long long g = base_out + s.key[h];
-      const uint32_t sr = q_src(i);
-      const long long prev = (sr & kSrcEps) ? base_out + s.key[sr & ~kSrcEps] : c.base_in + sr;
-      ToG(p.tok_prev)[g] = static_cast<int32_t>(prev);
-      ToG(p.tok_arc)[g] = static_cast<int32_t>(aidx);
+  if constexpr (M != 1) {
+    for (int i = tid; i < n_q; i += nt) {
+      const uint32_t h = q_h(i);
+      if (h == kKeyEmpty) continue;
+      const uint32_t aidx = q_arc(i);
+      if (s.cost[h] == q_nk(i) && s.arc[h] == aidx) {
+        const long long g = base_out + s.key[h];
+        const uint32_t sr = q_src(i);
+        const long long prev = (sr & kSrcEps) ? base_out + s.key[sr & ~kSrcEps] : c.base_in + sr;
+        ToG(p.tok_prev)[g] = static_cast<int32_t>(prev);
+        ToG(p.tok_arc)[g] = static_cast<int32_t>(aidx);
+      }
     }
   }
   KD_LAP(s, 16);
