@@ -226,10 +226,13 @@ struct Counters {
 // build executes no stamps.
 // -DKD_PROF_T1 details the LDS-resident small frames and lumps the others into
 // bucket 14; the default details the others and lumps the small frames into 19.
-#ifdef KD_PROF_T1
-constexpr int kBucketSmall = -1, kBucketBig = 14;
+// -DKD_PROF_SPILL details the global-table halves of the spill frames instead.
+#if defined(KD_PROF_T1)
+constexpr int kBucketSmall = -1, kBucketBig = 14, kBucketSpill = 14;
+#elif defined(KD_PROF_SPILL)
+constexpr int kBucketSmall = 19, kBucketBig = 19, kBucketSpill = -1;
 #else
-constexpr int kBucketSmall = 19, kBucketBig = -1;
+constexpr int kBucketSmall = 19, kBucketBig = -1, kBucketSpill = 14;
 #endif
 #ifdef KD_PROFILE
 #define KD_LAP(s, i)                                                              \
@@ -636,7 +639,7 @@ __device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int par, int nq, R
 template <bool LDS, bool EPS, int M>
 __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t, int n_items,
                                        const KD_G uint32_t *wl_in, Counters &cnt) {
-  constexpr int KD_BUCKET = LDS ? kBucketBig : 14;
+  constexpr int KD_BUCKET = LDS ? kBucketBig : kBucketSpill;
   (void)KD_BUCKET;
   CParams &p = c.p;
   Shared &s = c.s;
@@ -986,7 +989,7 @@ __device__ __forceinline__ void ClearLive(const FrameCtx<M> &c, const Table<LDS>
 template <bool LDS, int M>
 __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &t, int frame,
                                               int q_emit, Counters &cnt) {
-  constexpr int KD_BUCKET = LDS ? kBucketBig : 14;
+  constexpr int KD_BUCKET = LDS ? kBucketBig : kBucketSpill;
   (void)KD_BUCKET;
   CParams &p = c.p;
   Shared &s = c.s;

@@ -24,7 +24,7 @@ def run(name, g, lex, T, B, lattice, **opts):
         print("   cycles/frame by bucket:", " ".join("%d:%d" % (i, v) for i, v in enumerate(cyc) if v >= 1), "total", int(cyc.sum()))
 
 T = 1000
-for lattice in (False,):
+for lattice in (False, True):
     kw = dict(lattice_beam=8.0) if lattice else {}
     run("H8 beam 2", synth.ctc_topo(8), None, T, 1, lattice, beam=2.0, **kw)
     run("H500 beam 8", synth.ctc_topo(500), None, T, 1, lattice, beam=8.0, **kw)
