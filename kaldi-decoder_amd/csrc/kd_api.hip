@@ -81,7 +81,7 @@ struct kd_batch {
   int32_t lat_use_final = -1;
   kd_lattice_options lo{};
   int64_t link_cap = 0;  // per utterance
-  DevBuf<float> g_log_ac, g_log_gr, tok_extra, link_ac, link_graph, lat_frc, lat_fbc;
+  DevBuf<float> g_log_ac, g_log_gr, tok_extra, link_ac, link_graph, link_delta, lat_frc, lat_fbc;
   DevBuf<int32_t> link_src, link_dst, link_arc, link_emit_count, link_eps_count, tok_newid,
       lat_any_final, lat_sizes;
   DevBuf<long long> link_emit_base, link_eps_base, lat_state_off, lat_arc_off, lat_final_off;
@@ -165,6 +165,7 @@ struct kd_batch {
     p.link_arc = link_arc.p;
     p.link_ac = link_ac.p;
     p.link_graph = link_graph.p;
+    p.link_delta = link_delta.p;
     p.link_cap = static_cast<unsigned long long>(link_cap);
     p.link_top = link_top.p;
     p.link_emit_base = link_emit_base.p;
@@ -193,6 +194,7 @@ struct kd_batch {
     p.link_arc = link_arc.p;
     p.link_ac = link_ac.p;
     p.link_graph = link_graph.p;
+    p.link_delta = link_delta.p;
     p.link_emit_base = link_emit_base.p;
     p.link_emit_count = link_emit_count.p;
     p.link_eps_base = link_eps_base.p;
@@ -486,6 +488,7 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
     A2(b->link_arc.Alloc(nl));
     A2(b->link_ac.Alloc(nl));
     A2(b->link_graph.Alloc(nl));
+    A2(b->link_delta.Alloc(nl));
     A2(b->link_top.Alloc(max_batch));
     A2(b->link_emit_base.Alloc(nf));
     A2(b->link_emit_count.Alloc(nf));

@@ -103,6 +103,7 @@ struct SearchParams {
   int32_t *link_arc;
   float *link_ac;
   float *link_graph;
+  float *link_delta;  // (src.tot + ac + graph) - dst.tot, the constant of lattice-simple-decoder.cc:257-260
   unsigned long long link_cap;
   unsigned long long *link_top;  // [batch] next free link (absolute index)
   // per utterance [max_frames + 1]: links leaving frame f's tokens
@@ -130,6 +131,7 @@ struct LatticeParams {
   const int32_t *link_arc;
   const float *link_ac;
   const float *link_graph;
+  const float *link_delta;
   const long long *link_emit_base;
   const int32_t *link_emit_count;
   const long long *link_eps_base;

@@ -28,6 +28,7 @@ constexpr int kLBlock = 1024;
 constexpr int kLWaves = kLBlock / 64;
 constexpr int kLdsToks = 36864;  // extra-cost keys of one frame kept in LDS (144 KiB)
 constexpr uint32_t kFInfKey = 0xFF800000u;  // FloatKey(+inf)
+constexpr int kEpsRegs = 4;  // epsilon links of a frame a lane keeps in registers
 
 #define KD_G __attribute__((address_space(1)))
 template <class T>
@@ -81,12 +82,10 @@ __device__ __forceinline__ void ApplyLinks(const LatticeParams &p, LShared &s, K
     const int32_t dst = ToG(p.link_dst)[at];
     if (dst < 0) continue;  // already excised
     const int32_t src = ToG(p.link_src)[at];
-    const float tok_tot = static_cast<float>(ToG(p.tok_cost)[src]);
-    const float next_tot = static_cast<float>(ToG(p.tok_cost)[dst]);
     const float next_extra = ToG(p.tok_extra)[dst];
-    // lattice-simple-decoder.cc:257-260
-    float link_extra_cost =
-        next_extra + ((tok_tot + ToG(p.link_ac)[at] + ToG(p.link_graph)[at]) - next_tot);
+    // lattice-simple-decoder.cc:257-260; (tok.tot + ac + graph) - next.tot was
+    // taken when the link was made (both costs were final then)
+    float link_extra_cost = next_extra + ToG(p.link_delta)[at];
     if (link_extra_cost > p.lattice_beam) {  // :264 excise
       ToG(p.link_dst)[at] = -1;
       continue;
@@ -141,15 +140,130 @@ __global__ __launch_bounds__(kLBlock) void LatticePruneKernel(const LatticeParam
   }
   if (p.stats_only) return;
 
+  const uint32_t *next_b = nullptr;  // the next frame's final extras, while they are in LDS
+  long long next_base = 0;
+  // frame descriptors are fetched one frame ahead
+  struct Desc { long long base, eb, pb; int n, en, pn; };
+  auto describe = [&](int f) {
+    Desc d;
+    d.base = ToG(p.frame_base)[fb + f];
+    d.n = ToG(p.frame_count)[fb + f];
+    d.eb = f == F ? 0 : ToG(p.link_emit_base)[fb + f];
+    d.en = f == F ? 0 : ToG(p.link_emit_count)[fb + f];
+    d.pb = ToG(p.link_eps_base)[fb + f];
+    d.pn = ToG(p.link_eps_count)[fb + f];
+    return d;
+  };
+  Desc ahead = describe(F);
   for (int f = F; f >= 0; --f) {
-    const long long base = ToG(p.frame_base)[fb + f];
-    const int n = ToG(p.frame_count)[fb + f];
+    const Desc d = ahead;
+    if (f > 0) ahead = describe(f - 1);
+    const long long base = d.base;
+    const int n = d.n;
     const bool last = f == F;
+    const long long eb = d.eb;
+    const int en = d.en;
+    const long long pb = d.pb;
+    const int pn = d.pn;
+    if (3 * n <= kLdsToks / 2 && pn <= kEpsRegs * kLBlock) {
+      // The frame's fixpoint entirely in LDS.  Emitting links end in the next
+      // frame, whose extras are final: their contribution (A) is computed once.
+      // Epsilon links are fetched once into registers; each round recomputes
+      // C = min(A, epsilon links over the current estimate B) and B := C, as the
+      // loop below does through global memory.  Frames alternate between the two
+      // halves of the key array, so the next frame's extras are still there.
+      uint32_t *half = s.ne + (f & 1) * (kLdsToks / 2);
+      uint32_t *A = half, *B = half + n, *C = half + 2 * n;
+      for (int i = tid; i < n; i += kLBlock) {
+        uint32_t k = kFInfKey;
+        if (last) {  // the token's own final term (:467)
+          const float tot = static_cast<float>(ToG(p.tok_cost)[base + i]);
+          const float fc =
+              any_final ? ToG(p.states)[ToG(p.tok_state)[base + i]].final_cost : 0.0f;
+          k = FloatKey(tot + fc - final_best_cost);
+        }
+        A[i] = k;
+        B[i] = FloatKey(0.0f);  // tok_extra as the search left it
+      }
+      // this lane's epsilon links: source, destination (frame-relative) and the
+      // cost difference of :257-260
+      int e_src[kEpsRegs], e_dst[kEpsRegs];
+      float e_delta[kEpsRegs];
+#pragma unroll
+      for (int r = 0; r < kEpsRegs; ++r) {
+        const int i = tid + r * kLBlock;
+        e_src[r] = -1;
+        e_dst[r] = -1;
+        e_delta[r] = 0.0f;
+        if (i < pn) {
+          const long long at = pb + i;
+          const int32_t dst = ToG(p.link_dst)[at];
+          const int32_t src = ToG(p.link_src)[at];
+          const float delta = ToG(p.link_delta)[at];
+          if (dst >= 0) {
+            e_delta[r] = delta;
+            e_src[r] = static_cast<int>(src - base);
+            e_dst[r] = static_cast<int>(dst - base);
+          }
+        }
+      }
+      __syncthreads();
+      // emitting links, into A
+      for (int i = tid; i < en; i += kLBlock) {
+        const long long at = eb + i;
+        const int32_t dst = ToG(p.link_dst)[at];
+        const int32_t src = ToG(p.link_src)[at];
+        const float delta = ToG(p.link_delta)[at];
+        if (dst < 0) continue;  // already excised
+        const float next_extra = next_b ? KeyFloat(next_b[dst - next_base]) : ToG(p.tok_extra)[dst];
+        float link_extra_cost = next_extra + delta;  // :257-260
+        if (link_extra_cost > p.lattice_beam) {  // :264 excise
+          ToG(p.link_dst)[at] = -1;
+          continue;
+        }
+        if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
+        atomicMin(&A[src - base], FloatKey(link_extra_cost));
+      }
+      __syncthreads();
+      while (true) {
+        for (int i = tid; i < n; i += kLBlock) C[i] = A[i];
+        if (tid == 0) s.changed = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kEpsRegs; ++r) {
+          if (e_src[r] < 0) continue;
+          float link_extra_cost = KeyFloat(B[e_dst[r]]) + e_delta[r];
+          if (link_extra_cost > p.lattice_beam) {  // :264 excise
+            ToG(p.link_dst)[pb + tid + r * kLBlock] = -1;
+            e_src[r] = -1;
+            continue;
+          }
+          if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
+          atomicMin(&C[e_src[r]], FloatKey(link_extra_cost));
+        }
+        __syncthreads();
+        int ch = 0;
+        for (int i = tid; i < n; i += kLBlock) {
+          float v = KeyFloat(C[i]);
+          if (last && v > p.lattice_beam) v = Inf();  // :507-509
+          const uint32_t k = FloatKey(v);
+          if (k != B[i]) { B[i] = k; ch = 1; }
+        }
+        if (ch) s.changed = 1;
+        __syncthreads();
+        const int changed = s.changed;
+        __syncthreads();
+        // without epsilon links nothing in this frame depends on this frame
+        if (!changed || pn == 0) break;
+      }
+      for (int i = tid; i < n; i += kLBlock) ToG(p.tok_extra)[base + i] = KeyFloat(B[i]);
+      next_b = B;
+      next_base = base;
+      __syncthreads();
+      continue;
+    }
+    next_b = nullptr;  // this frame's extras go to global memory only
     const bool ne_in_lds = n <= kLdsToks;
-    const long long eb = last ? 0 : ToG(p.link_emit_base)[fb + f];
-    const int en = last ? 0 : ToG(p.link_emit_count)[fb + f];
-    const long long pb = ToG(p.link_eps_base)[fb + f];
-    const int pn = ToG(p.link_eps_count)[fb + f];
     while (true) {
       // start value: +inf, or for the last frame the token's own final term (:467)
       for (int i = tid; i < n; i += kLBlock) {
@@ -192,6 +306,50 @@ __device__ __forceinline__ bool Alive(const LatticeParams &p, long long g) {
   return !p.finalized || ToG(p.tok_extra)[g] != Inf();
 }
 
+// GetRawLattice numbers the live tokens frame by frame (:611-622).  Frames do not
+// depend on one another here, so the waves of the workgroup take frames
+// independently (a wave needs no barrier to rank the tokens of its frame: ballot
+// and popcount), and the links are one flat, frame-less range.
+//
+// Per-frame counts / id offsets live in LDS (the prune kernel's key array), or in
+// the utterance's global scratch when there are more frames than that.
+__device__ __forceinline__ uint32_t *FrameWords(const LatticeParams &p, LShared &s, int utt, int F) {
+  return F + 1 <= kLdsToks ? s.ne : ToFlat(ToG(p.scratch) + utt * p.scratch_stride);
+}
+
+// Calls visit(frame f, token i, alive, rank among the frame's live tokens so far)
+// for every token of the frames this wave owns; returns nothing.  kT tokens per
+// lane are fetched before any is ranked.
+template <class Visit>
+__device__ __forceinline__ void ForWaveFrames(const LatticeParams &p, int utt, int F, Visit visit) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long fb = static_cast<long long>(utt) * (p.max_frames + 1);
+  constexpr int kT = 4;
+  for (int f = wave; f <= F; f += kLWaves) {
+    const long long base = ToG(p.frame_base)[fb + f];
+    const int n = ToG(p.frame_count)[fb + f];
+    int before = 0;
+    for (int c0 = 0; c0 < n; c0 += 64 * kT) {
+      bool a[kT];
+#pragma unroll
+      for (int u = 0; u < kT; ++u) {
+        const int i = c0 + u * 64 + lane;
+        a[u] = i < n && Alive(p, base + i);
+      }
+#pragma unroll
+      for (int u = 0; u < kT; ++u) {
+        const int i = c0 + u * 64 + lane;
+        const unsigned long long m = __ballot(a[u]);
+        const int rank = before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+        if (i < n) visit(f, base + i, a[u], rank);
+        before += __popcll(m);
+      }
+    }
+    visit(f, -1ll, false, before);  // end of frame: `before` live tokens
+  }
+}
+
 __global__ __launch_bounds__(kLBlock) void LatticeCountKernel(const LatticeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   LShared &s = *reinterpret_cast<LShared *>(smem);
@@ -206,43 +364,53 @@ __global__ __launch_bounds__(kLBlock) void LatticeCountKernel(const LatticeParam
   }
   const long long fb = static_cast<long long>(utt) * (p.max_frames + 1);
   const bool any_final = ToG(p.any_final)[utt] != 0;
-  int next_id = 0;
-  for (int f = 0; f <= F; ++f) {
-    const long long base = ToG(p.frame_base)[fb + f];
-    const int n = ToG(p.frame_count)[fb + f];
-    int frame_alive = 0;
-    for (int c0 = 0; c0 < n; c0 += kLBlock) {
-      const int i = c0 + tid;
-      const bool a = i < n && Alive(p, base + i);
-      int tot;
-      const int off = BlockExclScanI(s, a ? 1 : 0, tot);
-      if (i < n) {
-        const int id = a ? next_id + off : -1;
-        ToG(p.tok_newid)[base + i] = id;
-        if (a) {
-          if (f == 0 && ToG(p.tok_state)[base + i] == p.start) s.start_id = id;
-          if (f == F) {
-            const float fc = ToG(p.states)[ToG(p.tok_state)[base + i]].final_cost;
-            if (!(p.use_final_probs && any_final) || fc != Inf()) atomicAdd(&s.n_finals, 1);
-          }
-        }
-      }
-      next_id += tot;
-      frame_alive += tot;
+  uint32_t *fw = FrameWords(p, s, utt, F);
+  // live tokens per frame
+  ForWaveFrames(p, utt, F, [&](int f, long long g, bool, int rank) {
+    if (g < 0 && (threadIdx.x & 63) == 0) {
+      fw[f] = static_cast<uint32_t>(rank);
+      if (rank == 0) s.empty_frame = 1;  // :615-619
     }
-    if (frame_alive == 0 && tid == 0) s.empty_frame = 1;  // :615-619
-    auto count_links = [&](long long lb, int ln) {
-      int c = 0;
-      for (int i = tid; i < ln; i += kLBlock) c += ToG(p.link_dst)[lb + i] >= 0;
-      if (c) atomicAdd(&s.n_arcs, c);
-    };
-    if (f < F) count_links(ToG(p.link_emit_base)[fb + f], ToG(p.link_emit_count)[fb + f]);
-    count_links(ToG(p.link_eps_base)[fb + f], ToG(p.link_eps_count)[fb + f]);
+  });
+  __syncthreads();
+  // first id of each frame (exclusive scan over the frames)
+  int carry = 0;
+  for (int f0 = 0; f0 <= F; f0 += kLBlock) {
+    const int f = f0 + tid;
+    const int v = f <= F ? static_cast<int>(fw[f]) : 0;
+    int tot;
+    const int off = BlockExclScanI(s, v, tot);
+    if (f <= F) fw[f] = static_cast<uint32_t>(carry + off);
+    carry += tot;
+  }
+  __syncthreads();
+  // ids, the start state, the final states
+  ForWaveFrames(p, utt, F, [&](int f, long long g, bool alive, int rank) {
+    if (g < 0) return;
+    const int id = alive ? static_cast<int>(fw[f]) + rank : -1;
+    ToG(p.tok_newid)[g] = id;
+    if (!alive) return;
+    if (f == 0 && ToG(p.tok_state)[g] == p.start) s.start_id = id;
+    if (f == F) {
+      const float fc = ToG(p.states)[ToG(p.tok_state)[g]].final_cost;
+      if (!(p.use_final_probs && any_final) || fc != Inf()) atomicAdd(&s.n_finals, 1);
+    }
+  });
+  // surviving links: one flat range per utterance (frame 0's epsilon links come
+  // first, frame F's epsilon links last)
+  {
+    const long long l0 = ToG(p.link_eps_base)[fb];
+    const long long l1 = ToG(p.link_eps_base)[fb + F] + ToG(p.link_eps_count)[fb + F];
+    int c = 0;
+    for (long long at = l0 + tid; at < l1; at += kLBlock) c += ToG(p.link_dst)[at] >= 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((tid & 63) == 0 && c) atomicAdd(&s.n_arcs, c);
   }
   __syncthreads();
   if (tid == 0) {
     if (s.empty_frame) { sz[0] = 0; sz[1] = 0; sz[2] = 0; sz[3] = -1; }
-    else { sz[0] = next_id; sz[1] = s.n_arcs; sz[2] = s.n_finals; sz[3] = s.start_id; }
+    else { sz[0] = carry; sz[1] = s.n_arcs; sz[2] = s.n_finals; sz[3] = s.start_id; }
   }
 }
 
@@ -258,47 +426,61 @@ __global__ __launch_bounds__(kLBlock) void LatticeFillKernel(const LatticeParams
                   fo = ToG(p.out_final_off)[utt];
   if (tid == 0) { s.n_arcs = 0; s.n_finals = 0; }
   __syncthreads();
-  for (int f = 0; f <= F; ++f) {
-    const long long base = ToG(p.frame_base)[fb + f];
-    const int n = ToG(p.frame_count)[fb + f];
-    for (int i = tid; i < n; i += kLBlock) {
-      const int id = ToG(p.tok_newid)[base + i];
-      if (id < 0) continue;
-      const int32_t st = ToG(p.tok_state)[base + i];
-      ToG(p.o_state_frame)[so + id] = f;
-      ToG(p.o_state_graph)[so + id] = st;
-      if (f == F) {
-        const float fc = ToG(p.states)[st].final_cost;
-        if (p.use_final_probs && any_final) {  // :645-652
-          if (fc != Inf()) {
+  // states (and final weights): frames are independent, one wave each
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int f = wave; f <= F; f += kLWaves) {
+      const long long base = ToG(p.frame_base)[fb + f];
+      const int n = ToG(p.frame_count)[fb + f];
+      for (int i = lane; i < n; i += 64) {
+        const int id = ToG(p.tok_newid)[base + i];
+        if (id < 0) continue;
+        const int32_t st = ToG(p.tok_state)[base + i];
+        ToG(p.o_state_frame)[so + id] = f;
+        ToG(p.o_state_graph)[so + id] = st;
+        if (f == F) {
+          const float fc = ToG(p.states)[st].final_cost;
+          if (p.use_final_probs && any_final) {  // :645-652
+            if (fc != Inf()) {
+              const int k = atomicAdd(&s.n_finals, 1);
+              ToG(p.o_final_state)[fo + k] = id;
+              ToG(p.o_final_graph)[fo + k] = fc;
+            }
+          } else {
             const int k = atomicAdd(&s.n_finals, 1);
             ToG(p.o_final_state)[fo + k] = id;
-            ToG(p.o_final_graph)[fo + k] = fc;
+            ToG(p.o_final_graph)[fo + k] = 0.0f;
           }
-        } else {
-          const int k = atomicAdd(&s.n_finals, 1);
-          ToG(p.o_final_state)[fo + k] = id;
-          ToG(p.o_final_graph)[fo + k] = 0.0f;
         }
       }
     }
-    auto fill_links = [&](long long lb, int ln) {
-      for (int i = tid; i < ln; i += kLBlock) {
-        const long long at = lb + i;
-        const int32_t dst = ToG(p.link_dst)[at];
-        if (dst < 0) continue;
+  }
+  // arcs: the utterance's links as one flat range, four per lane in flight
+  {
+    const long long l0 = ToG(p.link_eps_base)[fb];
+    const long long l1 = ToG(p.link_eps_base)[fb + F] + ToG(p.link_eps_count)[fb + F];
+    constexpr int kT = 4;
+    for (long long a0 = l0 + tid; a0 < l1; a0 += kT * kLBlock) {
+      int32_t dst[kT];
+#pragma unroll
+      for (int u = 0; u < kT; ++u) {
+        const long long at = a0 + u * kLBlock;
+        dst[u] = at < l1 ? ToG(p.link_dst)[at] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kT; ++u) {
+        if (dst[u] < 0) continue;
+        const long long at = a0 + u * kLBlock;
         const int k = atomicAdd(&s.n_arcs, 1);
         const int32_t arc = ToG(p.link_arc)[at];
         ToG(p.o_src)[ao + k] = ToG(p.tok_newid)[ToG(p.link_src)[at]];
-        ToG(p.o_dst)[ao + k] = ToG(p.tok_newid)[dst];
+        ToG(p.o_dst)[ao + k] = ToG(p.tok_newid)[dst[u]];
         ToG(p.o_ilabel)[ao + k] = ToG(p.arcs)[arc].ilabel;
         ToG(p.o_olabel)[ao + k] = ToG(p.arcs)[arc].olabel;
         ToG(p.o_graph)[ao + k] = ToG(p.link_graph)[at];
         ToG(p.o_ac)[ao + k] = ToG(p.link_ac)[at];
       }
-    };
-    if (f < F) fill_links(ToG(p.link_emit_base)[fb + f], ToG(p.link_emit_count)[fb + f]);
-    fill_links(ToG(p.link_eps_base)[fb + f], ToG(p.link_eps_count)[fb + f]);
+    }
   }
 }
 

@@ -1190,6 +1190,8 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
       ToG(p.link_arc)[at] = static_cast<int32_t>(aidx);
       ToG(p.link_ac)[at] = ac;
       ToG(p.link_graph)[at] = c.q_gr[i];
+      ToG(p.link_delta)[at] = static_cast<float>(KeyCost(c.q_nk[i])) -
+                              static_cast<float>(KeyCost(t.LoadCost(h)));
     }
   }
   KD_LAP(s, 17);
@@ -1642,6 +1644,8 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       ToG(p.link_arc)[at] = static_cast<int32_t>(q_arc(i));
       ToG(p.link_ac)[at] = ac;
       ToG(p.link_graph)[at] = q_gr(i);
+      ToG(p.link_delta)[at] =
+          static_cast<float>(KeyCost(q_nk(i))) - static_cast<float>(KeyCost(s.cost[h]));
     }
   }
   KD_LAP(s, 17);
