@@ -87,8 +87,12 @@ struct kd_batch {
   DevBuf<long long> link_emit_base, link_eps_base, lat_state_off, lat_arc_off, lat_final_off;
   DevBuf<unsigned long long> link_top;
   DevBuf<uint32_t> lat_scratch;
-  DevBuf<int32_t> lo_src, lo_dst, lo_il, lo_ol, lo_sf, lo_sg, lo_fs;
-  DevBuf<float> lo_gc, lo_ac, lo_fg;
+  // GetRawLattice output: the ten arrays back to back in one device buffer, read
+  // back with one copy into pinned host memory
+  DevBuf<int32_t> lo_blob;
+  int32_t *lo_host = nullptr;
+  size_t lo_host_words = 0;
+  size_t lo_na = 0, lo_ns = 0, lo_nf = 0;  // layout of the blob: 6 x na, 2 x ns, 2 x nf words
   std::vector<int32_t> h_lat_sizes;
   DevBuf<UttDesc> utt;
   DevBuf<float> staging;
@@ -110,6 +114,7 @@ struct kd_batch {
   bool timed = false;
 
   ~kd_batch() {
+    if (lo_host) (void)hipHostFree(lo_host);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
   }
@@ -209,9 +214,14 @@ struct kd_batch {
     p.out_state_off = lat_state_off.p;
     p.out_arc_off = lat_arc_off.p;
     p.out_final_off = lat_final_off.p;
-    p.o_src = lo_src.p; p.o_dst = lo_dst.p; p.o_ilabel = lo_il.p; p.o_olabel = lo_ol.p;
-    p.o_state_frame = lo_sf.p; p.o_state_graph = lo_sg.p; p.o_final_state = lo_fs.p;
-    p.o_graph = lo_gc.p; p.o_ac = lo_ac.p; p.o_final_graph = lo_fg.p;
+    int32_t *w = lo_blob.p;
+    p.o_src = w; p.o_dst = w + lo_na; p.o_ilabel = w + 2 * lo_na; p.o_olabel = w + 3 * lo_na;
+    p.o_graph = reinterpret_cast<float *>(w + 4 * lo_na);
+    p.o_ac = reinterpret_cast<float *>(w + 5 * lo_na);
+    w += 6 * lo_na;
+    p.o_state_frame = w; p.o_state_graph = w + lo_ns;
+    w += 2 * lo_ns;
+    p.o_final_state = w; p.o_final_graph = reinterpret_cast<float *>(w + lo_nf);
     return p;
   }
 
@@ -914,45 +924,48 @@ int kd_batch_raw_lattice_copy(kd_batch *b, const int64_t *state_off, const int64
     nfn += b->h_lat_sizes[4 * i + 2];
   }
   if (ns == 0) return KD_OK;
-  hipError_t e = hipSuccess;
-  auto R = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-  R(b->lo_src.Reserve(na)); R(b->lo_dst.Reserve(na)); R(b->lo_il.Reserve(na));
-  R(b->lo_ol.Reserve(na)); R(b->lo_gc.Reserve(na)); R(b->lo_ac.Reserve(na));
-  R(b->lo_sf.Reserve(ns)); R(b->lo_sg.Reserve(ns)); R(b->lo_fs.Reserve(nfn));
-  R(b->lo_fg.Reserve(nfn));
-  if (e != hipSuccess) return Fail(KD_E_HIP, std::string("lattice output: ") + hipGetErrorString(e));
+  const size_t words = 6 * na + 2 * ns + 2 * nfn;
+  b->lo_na = na;
+  b->lo_ns = ns;
+  b->lo_nf = nfn;
+  if (hipError_t e = b->lo_blob.Reserve(words); e != hipSuccess)
+    return Fail(KD_E_HIP, std::string("lattice output: ") + hipGetErrorString(e));
+  if (b->lo_host_words < words) {
+    if (b->lo_host) (void)hipHostFree(b->lo_host);
+    b->lo_host = nullptr;
+    b->lo_host_words = 0;
+    const size_t want = words + words / 2;
+    if (hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&b->lo_host), want * 4, hipHostMallocDefault);
+        e != hipSuccess)
+      return Fail(KD_E_HIP, std::string("lattice output (host): ") + hipGetErrorString(e));
+    b->lo_host_words = want;
+  }
   KD_HIP_TRY(hipMemcpyAsync(b->lat_state_off.p, so.data(), b->batch * 8, hipMemcpyHostToDevice, b->stream));
   KD_HIP_TRY(hipMemcpyAsync(b->lat_arc_off.p, ao.data(), b->batch * 8, hipMemcpyHostToDevice, b->stream));
   KD_HIP_TRY(hipMemcpyAsync(b->lat_final_off.p, fo.data(), b->batch * 8, hipMemcpyHostToDevice, b->stream));
   LatticeParams p = b->LParams();
   p.use_final_probs = b->lat_use_final;
   KD_HIP_TRY(LaunchLatticeFill(p, b->batch, b->stream));
-  std::vector<int32_t> hsrc(na), hdst(na), hil(na), hol(na), hsf(ns), hsg(ns), hfs(nfn);
-  std::vector<float> hgc(na), hac(na), hfg(nfn);
-  auto D = [&](void *d, const void *s2, size_t bytes) {
-    if (bytes) R(hipMemcpyAsync(d, s2, bytes, hipMemcpyDeviceToHost, b->stream));
-  };
-  D(hsrc.data(), b->lo_src.p, na * 4); D(hdst.data(), b->lo_dst.p, na * 4);
-  D(hil.data(), b->lo_il.p, na * 4); D(hol.data(), b->lo_ol.p, na * 4);
-  D(hgc.data(), b->lo_gc.p, na * 4); D(hac.data(), b->lo_ac.p, na * 4);
-  D(hsf.data(), b->lo_sf.p, ns * 4); D(hsg.data(), b->lo_sg.p, ns * 4);
-  D(hfs.data(), b->lo_fs.p, nfn * 4); D(hfg.data(), b->lo_fg.p, nfn * 4);
-  if (e != hipSuccess) return Fail(KD_E_HIP, std::string("lattice copy: ") + hipGetErrorString(e));
+  KD_HIP_TRY(hipMemcpyAsync(b->lo_host, b->lo_blob.p, words * 4, hipMemcpyDeviceToHost, b->stream));
   KD_HIP_TRY(hipStreamSynchronize(b->stream));
+  const int32_t *hw = b->lo_host;
+  const int32_t *hsrc = hw, *hdst = hw + na, *hil = hw + 2 * na, *hol = hw + 3 * na;
+  const int32_t *hgc = hw + 4 * na, *hac = hw + 5 * na;
+  const int32_t *hsf = hw + 6 * na, *hsg = hsf + ns, *hfs = hsg + ns, *hfg = hfs + nfn;
   for (int i = 0; i < b->batch; ++i) {
     const size_t s1 = b->h_lat_sizes[4 * i], a1 = b->h_lat_sizes[4 * i + 1],
                  f1 = b->h_lat_sizes[4 * i + 2];
     auto C4 = [&](void *d, const void *s2, size_t n) { if (d && n) std::memcpy(d, s2, n * 4); };
-    C4(src ? src + arc_off[i] : nullptr, hsrc.data() + ao[i], a1);
-    C4(dst ? dst + arc_off[i] : nullptr, hdst.data() + ao[i], a1);
-    C4(ilabel ? ilabel + arc_off[i] : nullptr, hil.data() + ao[i], a1);
-    C4(olabel ? olabel + arc_off[i] : nullptr, hol.data() + ao[i], a1);
-    C4(graph_cost ? graph_cost + arc_off[i] : nullptr, hgc.data() + ao[i], a1);
-    C4(ac_cost ? ac_cost + arc_off[i] : nullptr, hac.data() + ao[i], a1);
-    C4(state_frame ? state_frame + state_off[i] : nullptr, hsf.data() + so[i], s1);
-    C4(state_graph ? state_graph + state_off[i] : nullptr, hsg.data() + so[i], s1);
-    C4(final_state ? final_state + final_off[i] : nullptr, hfs.data() + fo[i], f1);
-    C4(final_graph ? final_graph + final_off[i] : nullptr, hfg.data() + fo[i], f1);
+    C4(src ? src + arc_off[i] : nullptr, hsrc + ao[i], a1);
+    C4(dst ? dst + arc_off[i] : nullptr, hdst + ao[i], a1);
+    C4(ilabel ? ilabel + arc_off[i] : nullptr, hil + ao[i], a1);
+    C4(olabel ? olabel + arc_off[i] : nullptr, hol + ao[i], a1);
+    C4(graph_cost ? graph_cost + arc_off[i] : nullptr, hgc + ao[i], a1);
+    C4(ac_cost ? ac_cost + arc_off[i] : nullptr, hac + ao[i], a1);
+    C4(state_frame ? state_frame + state_off[i] : nullptr, hsf + so[i], s1);
+    C4(state_graph ? state_graph + state_off[i] : nullptr, hsg + so[i], s1);
+    C4(final_state ? final_state + final_off[i] : nullptr, hfs + fo[i], f1);
+    C4(final_graph ? final_graph + final_off[i] : nullptr, hfg + fo[i], f1);
   }
   return KD_OK;
 }

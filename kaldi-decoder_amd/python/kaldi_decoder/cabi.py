@@ -378,10 +378,10 @@ class LatticeBatch(Batch):
         so, ao, fo = (np.zeros(self.batch, np.int64) for _ in range(3))
         so[1:], ao[1:], fo[1:] = np.cumsum(sz[:-1, 0]), np.cumsum(sz[:-1, 1]), np.cumsum(sz[:-1, 2])
         ns, na, nf = (max(int(sz[:, k].sum()), 1) for k in range(3))
-        src, dst, il, ol = (np.zeros(na, np.int32) for _ in range(4))
-        gc, ac = np.zeros(na, np.float32), np.zeros(na, np.float32)
-        sf, sg = np.zeros(ns, np.int32), np.zeros(ns, np.int32)
-        fs, fg = np.zeros(nf, np.int32), np.zeros(nf, np.float32)
+        src, dst, il, ol = (np.empty(na, np.int32) for _ in range(4))
+        gc, ac = np.empty(na, np.float32), np.empty(na, np.float32)
+        sf, sg = np.empty(ns, np.int32), np.empty(ns, np.int32)
+        fs, fg = np.empty(nf, np.int32), np.empty(nf, np.float32)
         _check(lib().kd_batch_raw_lattice_copy(self.h, so, ao, fo, src, dst, il, ol, gc, ac, sf,
                                                sg, fs, fg))
         out = []
@@ -389,11 +389,10 @@ class LatticeBatch(Batch):
             a, b = int(ao[i]), int(ao[i] + sz[i, 1])
             s0, s1 = int(so[i]), int(so[i] + sz[i, 0])
             f0, f1 = int(fo[i]), int(fo[i] + sz[i, 2])
+            # (views into the batch's arrays: one allocation per field, not per utterance)
             out.append(RawLattice(bool(sz[i, 0] > 0), int(sz[i, 0]), int(sz[i, 3]),
-                                  src[a:b].copy(), dst[a:b].copy(), il[a:b].copy(),
-                                  ol[a:b].copy(), gc[a:b].copy(), ac[a:b].copy(),
-                                  sf[s0:s1].copy(), sg[s0:s1].copy(), fs[f0:f1].copy(),
-                                  fg[f0:f1].copy()))
+                                  src[a:b], dst[a:b], il[a:b], ol[a:b], gc[a:b], ac[a:b],
+                                  sf[s0:s1], sg[s0:s1], fs[f0:f1], fg[f0:f1]))
         return out
 
 
