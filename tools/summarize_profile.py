@@ -35,7 +35,7 @@ def counter(path, name):
             if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name]
     # the search kernel is launched once for InitDecoding (tiny) and once per step
     vals = sorted(float(r["Counter_Value"]) for r in rows)
-    big = [v for v in vals if v > 0.5 * vals[-1]]
+    big = vals[len(vals) // 2:]
     return sum(big) / len(big), len(big)
 
 
@@ -48,7 +48,7 @@ def main():
     shutil.copy(stats, os.path.join(out, f"{rnd}_kernel_stats.csv"))
     durs = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
                   for r in csv.DictReader(open(trace)) if KERNEL in r["Kernel_Name"])
-    adv = [d for d in durs if d > 0.5 * durs[-1]]
+    adv = durs[len(durs) // 2:]  # every step launches the kernel twice: InitDecoding (short), then the frames
     fetch_kb, nf = counter(one(f"prof_{rnd}_fetch/*/*_counter_collection.csv"), "FETCH_SIZE")
     write_kb, nw = counter(one(f"prof_{rnd}_write/*/*_counter_collection.csv"), "WRITE_SIZE")
     bench = {}
@@ -59,7 +59,7 @@ def main():
             bench = json.loads(txt[-1])
     summary = {
         "round": rnd,
-        "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu "
+        "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu "
                    "(+ one run each with --pmc FETCH_SIZE / --pmc WRITE_SIZE)",
         "kernel": KERNEL,
         "advance_launches": len(adv),
