@@ -89,8 +89,14 @@ constexpr int kVmax = KD_VMAX;  // log-likelihood row staged in LDS when V <= kV
 constexpr int kLlLanes = KD_BLOCK - 256, kLlRegs = (kVmax + kLlLanes - 1) / kLlLanes;
 // ... a whole-workgroup team carries it in registers through the emitting filter
 constexpr int kPfRegs = (kVmax + KD_BLOCK - 1) / KD_BLOCK;
-constexpr int kSmallDeg = 4;  // tokens with at most this many arcs stay on their lane
-constexpr int kGroup = 4;     // queued tokens a wave scores at a time
+#ifndef KD_SMALL_DEG
+#define KD_SMALL_DEG 4
+#endif
+#ifndef KD_GROUP
+#define KD_GROUP 4
+#endif
+constexpr int kSmallDeg = KD_SMALL_DEG;  // tokens with at most this many arcs stay on their lane
+constexpr int kGroup = KD_GROUP;  // queued tokens a wave scores at a time
 // Tier 1 (frames whose frontier is at most one token per lane -- 97% of the frames
 // of an HLG decode): the lower half of the table arrays is a 4096-slot table, the
 // upper half holds the first kQL entries of the candidate queue, and the frontier
