@@ -262,3 +262,26 @@ def test_simple_decoder_mode_matches_canonical_oracle(oracle):
             r = oracle.SimpleDecoder(OG, beam=beam)
             r.decode(lps[i])
             assert r.get_best_path().osyms.tolist() == paths[i].osyms.tolist()
+
+
+def test_candidate_queue_overflow_rescans_under_the_final_cutoff(oracle):
+    # dense CTC topology: every frame scores 300 x 300 arcs, far more than the candidate queue
+    # of a small spill table holds under the running cutoff; the frame is then scanned again
+    # under the final cutoff, which few arcs survive
+    g = synth.ctc_topo(300)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lp = synth.make_logprobs(8, 300, 0, peak=4.0)
+    opts = dict(beam=3.0, min_active=0)
+    bt = cabi.Batch(G, max_batch=1, table_slots=1 << 14, **opts)
+    bt.init_decoding()
+    bt.advance_host([lp])
+    d = oracle.FasterDecoder(OG, policy=1, **opts)
+    d.decode(lp)
+    for f in (1, 4, 8):
+        s, c = bt.frame_tokens(0, f)
+        dd = oracle.FasterDecoder(OG, policy=1, **opts)
+        dd.init_decoding()
+        dd.advance_decoding(lp, max_num_frames=f)
+        so, co = dd.tokens()
+        assert s.tolist() == so.tolist() and c.tolist() == co.tolist(), f
+    _assert_same_path(bt.best_paths()[0], d.get_best_path(), "rescan")

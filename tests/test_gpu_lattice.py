@@ -120,3 +120,41 @@ def test_lattice_frames_that_spill_to_the_global_table(oracle):
     assert gl.state_set() == cl.state_set()
     assert gl.arc_set() == cl.arc_set()
     assert len(gl.src) == len(cl.src)  # no duplicate arcs
+
+
+def test_bench_size_workload_matches_canonical_oracle(oracle):
+    # BASELINE configs[2] at full size (4.9 M states, beam 15, lattice beam 8, T = 250), a few
+    # utterances: every tier of the search runs here (frontiers from 1 to > 20 000 tokens)
+    import bench
+    wl = bench.WORKLOADS["hlg-lattice"]
+    g = synth.hlg_graph(**wl["graph"])
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T, V = 4, wl["frames"], wl["V"]
+    lps = [synth.make_logprobs(T, V, i, peak=12.0, lexicon=g["lexicon"]) for i in range(B)]
+    lb = cabi.LatticeBatch(G, max_batch=B, max_frames=T, **wl["opts"])
+    lb.init_decoding()
+    lb.advance_host(lps)
+    st = lb.stats()
+    assert st[:, 0].tolist() == [T] * B
+    assert st[:, 11].sum() > 0 and st[:, 9].sum() > 0  # LDS-resident frames and spill frames
+    lb.finalize_decoding()
+    lats = lb.raw_lattices()
+    frc = lb.final_relative_cost()
+    for i in range(B):
+        can = oracle.CanonLatticeDecoder(OG, **wl["opts"])
+        can.decode(lps[i])
+        cl = can.get_raw_lattice()
+        gl = lats[i]
+        assert gl.state_set() == cl.state_set(), i
+        assert gl.arc_set() == cl.arc_set() and len(gl.src) == len(cl.src), i
+        assert gl.final_set() == cl.final_set(), i
+        assert frc[i] == can.final_relative_cost(), i
+        # size-independent properties: frame-major numbering, every arc goes forward in time
+        # or stays in its frame, every state but the start has an incoming arc
+        assert np.all(np.diff(gl.state_frame) >= 0)
+        df = gl.state_frame[gl.dst] - gl.state_frame[gl.src]
+        assert np.all((df == 0) | (df == 1))
+        has_in = np.zeros(gl.num_states, bool)
+        has_in[gl.dst] = True
+        has_in[gl.start] = True
+        assert has_in.all()
