@@ -250,10 +250,10 @@ def hlg_graph(V=500, n_words=20000, n_hist=None, avg_succ=35, seed=2, max_len=6)
     return g
 
 
-def hidden_token_path(T, V, seed, lexicon=None, p_blank=0.6):
-    """Per-frame hot token: blank w.p. p_blank else the next token of a hidden
-    word sequence (or of a random token sequence when no lexicon is given)."""
+def _hidden(T, V, seed, lexicon=None, p_blank=0.6):
+    """(per-frame hot token, the hidden words whose tokens were all emitted)."""
     rng = np.random.default_rng(seed)
+    words, ends = [], []
     if lexicon is None:
         seq = rng.integers(1, V, T + 1)
     else:
@@ -264,11 +264,26 @@ def hidden_token_path(T, V, seed, lexicon=None, p_blank=0.6):
         while len(seq) < T + 1:
             wd = int(rng.choice(n_words, p=p)) + 1
             seq.extend(toks[wd, :lens[wd]].tolist())
+            words.append(wd)
+            ends.append(len(seq))
         seq = np.asarray(seq)
     is_blank = rng.random(T) < p_blank
     pos = np.cumsum(~is_blank) - 1
     hot = np.where(is_blank, 0, seq[np.clip(pos, 0, len(seq) - 1)])
-    return hot.astype(np.int64)
+    emitted = int((~is_blank).sum())
+    return hot.astype(np.int64), [w for w, e in zip(words, ends) if e <= emitted]
+
+
+def hidden_token_path(T, V, seed, lexicon=None, p_blank=0.6):
+    """Per-frame hot token: blank w.p. p_blank else the next token of a hidden
+    word sequence (or of a random token sequence when no lexicon is given)."""
+    return _hidden(T, V, seed, lexicon, p_blank)[0]
+
+
+def hidden_word_sequence(T, V, utt_id=0, lexicon=None, p_blank=0.6):
+    """The word ids behind make_logprobs(T, V, utt_id, lexicon=lexicon): the words whose
+    tokens the hot path emitted completely ([] without a lexicon)."""
+    return _hidden(T, V, 1000 + utt_id + 500000, lexicon, p_blank)[1]
 
 
 def make_logprobs(T, V, utt_id=0, peak=12.0, lexicon=None, p_blank=0.6):

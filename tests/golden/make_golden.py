@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz.
+
+PARITY UNPINNED: the reference ships no decoder tests or golden vectors and its
+decoders cannot be built in this image, so these vectors are
+outputs of oracle/ -- the CPU restatement of the reference -- on seeded synthetic
+inputs (the G1-G6 cases of SURVEY.md 8c).  They pin the oracle against drift and
+give the GPU path fixed expected outputs; they are not outputs of the reference.
+
+    python tests/golden/make_golden.py        # rewrites every fixture
+
+Each fixture holds the graph arrays, the log-prob matrix, the options and, per
+decoder, the outputs before any third-party post-processing: the linear best
+path's arcs (ilabel, olabel, state, graph cost, acoustic cost), the final weight,
+reached_final / num_frames_decoded, per-frame token counts, and for the lattice
+decoders the raw lattice as sorted arc rows.  `ref_*` keys come from the
+reference-order restatement (policy 0), `canon_*` keys from the order-free
+semantics the GPU implements.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "kaldi-decoder_amd", "python"))
+from kaldi_decoder import synth  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+GRAPH_KEYS = ("row_ptr", "ilabel", "olabel", "weight", "nextstate", "final")
+
+
+def path_arrays(prefix, p):
+    return {prefix + "ok": np.array(p.ok), prefix + "ilabel": p.ilabel, prefix + "olabel": p.olabel,
+            prefix + "state": p.state, prefix + "graph_cost": p.graph_cost,
+            prefix + "ac_cost": p.ac_cost,
+            prefix + "final_weight": np.asarray(p.final_weight, np.float32)}
+
+
+def lattice_rows(lat):
+    """The raw lattice without its state numbering: one row per arc (frame and graph state of
+    both ends, labels, costs), sorted."""
+    rows = sorted(lat.arc_set())
+    return np.array(rows, np.float64).reshape(len(rows), -1)
+
+
+def faster_case(name, g, lex, T, peak, opts, chunk=0, offset=0, utt=0):
+    V = int(g["ilabel"].max())
+    lp = synth.make_logprobs(T, V, utt, peak=peak, lexicon=lex)
+    out = {k: np.asarray(g[k]) for k in GRAPH_KEYS}
+    out.update(num_states=np.array(g["num_states"]), start=np.array(g["start"]), logprobs=lp,
+               opt_names=np.array(sorted(opts)), opt_values=np.array([opts[k] for k in sorted(opts)], np.float64),
+               chunk=np.array(chunk))
+    OG = oracle.Graph(g)
+    for tag, policy in (("ref_", 0), ("canon_", 1)):
+        d = oracle.FasterDecoder(OG, policy=policy, **opts)
+        d.init_decoding()
+        counts = [len(d.tokens()[0])]
+        for t in range(T):
+            d.advance_decoding(lp, max_num_frames=1)
+            counts.append(len(d.tokens()[0]))
+        out[tag + "tokens_per_frame"] = np.array(counts, np.int32)
+        out[tag + "reached_final"] = np.array(d.reached_final())
+        out[tag + "num_frames_decoded"] = np.array(d.num_frames_decoded())
+        for uf in (1, 0):
+            out.update(path_arrays(f"{tag}uf{uf}_", d.get_best_path(bool(uf))))
+        if policy == 1:
+            s, c = d.tokens()
+            out["canon_last_states"], out["canon_last_costs"] = s, c
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def lattice_case(name, g, lex, T, peak, opts, utt=0):
+    V = int(g["ilabel"].max())
+    lp = synth.make_logprobs(T, V, utt, peak=peak, lexicon=lex)
+    out = {k: np.asarray(g[k]) for k in GRAPH_KEYS}
+    out.update(num_states=np.array(g["num_states"]), start=np.array(g["start"]), logprobs=lp,
+               opt_names=np.array(sorted(opts)), opt_values=np.array([opts[k] for k in sorted(opts)], np.float64))
+    OG = oracle.Graph(g)
+    ref = oracle.LatticeSimpleDecoder(OG, beam=opts["beam"], lattice_beam=opts["lattice_beam"],
+                                      prune_interval=25)
+    ref.decode(lp)
+    out["ref_arcs"] = lattice_rows(ref.get_raw_lattice())
+    out["ref_final_relative_cost"] = np.array(ref.final_relative_cost(), np.float32)
+    can = oracle.CanonLatticeDecoder(OG, **opts)
+    can.decode(lp)
+    cl = can.get_raw_lattice()
+    out["canon_arcs"] = lattice_rows(cl)
+    out["canon_num_states"] = np.array(cl.num_states)
+    out["canon_final_relative_cost"] = np.array(can.final_relative_cost(), np.float32)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def main():
+    INT_MAX = 2**31 - 1
+    # G1: tiny CTC topologies
+    for V, T in ((8, 20), (32, 50)):
+        for beam in (4.0, 8.0, 15.0):
+            for ma in (INT_MAX, 8):
+                faster_case(f"g1_h{V}_b{int(beam)}_ma{'inf' if ma == INT_MAX else ma}", synth.ctc_topo(V),
+                            None, T, 6.0, dict(beam=beam, max_active=ma, min_active=0))
+    # G3: HL- and HLG-like graphs with epsilon arcs
+    g = synth.hl_graph(V=40, n_words=300, seed=3)
+    for beam, mi, ma in ((8.0, 0, INT_MAX), (15.0, 20, 300)):
+        faster_case(f"g3_hl_b{int(beam)}_mi{mi}", g, g["lexicon"], 60, 8.0,
+                    dict(beam=beam, min_active=mi, max_active=ma))
+    g = synth.hlg_graph(V=40, n_words=150, n_hist=150, avg_succ=8, seed=4)
+    for beam, mi in ((8.0, 0), (15.0, 20)):
+        faster_case(f"g3_hlg_b{int(beam)}_mi{mi}", g, g["lexicon"], 60, 8.0,
+                    dict(beam=beam, min_active=mi, max_active=INT_MAX))
+    # G5: nothing reaches a final state / nothing survives
+    g5 = synth.random_graph(120, 3.0, 16, 0.2, 77)
+    g5 = dict(g5)
+    g5["final"] = np.full_like(g5["final"], np.inf)
+    faster_case("g5_no_final", g5, None, 25, 5.0, dict(beam=6.0, min_active=0, max_active=INT_MAX))
+    # G6: raw lattices
+    g = synth.hlg_graph(V=30, n_words=100, n_hist=100, avg_succ=6, seed=6)
+    for lb in (4.0, 8.0):
+        lattice_case(f"g6_hlg_lb{int(lb)}", g, g["lexicon"], 50, 6.0,
+                     dict(beam=10.0, lattice_beam=lb, min_active=0))
+    lattice_case("g6_rand_lb3", synth.random_graph(200, 3.0, 16, 0.2, 301), None, 40, 5.0,
+                 dict(beam=7.0, lattice_beam=3.0, min_active=0))
+
+
+if __name__ == "__main__":
+    main()
