@@ -173,6 +173,12 @@ def main():
     ap.add_argument("--streams", type=int, default=6,
                     help="independent batches in flight per GPU (each step is still one batch of "
                          "B utterances; a batch occupies B of the 256 CUs)")
+    ap.add_argument("--arena-tokens-per-utt", type=int, default=0,
+                    help="token records reserved per utterance (0: the library default, 2^21)")
+    ap.add_argument("--arena-links-per-utt", type=int, default=0,
+                    help="lattice decoders: forward links reserved per utterance (0: default)")
+    ap.add_argument("--search-only", action="store_true",
+                    help="diagnostic: time InitDecoding + AdvanceDecoding only (not a bench line)")
     args = ap.parse_args()
 
     import torch
@@ -204,7 +210,13 @@ def main():
     n_streams = max(1, args.streams)
     streams = [torch.cuda.Stream() for _ in range(n_streams)]
     cls = cabi.LatticeBatch if wl["lattice"] else cabi.Batch
-    bts = [cls(G, max_batch=B, max_frames=T, stream=st.cuda_stream, **wl["opts"]) for st in streams]
+    cap = {}
+    if args.arena_tokens_per_utt:
+        cap["arena_tokens"] = B * args.arena_tokens_per_utt
+    if args.arena_links_per_utt and wl["lattice"]:
+        cap["arena_links"] = B * args.arena_links_per_utt
+    bts = [cls(G, max_batch=B, max_frames=T, stream=st.cuda_stream, **wl["opts"], **cap)
+           for st in streams]
     setup_s = time.time() - t0
 
     def step(bt):
@@ -212,6 +224,8 @@ def main():
         bt.advance_device(ptrs, rows, V, sync=False)
         bt.sync()
         k_ms = bt.last_kernel_ms()  # HIP events around the search kernel, on its stream
+        if args.search_only:
+            return None, k_ms
         if wl["lattice"]:
             bt.finalize_decoding()
             out = bt.raw_lattices()
@@ -222,7 +236,7 @@ def main():
     def deliver(out):
         # the only exchange between ranks: finished results go to rank 0.  Issued by
         # the main thread in step order so every rank runs its collectives alike.
-        if world > 1:
+        if world > 1 and out is not None:
             if wl["lattice"]:
                 sharded.gather_lattices(out, dst=0)
             else:
@@ -279,7 +293,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if rank == 0:
+    if rank == 0 and args.search_only:
+        print(json.dumps({"diagnostic": "search only", "ms_per_step": elapsed / args.steps * 1e3,
+                          "kernel_ms": float(np.mean(kernel_ms)), "streams": n_streams}))
+    elif rank == 0:
         stats = bt.stats()  # counters of the last step (reset by InitDecoding)
         alg_bytes, per_frame = algorithmic_bytes(stats, V)
         k_ms = float(np.mean(kernel_ms))

@@ -8,7 +8,7 @@
 //   LatticeCountKernel  sizes of GetRawLattice's output (:584-657) and the state
 //   LatticeFillKernel   numbering, then the arcs / final weights themselves
 //
-// One 1024-thread workgroup per utterance walks its frames backwards.  A frame's
+// One workgroup (KD_LBLOCK threads) per utterance walks its frames backwards.  A frame's
 // links are processed link-parallel: link_extra = next.extra + ((tok.tot + ac +
 // graph) - next.tot), links above lattice_beam are excised (dst = -1), the
 // survivors min-reduce into their source token's extra cost with ds_min_u32 on an
@@ -24,11 +24,26 @@
 namespace kd {
 namespace {
 
-constexpr int kLBlock = 1024;
+// Geometry knobs.  Measured on MI355X (B = 128, six batches in flight): 256-thread
+// workgroups with 48 KiB of LDS (three per CU) take 3.4 ms instead of 1.5 ms per
+// batch for the pruning pass and leave the throughput unchanged, so the shipped
+// configuration is one 1024-thread workgroup per CU; the export kernels only ask
+// for the LDS they use.
+#ifndef KD_LBLOCK
+#define KD_LBLOCK 1024
+#endif
+#ifndef KD_LLDS_TOKS
+#define KD_LLDS_TOKS 36864
+#endif
+#ifndef KD_LEPS_REGS
+#define KD_LEPS_REGS 4
+#endif
+constexpr int kLBlock = KD_LBLOCK;
 constexpr int kLWaves = kLBlock / 64;
-constexpr int kLdsToks = 36864;  // extra-cost keys of one frame kept in LDS (144 KiB)
+constexpr int kLdsToks = KD_LLDS_TOKS;  // extra-cost keys of one frame kept in LDS (144 KiB)
+constexpr int kFwToks = 4096;  // export kernels: per-frame words kept in LDS (16 KiB)
 constexpr uint32_t kFInfKey = 0xFF800000u;  // FloatKey(+inf)
-constexpr int kEpsRegs = 4;  // epsilon links of a frame a lane keeps in registers
+constexpr int kEpsRegs = KD_LEPS_REGS;  // epsilon links of a frame a lane keeps in registers
 
 #define KD_G __attribute__((address_space(1)))
 template <class T>
@@ -36,18 +51,22 @@ __device__ __forceinline__ KD_G T *ToG(T *p) { return (KD_G T *)p; }
 template <class T>
 __device__ __forceinline__ T *ToFlat(KD_G T *p) { return (T *)p; }
 
-struct LShared {
-  uint32_t ne[kLdsToks];
+template <int N>
+struct LSharedT {
+  static constexpr int kWords = N;
+  uint32_t ne[N];
   int32_t red_i[kLWaves];
   uint32_t red_u[kLWaves];
   uint32_t best_key, bestwf_key;
   int32_t any_final, changed, count, start_id, empty_frame;
   int32_t n_states, n_arcs, n_finals;
 };
+typedef LSharedT<kLdsToks> LShared;  // pruning
+typedef LSharedT<kFwToks> CShared;   // export
 
 __device__ __forceinline__ float Inf() { return __int_as_float(0x7F800000); }
 
-__device__ __forceinline__ int BlockExclScanI(LShared &s, int v, int &total) {
+__device__ __forceinline__ int BlockExclScanI(CShared &s, int v, int &total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int x = v;
 #pragma unroll
@@ -313,8 +332,8 @@ __device__ __forceinline__ bool Alive(const LatticeParams &p, long long g) {
 //
 // Per-frame counts / id offsets live in LDS (the prune kernel's key array), or in
 // the utterance's global scratch when there are more frames than that.
-__device__ __forceinline__ uint32_t *FrameWords(const LatticeParams &p, LShared &s, int utt, int F) {
-  return F + 1 <= kLdsToks ? s.ne : ToFlat(ToG(p.scratch) + utt * p.scratch_stride);
+__device__ __forceinline__ uint32_t *FrameWords(const LatticeParams &p, CShared &s, int utt, int F) {
+  return F + 1 <= kFwToks ? s.ne : ToFlat(ToG(p.scratch) + utt * p.scratch_stride);
 }
 
 // Calls visit(frame f, token i, alive, rank among the frame's live tokens so far)
@@ -352,7 +371,7 @@ __device__ __forceinline__ void ForWaveFrames(const LatticeParams &p, int utt, i
 
 __global__ __launch_bounds__(kLBlock) void LatticeCountKernel(const LatticeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  LShared &s = *reinterpret_cast<LShared *>(smem);
+  CShared &s = *reinterpret_cast<CShared *>(smem);
   const int tid = threadIdx.x, utt = blockIdx.x;
   const int F = ToG(p.frames_decoded)[utt];
   KD_G int32_t *sz = ToG(p.sizes) + 4 * utt;
@@ -416,7 +435,7 @@ __global__ __launch_bounds__(kLBlock) void LatticeCountKernel(const LatticeParam
 
 __global__ __launch_bounds__(kLBlock) void LatticeFillKernel(const LatticeParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  LShared &s = *reinterpret_cast<LShared *>(smem);
+  CShared &s = *reinterpret_cast<CShared *>(smem);
   const int tid = threadIdx.x, utt = blockIdx.x;
   const int F = ToG(p.frames_decoded)[utt];
   if (F < 1 || ToG(p.sizes)[4 * utt] == 0) return;
@@ -484,31 +503,31 @@ __global__ __launch_bounds__(kLBlock) void LatticeFillKernel(const LatticeParams
   }
 }
 
-hipError_t SetLds(const void *fn) {
+hipError_t SetLds(const void *fn, size_t bytes) {
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             static_cast<int>(sizeof(LShared)));
+                             static_cast<int>(bytes));
 }
 
 }  // namespace
 
 hipError_t LaunchLatticePrune(const LatticeParams &p, int batch, hipStream_t stream) {
-  hipError_t e = SetLds(reinterpret_cast<const void *>(LatticePruneKernel));
+  hipError_t e = SetLds(reinterpret_cast<const void *>(LatticePruneKernel), sizeof(LShared));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(LatticePruneKernel, dim3(batch), dim3(kLBlock), sizeof(LShared), stream, p);
   return hipGetLastError();
 }
 
 hipError_t LaunchLatticeCount(const LatticeParams &p, int batch, hipStream_t stream) {
-  hipError_t e = SetLds(reinterpret_cast<const void *>(LatticeCountKernel));
+  hipError_t e = SetLds(reinterpret_cast<const void *>(LatticeCountKernel), sizeof(CShared));
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(LatticeCountKernel, dim3(batch), dim3(kLBlock), sizeof(LShared), stream, p);
+  hipLaunchKernelGGL(LatticeCountKernel, dim3(batch), dim3(kLBlock), sizeof(CShared), stream, p);
   return hipGetLastError();
 }
 
 hipError_t LaunchLatticeFill(const LatticeParams &p, int batch, hipStream_t stream) {
-  hipError_t e = SetLds(reinterpret_cast<const void *>(LatticeFillKernel));
+  hipError_t e = SetLds(reinterpret_cast<const void *>(LatticeFillKernel), sizeof(CShared));
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(LatticeFillKernel, dim3(batch), dim3(kLBlock), sizeof(LShared), stream, p);
+  hipLaunchKernelGGL(LatticeFillKernel, dim3(batch), dim3(kLBlock), sizeof(CShared), stream, p);
   return hipGetLastError();
 }
 

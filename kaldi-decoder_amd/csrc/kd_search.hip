@@ -222,6 +222,15 @@ __device__ __forceinline__ ArcRec LoadArcRec(const ArcRec *base, uint32_t i) {
   return r;
 }
 
+// A load that is issued whether or not the lane wants it (`on` false: arc `safe`,
+// which the caller knows to be a valid index).  hipcc puts a conditional load in a
+// branch of its own and waits for it there, so loads written as
+// "if (on) x = load" complete one after the other; written this way a group of them
+// is in flight together.
+__device__ __forceinline__ ArcRec LoadArcRecIf(const ArcRec *base, uint32_t i, bool on, uint32_t safe) {
+  return LoadArcRec(base, on ? i : safe);
+}
+
 // Per-frame, per-lane work counters, folded into LDS at the end of the frame.
 struct Counters {
   int tokens_expanded = 0, eps_exp = 0, arcs_scanned = 0, eps_arcs = 0;
@@ -602,10 +611,8 @@ __device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int par, int nq, R
     for (int g = 0; g < kGroup; ++g) {
       deg[g] = 0;
       abeg[g] = 0;
-      if (q0 + g < nq) {
-        range(q0 + g, abeg[g], deg[g]);
-        if (lane < deg[g]) ar[g] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg[g] + lane));
-      }
+      if (q0 + g < nq) range(q0 + g, abeg[g], deg[g]);
+      ar[g] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg[g] + lane), lane < deg[g], 0u);
     }
 #pragma unroll
     for (int g = 0; g < kGroup; ++g)
@@ -627,8 +634,8 @@ __device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int par, int nq, R
         ArcRec tr[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (a0 + 64 * u < deg[g])
-            tr[u] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg[g] + a0 + 64 * u));
+          tr[u] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg[g] + a0 + 64 * u),
+                               a0 + 64 * u < deg[g], static_cast<uint32_t>(abeg[g]));
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           if (a0 + 64 * u < deg[g])
@@ -688,7 +695,7 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
           ArcRec ar[kSmallDeg];
 #pragma unroll
           for (int a = 0; a < kSmallDeg; ++a)
-            if (a < deg) ar[a] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg + a));
+            ar[a] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg + a), a < deg, 0u);
 #pragma unroll
           for (int a = 0; a < kSmallDeg; ++a)
             if (a < deg) FilterArc<EPS>(c, ar[a], static_cast<uint32_t>(abeg + a), cst, srcid);
@@ -1311,7 +1318,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       ArcRec ar[kSmallDeg];
 #pragma unroll
       for (int a = 0; a < kSmallDeg; ++a)
-        if (a0 + a < deg) ar[a] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg + a0 + a));
+        ar[a] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg + a0 + a), a0 + a < deg, 0u);
 #pragma unroll
       for (int a = 0; a < kSmallDeg; ++a)
         if (a0 + a < deg)
@@ -1352,6 +1359,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
 #pragma unroll
       for (int g = 0; g < kGroup; ++g) {
         on[g] = false;
+        aidx[g] = 0;
         const int q = q0 + g * kPer + lane / W;
         ref[g] = -1;
         if (q < nq) {
@@ -1359,9 +1367,11 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
           const int off = lane % W;
           on[g] = off < s.it_deg[ref[g]];
           aidx[g] = s.it_abeg[ref[g]] + off;
-          if (on[g]) ar[g] = LoadArcRec(p.arcs, static_cast<uint32_t>(aidx[g]));
         }
       }
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g)
+        ar[g] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(aidx[g]), on[g], 0u);
 #pragma unroll
       for (int g = 0; g < kGroup; ++g)
         if (on[g])
@@ -1381,8 +1391,8 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
             ArcRec tr[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              if (a0 + 64 * u < deg)
-                tr[u] = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg + a0 + 64 * u));
+              tr[u] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg + a0 + 64 * u),
+                                   a0 + 64 * u < deg, static_cast<uint32_t>(abeg));
 #pragma unroll
             for (int u = 0; u < 4; ++u)
               if (a0 + 64 * u < deg)
