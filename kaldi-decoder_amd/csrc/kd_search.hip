@@ -111,6 +111,12 @@ constexpr int kT1W16 = 512;    // tokens of at most 16 arcs (in Shared::hist)
 static_assert(kBlock >= 256 && kT1Front >= kBlock && kSlots == 2 * kT1Slots && 2 * kQL == kT1Slots,
               "tier-1 LDS overlay");
 constexpr unsigned long long kCostInf = 0xFFF0000000000000ull;  // CostKey(+inf)
+// Global-table tier: tokens / queue entries a lane reads at a time in the passes that
+// only read the table.  Every read there is an L2 round trip (agent-scope loads), so
+// a lane keeps kSpillIlp independent ones in flight instead of one.  (The insert
+// pass gains nothing from the same treatment -- measured: it runs at the rate the CU
+// issues scattered L2 atomics, about four cycles an entry.)
+constexpr int kSpillIlp = 4;
 // Frame results besides 0 and the KD_UTT_* bits: run the table half again in the
 // next larger table / run the whole frame again in the big path.
 constexpr uint32_t kRetry = 0x100u, kRedo = 0x200u;
@@ -507,9 +513,64 @@ struct FrameCtx {
   bool min_only;  // simple: first filter pass only finds the minimum total cost
 };
 
-// Scores one arc out of a token with cost `csrc` and queues it if it survives
-// the (running) cutoff: the reference's test at faster-decoder.cc:208-211
-// (emitting) or :90-95 (epsilon).
+// Scores one arc out of a token with cost `csrc`: the reference's test at
+// faster-decoder.cc:208-211 (emitting; `seen_min` is the lowest new cost seen so
+// far) or :90-95 (epsilon).  Returns whether the arc survives; `nc` is the new
+// token's cost, `aux` the lattice decoders' acoustic cost (emitting) / source cost
+// (epsilon).  (SimpleDecoder's emitting arcs are scored in FilterArc.)
+template <bool EPS, int M>
+__device__ __forceinline__ bool ScoreArc(const FrameCtx<M> &c, const ArcRec &a, double csrc,
+                                         unsigned long long seen_min, double &nc, float &aux) {
+  aux = 0.f;
+  if constexpr (EPS) {
+    if (c.lattice) {
+      // lattice-simple-decoder.cc:170-174: float, strict
+      const float cur_cost = static_cast<float>(csrc), tot_cost = cur_cost + a.weight;
+      nc = tot_cost;
+      aux = cur_cost;
+      return tot_cost < static_cast<float>(c.cutoff);
+    }
+    nc = csrc + a.weight;     // faster-decoder.h:134
+    return !(nc > c.cutoff);  // faster-decoder.cc:92
+  } else {
+    const float ll = c.ll_in_lds ? c.s.ll[a.ilabel - 1] : c.ll_row[a.ilabel - 1];
+    if (c.lattice) {
+      // lattice-simple-decoder.cc:383-390: float, cur + ac + graph
+      const float ac_cost = -ll, cur_cost = static_cast<float>(csrc),
+                  tot_cost = cur_cost + ac_cost + a.weight;
+      nc = tot_cost;
+      aux = ac_cost;
+      return tot_cost < static_cast<float>(KeyCost(seen_min)) + c.adaptive_beam;
+    }
+    const float ac_cost = -1 * ll;   // :209
+    nc = a.weight + csrc + ac_cost;  // :210 (== Token cost, faster-decoder.h:126)
+    return nc < KeyCost(seen_min) + static_cast<double>(c.adaptive_beam);  // :211, :215-217
+  }
+}
+
+// Candidate-queue entry `pos` of a tier-1 frame: the first kQL entries are in LDS.
+template <int M>
+__device__ __forceinline__ void T1Put(const FrameCtx<M> &c, int pos, const ArcRec &a, uint32_t aidx,
+                                      uint32_t srcid, unsigned long long nk, float aux) {
+  Shared &s = c.s;
+  if (pos < kQL) {
+    T1QH(s)[pos] = a.next;
+    T1QArc(s)[pos] = aidx;
+    T1QSrc(s)[pos] = srcid;
+    T1QNk(s)[pos] = nk;
+    T1QAc(s)[pos] = aux;
+    if (c.lattice) T1QGr(s)[pos] = a.weight;
+  } else if (pos < c.q_cap) {
+    c.q_h[pos] = a.next;
+    c.q_arc[pos] = aidx;
+    c.q_src[pos] = srcid;
+    c.q_nk[pos] = nk;
+    if (c.lattice || c.simple) c.q_ac[pos] = aux;
+    if (c.lattice) c.q_gr[pos] = a.weight;
+  }
+}
+
+// Scores one arc and queues it if it survives the (running) cutoff.
 template <bool EPS, bool T1 = false, int M>
 __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a, uint32_t aidx,
                                           double csrc, uint32_t srcid) {
@@ -518,58 +579,33 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
   bool keep;
   float aux = 0.f;  // lattice: acoustic cost (emitting) / source cost (epsilon)
   unsigned long long seen_min = 0;
-  if constexpr (EPS) {
-    if (c.lattice) {
-      // lattice-simple-decoder.cc:170-174: float, strict
-      const float cur_cost = static_cast<float>(csrc), tot_cost = cur_cost + a.weight;
-      nc = tot_cost;
-      keep = tot_cost < static_cast<float>(c.cutoff);
-      aux = cur_cost;
-    } else {
-      nc = csrc + a.weight;     // faster-decoder.h:134
-      keep = !(nc > c.cutoff);  // faster-decoder.cc:92
-    }
-  } else {
-    const float ll = c.ll_in_lds ? s.ll[a.ilabel - 1] : c.ll_row[a.ilabel - 1];
+  if constexpr (!EPS) {
     seen_min = s.min_new;
     seen_min = c.run_min < seen_min ? c.run_min : seen_min;
-    if (c.simple) {
-      // simple-decoder.cc:167-176.  Two passes: the first only finds the minimum
-      // total cost, the second queues what is below min + beam.  The token stores
-      // prev.cost + (weight + ac) with the float sum first (simple-decoder.h:99).
-      const float acoustic_cost = -ll;
-      const double total_cost = csrc + a.weight + acoustic_cost;
-      if (c.min_only) {
-        const unsigned long long tk = CostKey(total_cost);
-        if (tk < seen_min) c.run_min = tk;
-        return;
-      }
-      keep = !(total_cost >= c.cutoff);
-      nc = csrc + (a.weight + acoustic_cost);
-      aux = acoustic_cost;
-    } else if (c.lattice) {
-      // lattice-simple-decoder.cc:383-390: float, cur + ac + graph
-      const float ac_cost = -ll, cur_cost = static_cast<float>(csrc),
-                  tot_cost = cur_cost + ac_cost + a.weight;
-      nc = tot_cost;
-      keep = tot_cost < static_cast<float>(KeyCost(seen_min)) + c.adaptive_beam;
-      aux = ac_cost;
-    } else {
-      const float ac_cost = -1 * ll;   // :209
-      nc = a.weight + csrc + ac_cost;  // :210 (== Token cost, faster-decoder.h:126)
-      keep = nc < KeyCost(seen_min) + static_cast<double>(c.adaptive_beam);  // :211, :215-217
+  }
+  if constexpr (!EPS && M == 2) {
+    // simple-decoder.cc:167-176.  Two passes: the first only finds the minimum
+    // total cost, the second queues what is below min + beam.  The token stores
+    // prev.cost + (weight + ac) with the float sum first (simple-decoder.h:99).
+    const float ll = c.ll_in_lds ? s.ll[a.ilabel - 1] : c.ll_row[a.ilabel - 1];
+    const float acoustic_cost = -ll;
+    const double total_cost = csrc + a.weight + acoustic_cost;
+    if (c.min_only) {
+      const unsigned long long tk = CostKey(total_cost);
+      if (tk < seen_min) c.run_min = tk;
+      return;
     }
+    keep = !(total_cost >= c.cutoff);
+    nc = csrc + (a.weight + acoustic_cost);
+    aux = acoustic_cost;
+  } else {
+    keep = ScoreArc<EPS>(c, a, csrc, seen_min, nc, aux);
   }
   if (keep) {
     const unsigned long long nk = CostKey(nc);
     const int pos = AggInc(&s.q_n);
-    if (T1 && pos < kQL) {
-      T1QH(s)[pos] = a.next;
-      T1QArc(s)[pos] = aidx;
-      T1QSrc(s)[pos] = srcid;
-      T1QNk(s)[pos] = nk;
-      T1QAc(s)[pos] = aux;
-      if (c.lattice) T1QGr(s)[pos] = a.weight;
+    if (T1) {
+      T1Put(c, pos, a, aidx, srcid, nk, aux);
     } else if (pos < c.q_cap) {
       c.q_h[pos] = a.next;
       c.q_arc[pos] = aidx;
@@ -1118,23 +1154,38 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
   unsigned long long my_min = kCostDead;
   uint32_t my_min_state = 0;
   {
-    for (int i0 = tid; i0 < n_out; i0 += kBlock) {
-      const uint32_t h = c.live[i0];
-      const unsigned long long ck = t.LoadCost(h);
-      int i = i0;
-      if (c.simple)
-        i = ck < prune_key ? AggInc(&s.n_act) : n_out - 1 - AggInc(&s.n_inact);
-      const long long g = base_out + i;
-      const uint32_t st_of_tok = t.LoadKey(h) & kStateMask;
-      ToG(p.tok_state)[g] = static_cast<int32_t>(st_of_tok);
-      ToG(p.tok_cost)[g] = KeyCost(ck);
-      if (c.lattice) ToG(p.tok_extra)[g] = 0.0f;  // lattice-simple-decoder.cc:91-95
-      if (t.LoadArc(h) == kArcNone) {  // the start token
-        ToG(p.tok_prev)[g] = -1;
-        ToG(p.tok_arc)[g] = -1;
+    // (global-table tier: kSpillIlp tokens per lane, their table words fetched together)
+    constexpr int U = LDS ? 1 : kSpillIlp;
+    for (int i0 = tid; i0 < n_out; i0 += U * kBlock) {
+      uint32_t h[U], kw[U], aw[U];
+      unsigned long long ckv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) h[u] = c.live[i0 + u * kBlock < n_out ? i0 + u * kBlock : 0];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ckv[u] = t.LoadCost(h[u]);
+        kw[u] = t.LoadKey(h[u]);
+        aw[u] = M != 1 ? t.LoadArc(h[u]) : 0u;  // (lattice tokens have no back-pointers)
       }
-      t.StoreKey(h, static_cast<uint32_t>(i));
-      if (ck < my_min) { my_min = ck; my_min_state = st_of_tok; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (i0 + u * kBlock >= n_out) continue;
+        const unsigned long long ck = ckv[u];
+        int i = i0 + u * kBlock;
+        if (c.simple)
+          i = ck < prune_key ? AggInc(&s.n_act) : n_out - 1 - AggInc(&s.n_inact);
+        const long long g = base_out + i;
+        const uint32_t st_of_tok = kw[u] & kStateMask;
+        ToG(p.tok_state)[g] = static_cast<int32_t>(st_of_tok);
+        ToG(p.tok_cost)[g] = KeyCost(ck);
+        if (c.lattice) ToG(p.tok_extra)[g] = 0.0f;  // lattice-simple-decoder.cc:91-95
+        if (M != 1 && aw[u] == kArcNone) {  // the start token
+          ToG(p.tok_prev)[g] = -1;
+          ToG(p.tok_arc)[g] = -1;
+        }
+        t.StoreKey(h[u], static_cast<uint32_t>(i));
+        if (ck < my_min) { my_min = ck; my_min_state = st_of_tok; }
+      }
     }
     const unsigned long long wmin = WaveMinU64(my_min);
     if ((tid & 63) == 0 && wmin != kCostDead) atomicMin(&s.f_best_next, wmin);
@@ -1179,32 +1230,88 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
     const bool full = lbase + n_emit + (n_q - q_emit) >
                       static_cast<long long>(c.utt + 1) * static_cast<long long>(p.link_cap);
     if (full) return KD_UTT_ARENA_FULL;
-    for (int i = tid; i < n_q; i += kBlock) {
-      const uint32_t h = c.q_h[i];
-      if (h == kKeyEmpty) continue;
-      const uint32_t sr = c.q_src[i];
-      long long at, src_tok;
-      float ac;
-      if (i < q_emit) {
-        src_tok = c.base_in + sr;
-        ac = c.q_ac[i];
-        at = lbase + AggInc(&s.n_emit_written);
-      } else {
-        const uint32_t hs = sr & ~kSrcEps;
-        // source cost at generation vs its final cost (its slot's cost word is intact)
-        if (c.q_ac[i] != static_cast<float>(KeyCost(t.LoadCost(hs)))) continue;
-        src_tok = base_out + t.LoadKey(hs);
-        ac = 0.0f;
-        at = lbase + n_emit + AggInc(&s.n_eps_links);
+    if constexpr (LDS) {
+      for (int i = tid; i < n_q; i += kBlock) {
+        const uint32_t h = c.q_h[i];
+        if (h == kKeyEmpty) continue;
+        const uint32_t sr = c.q_src[i];
+        long long at, src_tok;
+        float ac;
+        if (i < q_emit) {
+          src_tok = c.base_in + sr;
+          ac = c.q_ac[i];
+          at = lbase + AggInc(&s.n_emit_written);
+        } else {
+          const uint32_t hs = sr & ~kSrcEps;
+          // source cost at generation vs its final cost (its slot's cost word is intact)
+          if (c.q_ac[i] != static_cast<float>(KeyCost(t.LoadCost(hs)))) continue;
+          src_tok = base_out + t.LoadKey(hs);
+          ac = 0.0f;
+          at = lbase + n_emit + AggInc(&s.n_eps_links);
+        }
+        const uint32_t aidx = c.q_arc[i];
+        ToG(p.link_src)[at] = static_cast<int32_t>(src_tok);
+        ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + t.LoadKey(h));
+        ToG(p.link_arc)[at] = static_cast<int32_t>(aidx);
+        ToG(p.link_ac)[at] = ac;
+        ToG(p.link_graph)[at] = c.q_gr[i];
+        ToG(p.link_delta)[at] = static_cast<float>(KeyCost(c.q_nk[i])) -
+                                static_cast<float>(KeyCost(t.LoadCost(h)));
       }
-      const uint32_t aidx = c.q_arc[i];
-      ToG(p.link_src)[at] = static_cast<int32_t>(src_tok);
-      ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + t.LoadKey(h));
-      ToG(p.link_arc)[at] = static_cast<int32_t>(aidx);
-      ToG(p.link_ac)[at] = ac;
-      ToG(p.link_graph)[at] = c.q_gr[i];
-      ToG(p.link_delta)[at] = static_cast<float>(KeyCost(c.q_nk[i])) -
-                              static_cast<float>(KeyCost(t.LoadCost(h)));
+    } else {
+      // global-table tier: kSpillIlp entries per lane, their queue words and then their
+      // table words (destination slot; source slot of an epsilon entry) fetched together
+      constexpr int U = kSpillIlp;
+      for (int i0 = tid; i0 < n_q; i0 += U * kBlock) {
+        uint32_t h[U], sr[U], aidx[U], kd[U], ks[U];
+        float qa[U], qg[U];
+        unsigned long long nk[U], cd[U], cs[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * kBlock, idx = i < n_q ? i : 0;
+          h[u] = c.q_h[idx];
+          sr[u] = c.q_src[idx];
+          aidx[u] = c.q_arc[idx];
+          qa[u] = c.q_ac[idx];
+          qg[u] = c.q_gr[idx];
+          nk[u] = c.q_nk[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * kBlock;
+          ok[u] = i < n_q && h[u] != kKeyEmpty;
+          const uint32_t hd = ok[u] ? h[u] : 0u, hs = ok[u] && i >= q_emit ? sr[u] & ~kSrcEps : 0u;
+          kd[u] = t.LoadKey(hd);
+          cd[u] = t.LoadCost(hd);
+          ks[u] = t.LoadKey(hs);
+          cs[u] = t.LoadCost(hs);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!ok[u]) continue;
+          const int i = i0 + u * kBlock;
+          long long at, src_tok;
+          float ac;
+          if (i < q_emit) {
+            src_tok = c.base_in + sr[u];
+            ac = qa[u];
+            at = lbase + AggInc(&s.n_emit_written);
+          } else {
+            // source cost at generation vs its final cost (its slot's cost word is intact)
+            if (qa[u] != static_cast<float>(KeyCost(cs[u]))) continue;
+            src_tok = base_out + ks[u];
+            ac = 0.0f;
+            at = lbase + n_emit + AggInc(&s.n_eps_links);
+          }
+          ToG(p.link_src)[at] = static_cast<int32_t>(src_tok);
+          ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + kd[u]);
+          ToG(p.link_arc)[at] = static_cast<int32_t>(aidx[u]);
+          ToG(p.link_ac)[at] = ac;
+          ToG(p.link_graph)[at] = qg[u];
+          ToG(p.link_delta)[at] = static_cast<float>(KeyCost(nk[u])) - static_cast<float>(KeyCost(cd[u]));
+        }
+      }
     }
   }
   KD_LAP(s, 17);
@@ -1343,6 +1450,55 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     }
     T1Heads(s)[AggInc(&s.it_count[0])] = static_cast<uint16_t>(ref);
   };
+  // Scores N arcs per lane (`on[g]`: this lane holds arc g) and appends the survivors
+  // to the candidate queue with ONE queue allocation for the wave.  Call where the
+  // wave is converged.  The running cutoff is read once: a looser running cutoff
+  // only lengthens the queue, the exact one is applied at insert.  (Tightening it
+  // first with the wave's own minimum -- a 64-bit wave reduction -- costs more than
+  // the shorter queue saves: measured.)
+  auto score_batch = [&](auto eps_tag, auto n_tag, const ArcRec *ar, const int *aidx, const bool *on,
+                         const double *cst, const uint32_t *src) {
+    constexpr bool EPS = decltype(eps_tag)::value;
+    constexpr int N = decltype(n_tag)::value;
+    unsigned long long seen = 0;
+    if constexpr (!EPS) {
+      seen = s.min_new;
+      seen = c.run_min < seen ? c.run_min : seen;
+    }
+    unsigned long long nk[N], bal[N];
+    float aux[N];
+    bool keep[N];
+    int pre[N], total = 0;
+#pragma unroll
+    for (int g = 0; g < N; ++g) {
+      keep[g] = false;
+      nk[g] = 0;
+      aux[g] = 0.f;
+      if (on[g]) {
+        double nc;
+        keep[g] = ScoreArc<EPS>(c, ar[g], cst[g], seen, nc, aux[g]);
+        nk[g] = CostKey(nc);
+      }
+      bal[g] = __ballot(keep[g]);
+      pre[g] = total;
+      total += __popcll(bal[g]);
+    }
+    if (total == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&s.q_n, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+    for (int g = 0; g < N; ++g) {
+      if (!keep[g]) continue;
+      const int pos = base + pre[g] +
+                      __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(bal[g] >> 32),
+                                                __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bal[g]), 0));
+      T1Put(c, pos, ar[g], static_cast<uint32_t>(aidx[g]), src[g], nk[g], aux[g]);
+      if constexpr (!EPS) {
+        if (nk[g] < c.run_min) c.run_min = nk[g];
+      }
+    }
+  };
   // One pass over a list of work items of width W lanes: a wave takes kGroup rows
   // (kGroup * 64 / W items) at a time.  `item(q, ref, chunk)` describes item q.
   auto rows = [&](auto eps_tag, auto width_tag, int nq, int32_t *next, auto item_ref) {
@@ -1372,11 +1528,15 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
 #pragma unroll
       for (int g = 0; g < kGroup; ++g)
         ar[g] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(aidx[g]), on[g], 0u);
+      double cst[kGroup];
+      uint32_t src[kGroup];
 #pragma unroll
-      for (int g = 0; g < kGroup; ++g)
-        if (on[g])
-          FilterArc<EPS, true>(c, ar[g], static_cast<uint32_t>(aidx[g]), s.it_cost[ref[g]],
-                               EPS ? s.it_src[ref[g]] : static_cast<uint32_t>(ref[g]));
+      for (int g = 0; g < kGroup; ++g) {
+        const int rr = ref[g] < 0 ? 0 : ref[g];  // (unconditional reads: see LoadArcRecIf)
+        cst[g] = s.it_cost[rr];
+        src[g] = EPS ? s.it_src[rr] : static_cast<uint32_t>(rr);
+      }
+      score_batch(eps_tag, std::integral_constant<int, kGroup>{}, ar, aidx, on, cst, src);
       if constexpr (W == 64) {
         // tokens with more than 64 arcs: the rest, four wave-rows in flight
 #pragma unroll 1
