@@ -1501,6 +1501,9 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   };
   // One pass over a list of work items of width W lanes: a wave takes kGroup rows
   // (kGroup * 64 / W items) at a time.  `item(q, ref, chunk)` describes item q.
+  // (One loop per width on purpose: this phase is bound by instruction issue, and a
+  // single loop over rows of any width -- fewer rounds, more instructions per row --
+  // was measured 25% slower.)
   auto rows = [&](auto eps_tag, auto width_tag, int nq, int32_t *next, auto item_ref) {
     constexpr bool EPS = decltype(eps_tag)::value;
     constexpr int W = decltype(width_tag)::value, kPer = 64 / W;
@@ -1674,33 +1677,67 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     }
     tm.Sync(false);
     KD_LAP(s, 6);
-    // every team thread scans its share of the worklist mask, 16 slots at a time
-    for (int w16 = tid; w16 < kT1Slots / 16; w16 += nt) {
-      uint32_t m = (wlmask[cur * kMaskWords + (w16 >> 1)] >> ((w16 & 1) * 16)) & 0xFFFFu;
+    // The team's threads scan the worklist mask, 8 slots each (a lane rarely finds
+    // more than one token).  Tokens are taken two at a time: both state records are
+    // requested before either is used, and so are the arcs of low-degree tokens.
+    for (int w8 = tid; w8 < kT1Slots / 8; w8 += nt) {
+      uint32_t m = (wlmask[cur * kMaskWords + (w8 >> 2)] >> ((w8 & 3) * 8)) & 0xFFu;
       while (m) {
-        const int bit = __builtin_ctz(m);
+        uint32_t h[2];
+        h[0] = static_cast<uint32_t>(w8 * 8 + __builtin_ctz(m));
         m &= m - 1;
-        const uint32_t h = static_cast<uint32_t>(w16 * 16 + bit);
-        const double cst = KeyCost(s.cost[h]);
-        if (cst > c.cutoff) continue;  // :74
-        const StateRec r = LoadState(p.states, s.key[h] & kStateMask);
-        const int abeg = r.emit_end, deg = r.arc_end - r.emit_end;
-        cnt.eps_exp += 1;
-        cnt.eps_arcs += deg;
-        const uint32_t srcid = h | kSrcEps;
-        bool queued = false;
-        if (deg > kSmallDeg) {
-          const int q = AggInc(&s.it_count[1]);  // descriptor slot in it_*
-          if (q < kT1Front) {
-            s.it_abeg[q] = abeg;
-            s.it_deg[q] = deg;
-            s.it_cost[q] = cst;
-            s.it_src[q] = srcid;
-            push_items(EpsYes{}, q, abeg, deg, cst, srcid);
-            queued = true;
+        const bool two = m != 0;
+        h[1] = two ? static_cast<uint32_t>(w8 * 8 + __builtin_ctz(m)) : h[0];
+        if (two) m &= m - 1;
+        double cst[2];
+        bool ok[2], own[2];
+        StateRec r[2];
+        int abeg[2], deg[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          cst[j] = KeyCost(s.cost[h[j]]);
+          ok[j] = (j == 0 || two) && !(cst[j] > c.cutoff);  // :74
+          r[j] = LoadState(p.states, s.key[h[j]] & kStateMask);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          abeg[j] = r[j].emit_end;
+          deg[j] = r[j].arc_end - r[j].emit_end;
+          own[j] = ok[j];
+          if (!ok[j]) continue;
+          cnt.eps_exp += 1;
+          cnt.eps_arcs += deg[j];
+          if (deg[j] > kSmallDeg) {
+            const int q = AggInc(&s.it_count[1]);  // descriptor slot in it_*
+            if (q < kT1Front) {
+              const uint32_t srcid = h[j] | kSrcEps;
+              s.it_abeg[q] = abeg[j];
+              s.it_deg[q] = deg[j];
+              s.it_cost[q] = cst[j];
+              s.it_src[q] = srcid;
+              push_items(EpsYes{}, q, abeg[j], deg[j], cst[j], srcid);
+              own[j] = false;
+            }
           }
         }
-        if (!queued) lane_arcs(EpsYes{}, abeg, deg, cst, srcid);
+        // tokens that stay on the lane: the first kSmallDeg arcs of both in flight
+        ArcRec ar[2][kSmallDeg];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int a = 0; a < kSmallDeg; ++a)
+            ar[j][a] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg[j] + a), own[j] && a < deg[j], 0u);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int a = 0; a < kSmallDeg; ++a)
+            if (own[j] && a < deg[j])
+              FilterArc<true, true>(c, ar[j][a], static_cast<uint32_t>(abeg[j] + a), cst[j], h[j] | kSrcEps);
+        // (a token the full descriptor list sent back may have more arcs than that)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (own[j] && deg[j] > kSmallDeg)
+            lane_arcs(EpsYes{}, abeg[j] + kSmallDeg, deg[j] - kSmallDeg, cst[j], h[j] | kSrcEps);
       }
     }
     tm.Sync(false);
@@ -1740,31 +1777,39 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // ---- C1: live list -> token records; a slot's key word now holds its index in
   // the block.  Each token's state record is fetched now for the next frame's filter.
   const bool next_small = n_out <= kT1Front;
-  constexpr int kKeep = kT1Front / 256;  // tokens per thread of the smallest team
   unsigned long long my_min = kCostDead;
-  int nb[kKeep], nd[kKeep];
-#pragma unroll
-  for (int k = 0; k < kKeep; ++k) { nb[k] = 0; nd[k] = -1; }
+  // The new frontier's state records (at most kNextRecs tokens per lane when the next
+  // frame is a tier-1 frame): requested here, used when the frame ends -- the gather
+  // overlaps the passes in between.
+  constexpr int kNextRecs = (kT1Front + kBlock - 1) / kBlock;
+  static_assert(kT1Narrow == 0, "kNextRecs assumes the whole workgroup runs the frame");
+  StateRec next_rec[kNextRecs];
+  bool next_on[kNextRecs];
   {
-    int k = 0;
-    for (int i = tid; i < n_out; i += nt, ++k) {
-      const int h = T1Live(s)[i];
-      const unsigned long long ck = s.cost[h];
-      const uint32_t st = s.key[h] & kStateMask;
-      const long long g = base_out + i;
-      ToG(p.tok_state)[g] = static_cast<int32_t>(st);
-      ToG(p.tok_cost)[g] = KeyCost(ck);
-      if (c.lattice) ToG(p.tok_extra)[g] = 0.0f;  // lattice-simple-decoder.cc:91-95
-      my_min = ck < my_min ? ck : my_min;
-      s.key[h] = static_cast<uint32_t>(i);
-      if (next_small) {
-        s.it_cost[i] = KeyCost(ck);
-        s.it_src[i] = st;
-        const StateRec r = LoadState(p.states, st);
+    uint32_t st_next[kNextRecs];
 #pragma unroll
-        for (int kk = 0; kk < kKeep; ++kk)
-          if (kk == k) { nb[kk] = r.arc_begin; nd[kk] = r.emit_end - r.arc_begin; }
-      }
+    for (int j = 0; j < kNextRecs; ++j) {
+      const int i = tid + j * nt;
+      next_on[j] = next_small && i < n_out;
+      const int h = T1Live(s)[next_on[j] ? i : 0];
+      st_next[j] = next_on[j] ? s.key[h] & kStateMask : 0u;  // (before the key words become indices)
+    }
+#pragma unroll
+    for (int j = 0; j < kNextRecs; ++j) next_rec[j] = LoadState(p.states, st_next[j]);
+  }
+  for (int i = tid; i < n_out; i += nt) {
+    const int h = T1Live(s)[i];
+    const unsigned long long ck = s.cost[h];
+    const uint32_t st = s.key[h] & kStateMask;
+    const long long g = base_out + i;
+    ToG(p.tok_state)[g] = static_cast<int32_t>(st);
+    ToG(p.tok_cost)[g] = KeyCost(ck);
+    if (c.lattice) ToG(p.tok_extra)[g] = 0.0f;  // lattice-simple-decoder.cc:91-95
+    my_min = ck < my_min ? ck : my_min;
+    s.key[h] = static_cast<uint32_t>(i);
+    if (next_small) {
+      s.it_cost[i] = KeyCost(ck);
+      s.it_src[i] = st;
     }
   }
   if (my_min != kCostDead && my_min < s.f_best_next) atomicMin(&s.f_best_next, my_min);
@@ -1828,16 +1873,17 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   tm.Sync(false);
   KD_LAP(s, 12);
   // ---- clear the table; publish the next frontier's arc ranges
-  {
-    int k = 0;
-    for (int i = tid; i < n_out; i += nt, ++k) {
-      const int h = T1Live(s)[i];
-      s.key[h] = kKeyEmpty;
-      s.cost[h] = kCostDead;
-      s.arc[h] = kArcNone;
+  for (int i = tid; i < n_out; i += nt) {
+    const int h = T1Live(s)[i];
+    s.key[h] = kKeyEmpty;
+    s.cost[h] = kCostDead;
+    s.arc[h] = kArcNone;
+  }
 #pragma unroll
-      for (int kk = 0; kk < kKeep; ++kk)
-        if (kk == k && nd[kk] >= 0) { s.it_abeg[i] = nb[kk]; s.it_deg[i] = nd[kk]; }
+  for (int j = 0; j < kNextRecs; ++j) {
+    if (next_on[j]) {
+      s.it_abeg[tid + j * nt] = next_rec[j].arc_begin;
+      s.it_deg[tid + j * nt] = next_rec[j].emit_end - next_rec[j].arc_begin;
     }
   }
   if (tid == 0) {
