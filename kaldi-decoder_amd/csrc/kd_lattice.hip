@@ -66,6 +66,14 @@ typedef LSharedT<kFwToks> CShared;   // export
 
 __device__ __forceinline__ float Inf() { return __int_as_float(0x7F800000); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for
+// every outstanding global load and store of the wave; in the LDS-resident frames of
+// the pruning pass the waves exchange data through LDS alone, and the link records
+// requested for later steps (and the stores of finished values) stay in flight.
+__device__ __forceinline__ void LdsBarrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int BlockExclScanI(CShared &s, int v, int &total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int x = v;
@@ -93,27 +101,44 @@ __device__ __forceinline__ int BlockExclScanI(CShared &s, int v, int &total) {
   return off;
 }
 
-// Applies one link block to the frame's new-extra keys.
+// Applies one link block to the frame's new-extra keys (frames that do not fit the
+// LDS-resident path: thousands of tokens and links).  Four links per lane at a time:
+// their records, then the four destination extras (a gather), are requested together
+// (every lane issues every load -- a lane without a link reads a valid dummy --
+// because hipcc waits for a conditional load before it issues the next).
 __device__ __forceinline__ void ApplyLinks(const LatticeParams &p, LShared &s, KD_G uint32_t *ne,
                                            bool ne_in_lds, long long lb, int ln, long long base) {
-  for (int i = threadIdx.x; i < ln; i += kLBlock) {
-    const long long at = lb + i;
-    const int32_t dst = ToG(p.link_dst)[at];
-    if (dst < 0) continue;  // already excised
-    const int32_t src = ToG(p.link_src)[at];
-    const float next_extra = ToG(p.tok_extra)[dst];
-    // lattice-simple-decoder.cc:257-260; (tok.tot + ac + graph) - next.tot was
-    // taken when the link was made (both costs were final then)
-    float link_extra_cost = next_extra + ToG(p.link_delta)[at];
-    if (link_extra_cost > p.lattice_beam) {  // :264 excise
-      ToG(p.link_dst)[at] = -1;
-      continue;
+  constexpr int U = 4;
+  for (int i0 = threadIdx.x; i0 < ln; i0 += U * kLBlock) {
+    int32_t dst[U], src[U];
+    float delta[U], next_extra[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * kLBlock;
+      const long long at = lb + (i < ln ? i : i0);
+      dst[u] = ToG(p.link_dst)[at];
+      src[u] = ToG(p.link_src)[at];
+      delta[u] = ToG(p.link_delta)[at];
+      if (i >= ln) dst[u] = -1;
     }
-    if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
-    const uint32_t k = FloatKey(link_extra_cost);
-    const long long li = src - base;
-    if (ne_in_lds) atomicMin(&s.ne[li], k);
-    else atomicMin(ToFlat(&ne[li]), k);
+#pragma unroll
+    for (int u = 0; u < U; ++u) next_extra[u] = ToG(p.tok_extra)[dst[u] < 0 ? base : dst[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (dst[u] < 0) continue;  // already excised (or no link)
+      // lattice-simple-decoder.cc:257-260; (tok.tot + ac + graph) - next.tot was
+      // taken when the link was made (both costs were final then)
+      float link_extra_cost = next_extra[u] + delta[u];
+      if (link_extra_cost > p.lattice_beam) {  // :264 excise
+        ToG(p.link_dst)[lb + i0 + u * kLBlock] = -1;
+        continue;
+      }
+      if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
+      const uint32_t k = FloatKey(link_extra_cost);
+      const long long li = src[u] - base;
+      if (ne_in_lds) atomicMin(&s.ne[li], k);
+      else atomicMin(ToFlat(&ne[li]), k);
+    }
   }
 }
 
@@ -226,7 +251,7 @@ __global__ __launch_bounds__(kLBlock) void LatticePruneKernel(const LatticeParam
           }
         }
       }
-      __syncthreads();
+      LdsBarrier();
       // emitting links, into A
       for (int i = tid; i < en; i += kLBlock) {
         const long long at = eb + i;
@@ -243,11 +268,11 @@ __global__ __launch_bounds__(kLBlock) void LatticePruneKernel(const LatticeParam
         if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
         atomicMin(&A[src - base], FloatKey(link_extra_cost));
       }
-      __syncthreads();
+      LdsBarrier();
       while (true) {
         for (int i = tid; i < n; i += kLBlock) C[i] = A[i];
         if (tid == 0) s.changed = 0;
-        __syncthreads();
+        LdsBarrier();
 #pragma unroll
         for (int r = 0; r < kEpsRegs; ++r) {
           if (e_src[r] < 0) continue;
@@ -260,7 +285,7 @@ __global__ __launch_bounds__(kLBlock) void LatticePruneKernel(const LatticeParam
           if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
           atomicMin(&C[e_src[r]], FloatKey(link_extra_cost));
         }
-        __syncthreads();
+        LdsBarrier();
         int ch = 0;
         for (int i = tid; i < n; i += kLBlock) {
           float v = KeyFloat(C[i]);
@@ -269,16 +294,18 @@ __global__ __launch_bounds__(kLBlock) void LatticePruneKernel(const LatticeParam
           if (k != B[i]) { B[i] = k; ch = 1; }
         }
         if (ch) s.changed = 1;
-        __syncthreads();
+        LdsBarrier();
         const int changed = s.changed;
-        __syncthreads();
+        LdsBarrier();
         // without epsilon links nothing in this frame depends on this frame
         if (!changed || pn == 0) break;
       }
       for (int i = tid; i < n; i += kLBlock) ToG(p.tok_extra)[base + i] = KeyFloat(B[i]);
       next_b = B;
       next_base = base;
-      __syncthreads();
+      // (a later frame that reads these extras from global memory -- the path below --
+      // does so behind a full barrier of its own)
+      LdsBarrier();
       continue;
     }
     next_b = nullptr;  // this frame's extras go to global memory only
@@ -301,14 +328,26 @@ __global__ __launch_bounds__(kLBlock) void LatticePruneKernel(const LatticeParam
       ApplyLinks(p, s, gne, ne_in_lds, pb, pn, base);
       __syncthreads();
       int ch = 0;
-      for (int i = tid; i < n; i += kLBlock) {
-        float v = KeyFloat(ne_in_lds ? s.ne[i]
-                                     : __hip_atomic_load(ToFlat(&gne[i]), __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT));
-        if (last && v > p.lattice_beam) v = Inf();  // :507-509
-        if (v != ToG(p.tok_extra)[base + i]) {
-          ToG(p.tok_extra)[base + i] = v;
-          ch = 1;
+      for (int i0 = tid; i0 < n; i0 += 4 * kLBlock) {  // (four tokens per lane in flight)
+        float was[4];
+        uint32_t now[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * kLBlock < n ? i0 + u * kLBlock : i0;
+          was[u] = ToG(p.tok_extra)[base + i];
+          now[u] = ne_in_lds ? s.ne[i]
+                             : __hip_atomic_load(ToFlat(&gne[i]), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + u * kLBlock >= n) continue;
+          float v = KeyFloat(now[u]);
+          if (last && v > p.lattice_beam) v = Inf();  // :507-509
+          if (v != was[u]) {
+            ToG(p.tok_extra)[base + i0 + u * kLBlock] = v;
+            ch = 1;
+          }
         }
       }
       if (ch) s.changed = 1;
