@@ -165,7 +165,7 @@ def cpu_baseline(g, lps, wl, gpu_out, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="hlg-lattice", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")

@@ -24,7 +24,9 @@ KERNEL = "SearchKernel"
 
 
 def one(pattern):
-    hits = glob.glob(os.path.join(ROOT, "gpurun_out", pattern))
+    # rocprofv3 writes <dir>/<prefix>_*.csv, or <dir>/<host>/<pid>_*.csv without -o
+    hits = (glob.glob(os.path.join(ROOT, "gpurun_out", pattern)) +
+            glob.glob(os.path.join(ROOT, "gpurun_out", pattern.replace("/*/", "/"))))
     if not hits:
         raise SystemExit(f"missing gpurun_out/{pattern}")
     return max(hits, key=os.path.getmtime)  # a directory may hold several runs: newest
