@@ -143,8 +143,7 @@ __device__ __forceinline__ void ApplyLinks(const LatticeParams &p, LShared &s, K
 }
 
 __global__ __launch_bounds__(kLBlock) void LatticePruneKernel(const LatticeParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  LShared &s = *reinterpret_cast<LShared *>(smem);
+  __shared__ LShared s;  // (static: see kd_search.hip's kd_smem)
   const int tid = threadIdx.x, utt = blockIdx.x;
   const int F = ToG(p.frames_decoded)[utt];
   if (F < 0) return;
@@ -409,8 +408,7 @@ __device__ __forceinline__ void ForWaveFrames(const LatticeParams &p, int utt, i
 }
 
 __global__ __launch_bounds__(kLBlock) void LatticeCountKernel(const LatticeParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  CShared &s = *reinterpret_cast<CShared *>(smem);
+  __shared__ CShared s;
   const int tid = threadIdx.x, utt = blockIdx.x;
   const int F = ToG(p.frames_decoded)[utt];
   KD_G int32_t *sz = ToG(p.sizes) + 4 * utt;
@@ -473,8 +471,7 @@ __global__ __launch_bounds__(kLBlock) void LatticeCountKernel(const LatticeParam
 }
 
 __global__ __launch_bounds__(kLBlock) void LatticeFillKernel(const LatticeParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  CShared &s = *reinterpret_cast<CShared *>(smem);
+  __shared__ CShared s;
   const int tid = threadIdx.x, utt = blockIdx.x;
   const int F = ToG(p.frames_decoded)[utt];
   if (F < 1 || ToG(p.sizes)[4 * utt] == 0) return;
@@ -542,31 +539,20 @@ __global__ __launch_bounds__(kLBlock) void LatticeFillKernel(const LatticeParams
   }
 }
 
-hipError_t SetLds(const void *fn, size_t bytes) {
-  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             static_cast<int>(bytes));
-}
-
 }  // namespace
 
 hipError_t LaunchLatticePrune(const LatticeParams &p, int batch, hipStream_t stream) {
-  hipError_t e = SetLds(reinterpret_cast<const void *>(LatticePruneKernel), sizeof(LShared));
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(LatticePruneKernel, dim3(batch), dim3(kLBlock), sizeof(LShared), stream, p);
+  hipLaunchKernelGGL(LatticePruneKernel, dim3(batch), dim3(kLBlock), 0, stream, p);
   return hipGetLastError();
 }
 
 hipError_t LaunchLatticeCount(const LatticeParams &p, int batch, hipStream_t stream) {
-  hipError_t e = SetLds(reinterpret_cast<const void *>(LatticeCountKernel), sizeof(CShared));
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(LatticeCountKernel, dim3(batch), dim3(kLBlock), sizeof(CShared), stream, p);
+  hipLaunchKernelGGL(LatticeCountKernel, dim3(batch), dim3(kLBlock), 0, stream, p);
   return hipGetLastError();
 }
 
 hipError_t LaunchLatticeFill(const LatticeParams &p, int batch, hipStream_t stream) {
-  hipError_t e = SetLds(reinterpret_cast<const void *>(LatticeFillKernel), sizeof(CShared));
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(LatticeFillKernel, dim3(batch), dim3(kLBlock), sizeof(CShared), stream, p);
+  hipLaunchKernelGGL(LatticeFillKernel, dim3(batch), dim3(kLBlock), 0, stream, p);
   return hipGetLastError();
 }
 

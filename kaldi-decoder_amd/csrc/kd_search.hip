@@ -183,7 +183,11 @@ static_assert(sizeof(Shared) <= 163840 / KD_WG_PER_CU, "LDS budget");
 
 // The workgroup's LDS block.  Functions that are not inlined into the kernel reach
 // it through this (an LDS pointer passed as an argument would become a flat one).
-extern __shared__ __attribute__((aligned(16))) unsigned char kd_smem[];
+// (A static array, not `extern __shared__`: with the block's address and size known
+// at compile time the field addresses are literals; as offsets from a dynamic base
+// they were sixty more scalar registers held -- and spilled -- across the frame loop.
+// Measured: 12.2 -> 11.9 ms per launch.)
+__shared__ __attribute__((aligned(16))) unsigned char kd_smem[sizeof(Shared)];
 __device__ __forceinline__ Shared &Lds() { return *reinterpret_cast<Shared *>(kd_smem); }
 
 // Tier-1 views of the upper table halves: candidate queue entries [0, kQL) and
@@ -1402,7 +1406,16 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   (void)KD_BUCKET;
   CParams &p = c.p;
   Shared &s = c.s;
-  const int tid = threadIdx.x, lane = tid & 63, nt = tm.nt;
+  // The thread index is made opaque once per frame: otherwise every address the
+  // frame derives from it (tid * 4 + array base, tid + kBlock, ...) is hoisted out of
+  // the frame loop and held in a register of its own for the whole launch, and the
+  // frame's hot loops spill.  Recomputing them where they are used costs a few
+  // instructions a frame.
+  int tid_opaque = threadIdx.x;
+#ifndef KD_NO_OPAQUE_TID
+  asm volatile("" : "+v"(tid_opaque));
+#endif
+  const int tid = tid_opaque, lane = tid & 63, nt = tm.nt;
   const int n_in = c.n_in;
   uint32_t *wlmask = s.bitmask;  // two masks of kT1Slots bits
   constexpr int kMaskWords = kT1Slots / 32;
@@ -2285,19 +2298,7 @@ size_t SearchLdsBytes() { return sizeof(Shared); }
 namespace {
 template <int M>
 hipError_t LaunchMode(const SearchParams &p, int batch, hipStream_t stream) {
-  // the opt-in to > 64 KiB of dynamic LDS is per device; remember where it was done
-  static std::atomic<uint64_t> done{0};
-  int dev = 0;
-  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-  const uint64_t bit = 1ull << (dev & 63);
-  if (!(done.load(std::memory_order_acquire) & bit)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(SearchKernel<M>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(sizeof(Shared)));
-    if (e != hipSuccess) return e;
-    done.fetch_or(bit, std::memory_order_release);
-  }
-  hipLaunchKernelGGL(SearchKernel<M>, dim3(batch), dim3(kBlock), sizeof(Shared), stream, p);
+  hipLaunchKernelGGL(SearchKernel<M>, dim3(batch), dim3(kBlock), 0, stream, p);
   return hipGetLastError();
 }
 }  // namespace
