@@ -2162,7 +2162,7 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
     bool filtered = false;  // the emitting filter already ran (tier 1 did not fit)
     if (small) {
       // a small frame of few tokens is run by the first four waves alone
-      const Team tm{c.n_in <= kT1Narrow ? 256 : kBlock, gen};
+      const Team tm{kT1Narrow > 0 && c.n_in <= kT1Narrow ? 256 : kBlock, gen};
       const bool have_next = c.ll_in_lds && frame + 1 < target;
       if (tid < tm.nt) {
         float ll_next[kPfRegs];
