@@ -110,7 +110,35 @@ constexpr int kQL = kT1Slots / 2;
 constexpr int kT1W16 = 512;    // tokens of at most 16 arcs (in Shared::hist)
 static_assert(kBlock >= 256 && kT1Front >= kBlock && kSlots == 2 * kT1Slots && 2 * kQL == kT1Slots,
               "tier-1 LDS overlay");
-constexpr unsigned long long kCostInf = 0xFFF0000000000000ull;  // CostKey(+inf)
+// Cost keys: order-preserving 64-bit images of costs, so that one integer atomicMin
+// relaxes a state.  FasterDecoder / SimpleDecoder costs are doubles (CostKey).  The
+// lattice decoders' costs are floats: their key is the float's 32-bit key in the
+// high word (low word zero) -- no f64 conversion and no 64-bit arithmetic per arc
+// (MI355X issues those at a fraction of the 32-bit rate).  Keys never leave this
+// file; a launch uses one mapping throughout.
+template <int M>
+__device__ __forceinline__ unsigned long long CK(double d) {
+  if constexpr (M == 1) return static_cast<unsigned long long>(FloatKey(static_cast<float>(d))) << 32;
+  else return CostKey(d);
+}
+template <int M>
+__device__ __forceinline__ unsigned long long CKf(float f) {  // (lattice: the cost as it was computed)
+  if constexpr (M == 1) return static_cast<unsigned long long>(FloatKey(f)) << 32;
+  else return CostKey(static_cast<double>(f));
+}
+template <int M>
+__device__ __forceinline__ float KCf(unsigned long long k) {
+  if constexpr (M == 1) return KeyFloat(static_cast<uint32_t>(k >> 32));
+  else return static_cast<float>(KeyCost(k));
+}
+template <int M>
+__device__ __forceinline__ double KC(unsigned long long k) {
+  if constexpr (M == 1) return static_cast<double>(KeyFloat(static_cast<uint32_t>(k >> 32)));
+  else return KeyCost(k);
+}
+// key of +infinity
+template <int M>
+constexpr unsigned long long kCostInf = M == 1 ? 0xFF80000000000000ull : 0xFFF0000000000000ull;
 // Global-table tier: tokens / queue entries a lane reads at a time in the passes that
 // only read the table.  Every read there is an L2 round trip (agent-scope loads), so
 // a lane keeps kSpillIlp independent ones in flight instead of one.  (The insert
@@ -330,8 +358,9 @@ __device__ __forceinline__ double Uni(double v) {
 __device__ __forceinline__ float Uni(float v) { return __int_as_float(Uni(__float_as_int(v))); }
 
 // Per-frame counters, reset by one thread at the end of a frame for the next one.
+template <int M>
 __device__ __forceinline__ void ResetFrame(Shared &s) {
-  s.min_new = kCostInf;
+  s.min_new = kCostInf<M>;
   s.wl_count[0] = 0;
   s.wl_count[1] = 0;
   s.q_n = 0;
@@ -342,7 +371,7 @@ __device__ __forceinline__ void ResetFrame(Shared &s) {
   s.n_emit_links = 0;
   s.n_eps_links = 0;
   s.n_emit_written = 0;
-  s.min_stored = kCostInf;
+  s.min_stored = kCostInf<M>;
   s.n_act = 0;
   s.n_inact = 0;
   s.it_count[0] = 0;
@@ -441,6 +470,20 @@ struct Table {
   __device__ __forceinline__ unsigned long long LoadCost(uint32_t h) const {
     if constexpr (LDS) return s.cost[h];
     else return __hip_atomic_load(ToFlat(&gcost[h]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // The cost word as decoder M keys it.  The lattice decoders' keys live in the high
+  // word (the low word is zero): the global table is asked for that word only.  (Also
+  // a necessity: this hipcc's instruction selection crashes when it narrows the 64-bit
+  // atomic load to its high half by itself.)
+  template <int M>
+  __device__ __forceinline__ unsigned long long LoadCostM(uint32_t h) const {
+    if constexpr (LDS || M != 1) {
+      return LoadCost(h);
+    } else {
+      const uint32_t hi = __hip_atomic_load(reinterpret_cast<uint32_t *>(ToFlat(&gcost[h])) + 1,
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return static_cast<unsigned long long>(hi) << 32;
+    }
   }
   __device__ __forceinline__ void StoreCost(uint32_t h, unsigned long long v) const {
     if constexpr (LDS) s.cost[h] = v;
@@ -544,11 +587,11 @@ __device__ __forceinline__ bool ScoreArc(const FrameCtx<M> &c, const ArcRec &a, 
                   tot_cost = cur_cost + ac_cost + a.weight;
       nc = tot_cost;
       aux = ac_cost;
-      return tot_cost < static_cast<float>(KeyCost(seen_min)) + c.adaptive_beam;
+      return tot_cost < KCf<M>(seen_min) + c.adaptive_beam;
     }
     const float ac_cost = -1 * ll;   // :209
     nc = a.weight + csrc + ac_cost;  // :210 (== Token cost, faster-decoder.h:126)
-    return nc < KeyCost(seen_min) + static_cast<double>(c.adaptive_beam);  // :211, :215-217
+    return nc < KC<M>(seen_min) + static_cast<double>(c.adaptive_beam);  // :211, :215-217
   }
 }
 
@@ -595,7 +638,7 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
     const float acoustic_cost = -ll;
     const double total_cost = csrc + a.weight + acoustic_cost;
     if (c.min_only) {
-      const unsigned long long tk = CostKey(total_cost);
+      const unsigned long long tk = CK<M>(total_cost);
       if (tk < seen_min) c.run_min = tk;
       return;
     }
@@ -606,7 +649,7 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
     keep = ScoreArc<EPS>(c, a, csrc, seen_min, nc, aux);
   }
   if (keep) {
-    const unsigned long long nk = CostKey(nc);
+    const unsigned long long nk = CK<M>(nc);
     const int pos = AggInc(&s.q_n);
     if (T1) {
       T1Put(c, pos, a, aidx, srcid, nk, aux);
@@ -714,7 +757,7 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
       } else {
         const uint32_t hs = wl_in[i];
         st = t.LoadKey(hs) & kStateMask;
-        cst = KeyCost(t.LoadCost(hs));
+        cst = KC<M>(t.template LoadCostM<M>(hs));
         srcid = hs | kSrcEps;
         ok = !(cst > c.cutoff);  // faster-decoder.cc:74
       }
@@ -867,7 +910,7 @@ __device__ __forceinline__ void FrontierStats(const FrameCtx<M> &c) {
   unsigned long long mk = kCostDead;
   int mi = -1;
   for (int i = tid; i < c.n_in; i += kBlock) {
-    const unsigned long long k = CostKey(ToG(p.tok_cost)[c.base_in + i]);
+    const unsigned long long k = CK<M>(ToG(p.tok_cost)[c.base_in + i]);
     if (k < mk) { mk = k; mi = i; }
   }
   const unsigned long long best = BlockMinU64(s, mk);
@@ -877,7 +920,7 @@ __device__ __forceinline__ void FrontierStats(const FrameCtx<M> &c) {
     const StateRec r = LoadState(p.states, static_cast<uint32_t>(ToG(p.tok_state)[c.base_in + mi]));
     s.best_abeg = r.arc_begin;
     s.best_deg = r.emit_end - r.arc_begin;
-    s.best_cost = KeyCost(best);
+    s.best_cost = KC<M>(best);
   }
   __syncthreads();
 }
@@ -888,7 +931,7 @@ __device__ __forceinline__ void GetCutoff(FrameCtx<M> &c, const Team &tm) {
   CParams &p = c.p;
   Shared &s = c.s;
   const int tid = threadIdx.x;
-  const double best_cost = Uni(KeyCost(s.f_best));
+  const double best_cost = Uni(KC<M>(s.f_best));
   const double beam_cutoff = best_cost + p.beam;
   if (p.max_active == INT_MAX && p.min_active == 0) {  // :249-272
     // LatticeSimpleDecoder has no cutoff on the tokens it expands (:376-401)
@@ -965,7 +1008,7 @@ __device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
   // Bound the next cutoff from the best token's arcs first (:176-189); it only
   // shortens the queue, the final cutoff is the same.
   if (!c.simple) {
-    unsigned long long mk = kCostInf;
+    unsigned long long mk = kCostInf<M>;
     const int bdeg = s.best_deg, babeg = s.best_abeg;
     const double bcost = s.best_cost;
     for (int a = tid; a < bdeg; a += kBlock) {
@@ -973,12 +1016,12 @@ __device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
       const float ll = c.ll_in_lds ? s.ll[arc.ilabel - 1] : c.ll_row[arc.ilabel - 1];
       const float ac_cost = -1 * ll;
       const unsigned long long k =
-          c.lattice ? CostKey(static_cast<double>(static_cast<float>(bcost) + ac_cost + arc.weight))
-                    : CostKey(arc.weight + bcost + ac_cost);
+          c.lattice ? CK<M>(static_cast<double>(static_cast<float>(bcost) + ac_cost + arc.weight))
+                    : CK<M>(arc.weight + bcost + ac_cost);
       mk = k < mk ? k : mk;
     }
     mk = WaveMinU64(mk);
-    if ((tid & 63) == 0 && mk != kCostInf) atomicMin(&s.min_new, mk);
+    if ((tid & 63) == 0 && mk != kCostInf<M>) atomicMin(&s.min_new, mk);
   }
   KD_LAP(s, 2);
   Table<true> none{s, nullptr, nullptr, nullptr, nullptr, 0, 0};
@@ -988,7 +1031,7 @@ __device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
   for (int pass = c.simple ? 0 : 1; pass < 3; ++pass) {
     c.min_only = pass == 0;
     if (pass == 1 && c.simple) {
-      c.cutoff = KeyCost(s.min_new) + static_cast<double>(p.beam);
+      c.cutoff = KC<M>(s.min_new) + static_cast<double>(p.beam);
       cnt = Counters();
     }
     if (pass == 2) {
@@ -1004,9 +1047,9 @@ __device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
   }
   if (c.simple) return;
   if (c.lattice)  // float, lattice-simple-decoder.cc:388-390
-    c.cutoff = static_cast<float>(KeyCost(s.min_new)) + c.adaptive_beam;
+    c.cutoff = KCf<M>(s.min_new) + c.adaptive_beam;
   else
-    c.cutoff = KeyCost(s.min_new) + static_cast<double>(c.adaptive_beam);  // value of :240
+    c.cutoff = KC<M>(s.min_new) + static_cast<double>(c.adaptive_beam);  // value of :240
 }
 
 template <bool LDS>
@@ -1048,7 +1091,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
   Shared &s = c.s;
   const int tid = threadIdx.x;
   // simple mode queued exactly what is below the cutoff (on the total cost)
-  const unsigned long long cutkey = c.simple ? kCostDead : CostKey(c.cutoff);
+  const unsigned long long cutkey = c.simple ? kCostDead : CK<M>(c.cutoff);
 
   if (frame < 0) {
     if (tid == 0) {  // faster-decoder.cc:49-51: dummy arc into the start state, cost 0
@@ -1056,7 +1099,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
       const bool eps = r.arc_end > r.emit_end;
       const uint32_t h = t.Hash(static_cast<uint32_t>(p.start));
       t.StoreKey(h, static_cast<uint32_t>(p.start) | (eps ? kHasEps : 0u));
-      t.StoreCost(h, CostKey(0.0));
+      t.StoreCost(h, CK<M>(0.0));
       c.live[0] = h;
       s.n_live = 1;
       if (eps) { c.wl0[0] = h; s.wl_count[0] = 1; }
@@ -1068,7 +1111,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
   KD_LAP(s, 5);
   if (s.overflow) return kRetry;
   if (c.simple)  // ProcessNonemitting: best stored cost + beam (simple-decoder.cc:199-205)
-    c.cutoff = (frame < 0 ? 0.0 : KeyCost(s.min_stored)) + static_cast<double>(p.beam);
+    c.cutoff = (frame < 0 ? 0.0 : KC<M>(s.min_stored)) + static_cast<double>(p.beam);
 
   // ProcessNonemitting to a fixpoint (:59-119)
   int cur = 0, q_begin = q_emit;
@@ -1112,7 +1155,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
       const int i = u * kBlock + tid;
       if (i < n_q) {
         const uint32_t h = c.q_h[i];
-        if (h != kKeyEmpty && t.LoadCost(h) == c.q_nk[i]) {
+        if (h != kKeyEmpty && t.template LoadCostM<M>(h) == c.q_nk[i]) {
           const uint32_t aidx = c.q_arc[i];
           atomicMin(t.ArcP(h), aidx);
           lg_h[u] = h;
@@ -1122,7 +1165,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
     }
     for (int i = kQRegs * kBlock + tid; i < n_q; i += kBlock) {
       const uint32_t h = c.q_h[i];
-      if (h != kKeyEmpty && t.LoadCost(h) == c.q_nk[i]) atomicMin(t.ArcP(h), c.q_arc[i]);
+      if (h != kKeyEmpty && t.template LoadCostM<M>(h) == c.q_nk[i]) atomicMin(t.ArcP(h), c.q_arc[i]);
     }
   }
   if (tid == 0) {
@@ -1148,11 +1191,11 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
   if (c.simple) {
     unsigned long long mk = kCostDead;
     for (int i = tid; i < n_out; i += kBlock) {
-      const unsigned long long ck = t.LoadCost(c.live[i]);
+      const unsigned long long ck = t.template LoadCostM<M>(c.live[i]);
       mk = ck < mk ? ck : mk;
     }
     mk = BlockMinU64(s, mk);
-    prune_key = CostKey(KeyCost(mk) + static_cast<double>(p.beam));
+    prune_key = CK<M>(KC<M>(mk) + static_cast<double>(p.beam));
   }
   // C1: live list -> (state, cost); a slot's key word now holds its index in the block.
   unsigned long long my_min = kCostDead;
@@ -1167,7 +1210,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
       for (int u = 0; u < U; ++u) h[u] = c.live[i0 + u * kBlock < n_out ? i0 + u * kBlock : 0];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        ckv[u] = t.LoadCost(h[u]);
+        ckv[u] = t.template LoadCostM<M>(h[u]);
         kw[u] = t.LoadKey(h[u]);
         aw[u] = M != 1 ? t.LoadArc(h[u]) : 0u;  // (lattice tokens have no back-pointers)
       }
@@ -1181,7 +1224,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
         const long long g = base_out + i;
         const uint32_t st_of_tok = kw[u] & kStateMask;
         ToG(p.tok_state)[g] = static_cast<int32_t>(st_of_tok);
-        ToG(p.tok_cost)[g] = KeyCost(ck);
+        ToG(p.tok_cost)[g] = KC<M>(ck);
         if (c.lattice) ToG(p.tok_extra)[g] = 0.0f;  // lattice-simple-decoder.cc:91-95
         if (M != 1 && aw[u] == kArcNone) {  // the start token
           ToG(p.tok_prev)[g] = -1;
@@ -1218,7 +1261,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
         const uint32_t h = c.q_h[i];
         if (h == kKeyEmpty) continue;
         const uint32_t aidx = c.q_arc[i];
-        if (t.LoadCost(h) == c.q_nk[i] && t.LoadArc(h) == aidx) write_bp(h, aidx, i);
+        if (t.template LoadCostM<M>(h) == c.q_nk[i] && t.LoadArc(h) == aidx) write_bp(h, aidx, i);
       }
     }
   }
@@ -1248,7 +1291,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
         } else {
           const uint32_t hs = sr & ~kSrcEps;
           // source cost at generation vs its final cost (its slot's cost word is intact)
-          if (c.q_ac[i] != static_cast<float>(KeyCost(t.LoadCost(hs)))) continue;
+          if (c.q_ac[i] != KCf<M>(t.template LoadCostM<M>(hs))) continue;
           src_tok = base_out + t.LoadKey(hs);
           ac = 0.0f;
           at = lbase + n_emit + AggInc(&s.n_eps_links);
@@ -1259,8 +1302,8 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
         ToG(p.link_arc)[at] = static_cast<int32_t>(aidx);
         ToG(p.link_ac)[at] = ac;
         ToG(p.link_graph)[at] = c.q_gr[i];
-        ToG(p.link_delta)[at] = static_cast<float>(KeyCost(c.q_nk[i])) -
-                                static_cast<float>(KeyCost(t.LoadCost(h)));
+        ToG(p.link_delta)[at] = KCf<M>(c.q_nk[i]) -
+                                KCf<M>(t.template LoadCostM<M>(h));
       }
     } else {
       // global-table tier: kSpillIlp entries per lane, their queue words and then their
@@ -1287,9 +1330,9 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
           ok[u] = i < n_q && h[u] != kKeyEmpty;
           const uint32_t hd = ok[u] ? h[u] : 0u, hs = ok[u] && i >= q_emit ? sr[u] & ~kSrcEps : 0u;
           kd[u] = t.LoadKey(hd);
-          cd[u] = t.LoadCost(hd);
+          cd[u] = t.template LoadCostM<M>(hd);
           ks[u] = t.LoadKey(hs);
-          cs[u] = t.LoadCost(hs);
+          cs[u] = t.template LoadCostM<M>(hs);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1303,7 +1346,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
             at = lbase + AggInc(&s.n_emit_written);
           } else {
             // source cost at generation vs its final cost (its slot's cost word is intact)
-            if (qa[u] != static_cast<float>(KeyCost(cs[u]))) continue;
+            if (qa[u] != KCf<M>(cs[u])) continue;
             src_tok = base_out + ks[u];
             ac = 0.0f;
             at = lbase + n_emit + AggInc(&s.n_eps_links);
@@ -1313,7 +1356,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
           ToG(p.link_arc)[at] = static_cast<int32_t>(aidx[u]);
           ToG(p.link_ac)[at] = ac;
           ToG(p.link_graph)[at] = qg[u];
-          ToG(p.link_delta)[at] = static_cast<float>(KeyCost(nk[u])) - static_cast<float>(KeyCost(cd[u]));
+          ToG(p.link_delta)[at] = KCf<M>(nk[u]) - KCf<M>(cd[u]);
         }
       }
     }
@@ -1325,7 +1368,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
     const StateRec r = LoadState(p.states, my_min_state);
     s.best_abeg = r.arc_begin;
     s.best_deg = r.emit_end - r.arc_begin;
-    s.best_cost = KeyCost(best);
+    s.best_cost = KC<M>(best);
   }
   if (tid == 0) {
     const long long fi = static_cast<long long>(c.utt) * (p.max_frames + 1) + (frame + 1);
@@ -1490,7 +1533,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       if (on[g]) {
         double nc;
         keep[g] = ScoreArc<EPS>(c, ar[g], cst[g], seen, nc, aux[g]);
-        nk[g] = CostKey(nc);
+        nk[g] = CK<M>(nc);
       }
       bal[g] = __ballot(keep[g]);
       pre[g] = total;
@@ -1593,7 +1636,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   using EpsYes = std::true_type;
 
   if (tid < kMaskWords) wlmask[tid] = 0;  // worklist 0 collects the emitting insert's tokens
-  c.run_min = kCostInf;
+  c.run_min = kCostInf<M>;
   GetCutoff<true>(c, tm);
   KD_LAP(s, 1);
 
@@ -1624,16 +1667,16 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   }
   const int q_emit = Uni(s.q_n);
   if (c.lattice)  // float, lattice-simple-decoder.cc:388-390
-    c.cutoff = static_cast<float>(KeyCost(s.min_new)) + c.adaptive_beam;
+    c.cutoff = KCf<M>(s.min_new) + c.adaptive_beam;
   else
-    c.cutoff = KeyCost(s.min_new) + static_cast<double>(c.adaptive_beam);  // value of :240
+    c.cutoff = KC<M>(s.min_new) + static_cast<double>(c.adaptive_beam);  // value of :240
   c.cutoff = Uni(c.cutoff);
   if (tid == 0) {  // what a replay in the big table needs
     s.ctl[frame & 1].q_emit = q_emit;
     s.ctl[frame & 1].cutoff = c.cutoff;
   }
   if (q_emit > c.q_cap) return kRedo;  // the big path scans again under the final cutoff
-  const unsigned long long cutkey = CostKey(c.cutoff);
+  const unsigned long long cutkey = CK<M>(c.cutoff);
 
   // Insert queue entries [b, e): claim + relax; a token that is new, or (epsilon
   // rounds) improved, and has epsilon arcs is flagged in worklist mask `out`.
@@ -1708,7 +1751,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
         int abeg[2], deg[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          cst[j] = KeyCost(s.cost[h[j]]);
+          cst[j] = KC<M>(s.cost[h[j]]);
           ok[j] = (j == 0 || two) && !(cst[j] > c.cutoff);  // :74
           r[j] = LoadState(p.states, s.key[h[j]] & kStateMask);
         }
@@ -1816,12 +1859,12 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     const uint32_t st = s.key[h] & kStateMask;
     const long long g = base_out + i;
     ToG(p.tok_state)[g] = static_cast<int32_t>(st);
-    ToG(p.tok_cost)[g] = KeyCost(ck);
+    ToG(p.tok_cost)[g] = KC<M>(ck);
     if (c.lattice) ToG(p.tok_extra)[g] = 0.0f;  // lattice-simple-decoder.cc:91-95
     my_min = ck < my_min ? ck : my_min;
     s.key[h] = static_cast<uint32_t>(i);
     if (next_small) {
-      s.it_cost[i] = KeyCost(ck);
+      s.it_cost[i] = KC<M>(ck);
       s.it_src[i] = st;
     }
   }
@@ -1868,7 +1911,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
         at = lbase + AggInc(&s.n_emit_written);
       } else {
         const uint32_t hs = sr & ~kSrcEps;
-        if (q_ac(i) != static_cast<float>(KeyCost(s.cost[hs]))) continue;
+        if (q_ac(i) != KCf<M>(s.cost[hs])) continue;
         src_tok = base_out + s.key[hs];
         ac = 0.0f;
         at = lbase + n_emit + AggInc(&s.n_eps_links);
@@ -1879,7 +1922,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       ToG(p.link_ac)[at] = ac;
       ToG(p.link_graph)[at] = q_gr(i);
       ToG(p.link_delta)[at] =
-          static_cast<float>(KeyCost(q_nk(i))) - static_cast<float>(KeyCost(s.cost[h]));
+          KCf<M>(q_nk(i)) - KCf<M>(s.cost[h]);
     }
   }
   KD_LAP(s, 17);
@@ -1923,7 +1966,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       s.link_next = lbase + n_emit + n_eps;
       atomicAdd(&s.ustat[KD_STAT_LINKS], static_cast<unsigned long long>(n_emit + n_eps));
     }
-    ResetFrame(s);
+    ResetFrame<M>(s);
     s.f_best = best;
     s.ctl[frame & 1].n_in = n_out;
     s.ctl[frame & 1].base_out = base_out;
@@ -1962,7 +2005,7 @@ __device__ __forceinline__ void InitCtx(FrameCtx<M> &c, CParams &p, int utt) {
   c.q_ac = ToG(p.g_log_ac) + utt * 2 * gslots;
   c.q_gr = ToG(p.g_log_gr) + utt * 2 * gslots;
   c.min_only = false;
-  c.run_min = kCostInf;
+  c.run_min = kCostInf<M>;
   c.replay = false;
   c.ll_in_lds = p.num_cols <= kVmax;
 }
@@ -2147,7 +2190,7 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
   };
   // At the top of the loop the per-frame counters are reset and s.ll holds the
   // frame's log-likelihood row: a frame boundary costs one barrier.
-  if (tid == 0) ResetFrame(s);
+  if (tid == 0) ResetFrame<M>(s);
   if (err == 0) row_to_lds(frame);
   __syncthreads();
   Counters tot;  // per-lane work counters of the small frames, folded when the launch ends
@@ -2216,7 +2259,7 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
         // needs this frame's row back (its place was taken by the next frame's)
         r = kRetry;
         cnt = Counters();
-        if (tid == 0) ResetFrame(s);
+        if (tid == 0) ResetFrame<M>(s);
         row_to_lds(frame);
         __syncthreads();
       } else if (r == kRetry) {
@@ -2253,7 +2296,7 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
       // the next frame's start state; every wave's token stores have landed before a
       // small team reads them
       __syncthreads();
-      if (tid == 0) ResetFrame(s);
+      if (tid == 0) ResetFrame<M>(s);
       if (tid < 4) s.frame_cnt[tid] = 0;
       row_to_lds(frame + 1);
       __syncthreads();
