@@ -673,6 +673,62 @@ __device__ __forceinline__ void PublishMin(const FrameCtx<M> &c) {
   if (c.run_min < c.s.min_new) atomicMin(&c.s.min_new, c.run_min);
 }
 
+// Scores N arcs per lane (`on[g]`: this lane holds arc g) and appends the survivors to
+// the candidate queue in global memory with ONE queue allocation for the wave (the big
+// tiers' form of the tier-1 frames' score_batch).  Call where the wave is converged.
+// Not for SimpleDecoder's emitting arcs (two passes: FilterArc).
+template <bool EPS, int N, int M>
+__device__ __forceinline__ void ScoreBatchBig(const FrameCtx<M> &c, const ArcRec (&ar)[N],
+                                              const uint32_t (&aidx)[N], const bool (&on)[N],
+                                              const double (&cst)[N], const uint32_t (&src)[N]) {
+  Shared &s = c.s;
+  unsigned long long seen = 0;
+  if constexpr (!EPS) {
+    seen = s.min_new;
+    seen = c.run_min < seen ? c.run_min : seen;
+  }
+  unsigned long long nk[N], bal[N];
+  float aux[N];
+  bool keep[N];
+  int pre[N], total = 0;
+#pragma unroll
+  for (int g = 0; g < N; ++g) {
+    keep[g] = false;
+    nk[g] = 0;
+    aux[g] = 0.f;
+    if (on[g]) {
+      double nc;
+      keep[g] = ScoreArc<EPS>(c, ar[g], cst[g], seen, nc, aux[g]);
+      nk[g] = CK<M>(nc);
+    }
+    bal[g] = __ballot(keep[g]);
+    pre[g] = total;
+    total += __popcll(bal[g]);
+  }
+  if (total == 0) return;
+  int base = 0;
+  if ((threadIdx.x & 63) == 0) base = atomicAdd(&s.q_n, total);
+  base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+  for (int g = 0; g < N; ++g) {
+    if (!keep[g]) continue;
+    const int pos = base + pre[g] +
+                    __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(bal[g] >> 32),
+                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(bal[g]), 0));
+    if (pos < c.q_cap) {
+      c.q_h[pos] = ar[g].next;
+      c.q_arc[pos] = aidx[g];
+      c.q_src[pos] = src[g];
+      c.q_nk[pos] = nk[g];
+      if (c.lattice || c.simple) c.q_ac[pos] = aux[g];
+      if (c.lattice) c.q_gr[pos] = ar[g].weight;
+    }
+    if constexpr (!EPS) {
+      if (nk[g] < c.run_min) c.run_min = nk[g];
+    }
+  }
+}
+
 // High-degree tokens queued by a filter pass: a wave takes kGroup of them at a
 // time, lanes over consecutive arcs; the first 64 arcs of all kGroup tokens are
 // loaded before any is scored so their latencies overlap.  `range(q, abeg, deg)`
@@ -697,14 +753,29 @@ __device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int par, int nq, R
       if (q0 + g < nq) range(q0 + g, abeg[g], deg[g]);
       ar[g] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg[g] + lane), lane < deg[g], 0u);
     }
+    if constexpr (!T1 && (EPS || M != 2)) {
+      uint32_t aidx[kGroup], src[kGroup];
+      bool on[kGroup];
+      double cst[kGroup];
 #pragma unroll
-    for (int g = 0; g < kGroup; ++g)
-      if (lane < deg[g]) {
-        double cst;
-        uint32_t srcid;
-        source(q0 + g, cst, srcid);
-        FilterArc<EPS, T1>(c, ar[g], static_cast<uint32_t>(abeg[g] + lane), cst, srcid);
+      for (int g = 0; g < kGroup; ++g) {
+        on[g] = lane < deg[g];
+        aidx[g] = static_cast<uint32_t>(abeg[g] + lane);
+        cst[g] = 0.0;
+        src[g] = 0;
+        if (q0 + g < nq) source(q0 + g, cst[g], src[g]);
       }
+      ScoreBatchBig<EPS>(c, ar, aidx, on, cst, src);
+    } else {
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g)
+        if (lane < deg[g]) {
+          double cst;
+          uint32_t srcid;
+          source(q0 + g, cst, srcid);
+          FilterArc<EPS, T1>(c, ar[g], static_cast<uint32_t>(abeg[g] + lane), cst, srcid);
+        }
+    }
     if constexpr (!EPS) PublishMin(c);
     // tails of tokens with more than 64 arcs, four wave-rows in flight
 #pragma unroll 1
@@ -713,16 +784,31 @@ __device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int par, int nq, R
       double cst;
       uint32_t srcid;
       source(q0 + g, cst, srcid);
-      for (int a0 = 64 + lane; a0 < deg[g]; a0 += 256) {
+      for (int r0 = 64; r0 < deg[g]; r0 += 256) {  // (wave-uniform: every lane takes every round)
+        const int a0 = r0 + lane;
         ArcRec tr[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           tr[u] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg[g] + a0 + 64 * u),
                                a0 + 64 * u < deg[g], static_cast<uint32_t>(abeg[g]));
+        if constexpr (!T1 && (EPS || M != 2)) {
+          uint32_t aidx[4], src[4];
+          bool on[4];
+          double cs[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (a0 + 64 * u < deg[g])
-            FilterArc<EPS, T1>(c, tr[u], static_cast<uint32_t>(abeg[g] + a0 + 64 * u), cst, srcid);
+          for (int u = 0; u < 4; ++u) {
+            on[u] = a0 + 64 * u < deg[g];
+            aidx[u] = static_cast<uint32_t>(abeg[g] + a0 + 64 * u);
+            cs[u] = cst;
+            src[u] = srcid;
+          }
+          ScoreBatchBig<EPS>(c, tr, aidx, on, cs, src);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (a0 + 64 * u < deg[g])
+              FilterArc<EPS, T1>(c, tr[u], static_cast<uint32_t>(abeg[g] + a0 + 64 * u), cst, srcid);
+        }
       }
     }
     if constexpr (!EPS) PublishMin(c);
