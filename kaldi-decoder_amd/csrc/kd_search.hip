@@ -1711,12 +1711,17 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   auto item_loop = [&](auto eps_tag) {
     const int n64 = Uni(s.it_count[0]), n32 = Uni(s.it_n32), n16r = Uni(s.it_n16);
     const int n16 = n16r < kT1W16 ? n16r : kT1W16;
-    rows(eps_tag, std::integral_constant<int, 64>{}, n64, &s.it_next[0],
-         [&](int q) -> int { return T1Heads(s)[q]; });
-    rows(eps_tag, std::integral_constant<int, 32>{}, n32, &s.it_next32,
-         [&](int q) -> int { return T1Heads(s)[kT1Front - 1 - q]; });
-    rows(eps_tag, std::integral_constant<int, 16>{}, n16, &s.it_next16,
-         [&](int q) -> int { return T1W16(s)[q]; });
+    // (an empty list is not entered: finding that out inside costs every wave an LDS
+    // round trip, and the epsilon rounds' lists are empty more often than not)
+    if (n64 > 0)
+      rows(eps_tag, std::integral_constant<int, 64>{}, n64, &s.it_next[0],
+           [&](int q) -> int { return T1Heads(s)[q]; });
+    if (n32 > 0)
+      rows(eps_tag, std::integral_constant<int, 32>{}, n32, &s.it_next32,
+           [&](int q) -> int { return T1Heads(s)[kT1Front - 1 - q]; });
+    if (n16 > 0)
+      rows(eps_tag, std::integral_constant<int, 16>{}, n16, &s.it_next16,
+           [&](int q) -> int { return T1W16(s)[q]; });
   };
   using EpsNo = std::false_type;
   using EpsYes = std::true_type;
@@ -2014,6 +2019,8 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   KD_LAP(s, 17);
   tm.Sync(false);
   KD_LAP(s, 12);
+  // (final now; read by every lane before thread 0 resets them for the next frame)
+  const int n_emit_fin = Uni(s.n_emit_links), n_eps_fin = Uni(s.n_eps_links);
   // ---- clear the table; publish the next frontier's arc ranges
   for (int i = tid; i < n_out; i += nt) {
     const int h = T1Live(s)[i];
@@ -2028,29 +2035,33 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       s.it_deg[tid + j * nt] = next_rec[j].emit_end - next_rec[j].arc_begin;
     }
   }
-  if (tid == 0) {
-    // frame index, launch counters (fire-and-forget LDS adds; the per-lane work
-    // counters are folded once, when the launch ends) and the next frame's start state
-    const long long fi = static_cast<long long>(c.utt) * (p.max_frames + 1) + (frame + 1);
-    ToG(p.frame_base)[fi] = base_out;
-    ToG(p.frame_count)[fi] = n_out;
+  if (tid == 64) {
+    // launch counters, by a thread of another wave than the one that prepares the next
+    // frame (fire-and-forget LDS adds; the per-lane work counters are folded once, when
+    // the launch ends)
     atomicAdd(&s.ustat[KD_STAT_ARCS_KEPT], static_cast<unsigned long long>(q_emit));
     atomicAdd(&s.ustat[KD_STAT_TOKENS_OUT], static_cast<unsigned long long>(n_out));
     atomicMax(&s.ustat[KD_STAT_MAX_TOKENS], static_cast<unsigned long long>(n_out));
     atomicAdd(&s.ustat[KD_STAT_FRAMES], 1ull);
     atomicAdd(&s.ustat[KD_STAT_SMALL_FRAMES], 1ull);
     atomicAdd(&s.ustat[KD_STAT_TOKENS_IN], static_cast<unsigned long long>(n_in));
+    if (c.lattice)
+      atomicAdd(&s.ustat[KD_STAT_LINKS], static_cast<unsigned long long>(n_emit_fin + n_eps_fin));
+  }
+  if (tid == 0) {
+    // frame index and the next frame's start state
+    const long long fi = static_cast<long long>(c.utt) * (p.max_frames + 1) + (frame + 1);
+    ToG(p.frame_base)[fi] = base_out;
+    ToG(p.frame_count)[fi] = n_out;
     const unsigned long long best = s.f_best_next;
-    const int n_emit = s.n_emit_links, n_eps = s.n_eps_links;
     if (c.lattice) {
       const long long lbase = s.link_next;
       const long long fb = static_cast<long long>(c.utt) * (p.max_frames + 1);
       ToG(p.link_emit_base)[fb + frame] = lbase;
-      ToG(p.link_emit_count)[fb + frame] = n_emit;
-      ToG(p.link_eps_base)[fb + frame + 1] = lbase + n_emit;
-      ToG(p.link_eps_count)[fb + frame + 1] = n_eps;
-      s.link_next = lbase + n_emit + n_eps;
-      atomicAdd(&s.ustat[KD_STAT_LINKS], static_cast<unsigned long long>(n_emit + n_eps));
+      ToG(p.link_emit_count)[fb + frame] = n_emit_fin;
+      ToG(p.link_eps_base)[fb + frame + 1] = lbase + n_emit_fin;
+      ToG(p.link_eps_count)[fb + frame + 1] = n_eps_fin;
+      s.link_next = lbase + n_emit_fin + n_eps_fin;
     }
     ResetFrame<M>(s);
     s.f_best = best;
