@@ -2182,7 +2182,8 @@ __device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long 
     __syncthreads();
   } else if (frame >= 0) {
     if (best_stale) FrontierStats(c);
-    FrameFront(c, cnt);
+    if (c.ll_in_lds) FrameFront(c, cnt);  // (two copies: see the tier-1 call)
+    else FrameFront(c, cnt);
     q_emit = s.q_n;
   } else {
     // faster-decoder.cc:53; the lattice decoders use best (= 0) + beam
@@ -2318,7 +2319,11 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
         }
         c.ll_row = row_of(frame);
         if (!front_lds) LoadFront(c, tm);
-        r = SmallFrame(c, t1, frame, cnt, tm, ll_next, have_next);
+        // (two copies of the frame on purpose: in each the compiler knows where the
+        // log-likelihood row is, and the copy for rows held in LDS loses the branch --
+        // and the wait for outstanding vector-memory operations -- per arc)
+        if (c.ll_in_lds) r = SmallFrame(c, t1, frame, cnt, tm, ll_next, have_next);
+        else r = SmallFrame(c, t1, frame, cnt, tm, ll_next, have_next);
         if (tid == 0) s.ctl[frame & 1].r = r;
         LdsBarrier();  // the whole workgroup again: nobody reads this frame's row any more
       } else {
