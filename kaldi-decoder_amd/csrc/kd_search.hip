@@ -1549,12 +1549,23 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   uint32_t *wlmask = s.bitmask;  // two masks of kT1Slots bits
   constexpr int kMaskWords = kT1Slots / 32;
 
-  auto q_h = [&](int i) -> uint32_t { return i < kQL ? T1QH(s)[i] : c.q_h[i]; };
-  auto q_nk = [&](int i) -> unsigned long long { return i < kQL ? T1QNk(s)[i] : c.q_nk[i]; };
-  auto q_arc = [&](int i) -> uint32_t { return i < kQL ? T1QArc(s)[i] : c.q_arc[i]; };
-  auto q_src = [&](int i) -> uint32_t { return i < kQL ? T1QSrc(s)[i] : c.q_src[i]; };
-  auto q_ac = [&](int i) -> float { return i < kQL ? T1QAc(s)[i] : c.q_ac[i]; };
-  auto q_gr = [&](int i) -> float { return i < kQL ? T1QGr(s)[i] : c.q_gr[i]; };
+  // Queue entry i: the first kQL entries are in LDS, the rest in global memory.  The
+  // passes over the queue run once per part (split): a loop that picks the location per
+  // entry makes hipcc wait for all outstanding vector-memory operations -- the pass's
+  // own stores -- before every LDS read behind the branch.
+  using InLds = std::true_type;
+  using InGlobal = std::false_type;
+  auto q_h = [&](auto w, int i) -> uint32_t { if constexpr (decltype(w)::value) return T1QH(s)[i]; else return c.q_h[i]; };
+  auto q_nk = [&](auto w, int i) -> unsigned long long { if constexpr (decltype(w)::value) return T1QNk(s)[i]; else return c.q_nk[i]; };
+  auto q_arc = [&](auto w, int i) -> uint32_t { if constexpr (decltype(w)::value) return T1QArc(s)[i]; else return c.q_arc[i]; };
+  auto q_src = [&](auto w, int i) -> uint32_t { if constexpr (decltype(w)::value) return T1QSrc(s)[i]; else return c.q_src[i]; };
+  auto q_ac = [&](auto w, int i) -> float { if constexpr (decltype(w)::value) return T1QAc(s)[i]; else return c.q_ac[i]; };
+  auto q_gr = [&](auto w, int i) -> float { if constexpr (decltype(w)::value) return T1QGr(s)[i]; else return c.q_gr[i]; };
+  auto split = [&](int b, int e, auto body) {  // body(where, lo, hi) over [b, e)
+    const int m = e < kQL ? e : kQL;
+    if (b < m) body(InLds{}, b, m);
+    if (e > kQL) body(InGlobal{}, b > kQL ? b : kQL, e);
+  };
   // queue entries past kQL are in global memory: their stores must have landed
   auto queue_sync = [&]() {
     tm.Sync(false);
@@ -1773,34 +1784,36 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // rounds) improved, and has epsilon arcs is flagged in worklist mask `out`.
   auto insert = [&](auto eps_tag, int b, int e, int out) {
     constexpr bool EPS = decltype(eps_tag)::value;
-    for (int i = b + tid; i < e; i += nt) {
-      const uint32_t k = q_h(i);
-      const unsigned long long nk = q_nk(i);
-      uint32_t h = kKeyEmpty;
-      if ((EPS || nk < cutkey) && !s.overflow) {
-        h = t.Claim(k);
-        if (h == kKeyEmpty) {
-          s.overflow = 1;
-        } else {
-          const unsigned long long old = atomicMin(&s.cost[h], nk);
-          bool push = false;
-          if (old == kCostDead) {  // the state's first token this frame
-            const int pos = AggInc(&s.n_live);
-            if (pos < static_cast<int>(t.FillLimit())) T1Live(s)[pos] = static_cast<uint16_t>(h);
-            else s.overflow = 1;
-            push = (k & kHasEps) != 0;  // every new token is expanded once (:63-65)
-          } else if (EPS && old > nk && (k & kHasEps)) {  // re-queue on improvement, :97-113
-            push = true;
+    split(b, e, [&](auto w, int lo, int hi) {
+      for (int i = lo + tid; i < hi; i += nt) {
+        const uint32_t k = q_h(w, i);
+        const unsigned long long nk = q_nk(w, i);
+        uint32_t h = kKeyEmpty;
+        if ((EPS || nk < cutkey) && !s.overflow) {
+          h = t.Claim(k);
+          if (h == kKeyEmpty) {
+            s.overflow = 1;
+          } else {
+            const unsigned long long old = atomicMin(&s.cost[h], nk);
+            bool push = false;
+            if (old == kCostDead) {  // the state's first token this frame
+              const int pos = AggInc(&s.n_live);
+              if (pos < static_cast<int>(t.FillLimit())) T1Live(s)[pos] = static_cast<uint16_t>(h);
+              else s.overflow = 1;
+              push = (k & kHasEps) != 0;  // every new token is expanded once (:63-65)
+            } else if (EPS && old > nk && (k & kHasEps)) {  // re-queue on improvement, :97-113
+              push = true;
+            }
+            if (push) {
+              atomicOr(&wlmask[out * kMaskWords + (h >> 5)], 1u << (h & 31));
+              s.wl_count[out] = 1;
+            }
+            if (!EPS && c.lattice) AggAdd1(&s.n_emit_links);
           }
-          if (push) {
-            atomicOr(&wlmask[out * kMaskWords + (h >> 5)], 1u << (h & 31));
-            s.wl_count[out] = 1;
-          }
-          if (!EPS && c.lattice) AggAdd1(&s.n_emit_links);
         }
+        if constexpr (decltype(w)::value) T1QH(s)[i] = h; else c.q_h[i] = h;
       }
-      if (i < kQL) T1QH(s)[i] = h; else c.q_h[i] = h;
-    }
+    });
   };
 
   insert(EpsNo{}, 0, q_emit, 0);
@@ -1907,10 +1920,12 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   const int n_q = q_begin;
   const int n_out = Uni(s.n_live);
   if constexpr (M != 1) {  // (lattice tokens keep forward links, not back-pointers)
-    for (int i = tid; i < n_q; i += nt) {
-      const uint32_t h = q_h(i);
-      if (h != kKeyEmpty && s.cost[h] == q_nk(i)) atomicMin(&s.arc[h], q_arc(i));
-    }
+    split(0, n_q, [&](auto w, int lo, int hi) {
+      for (int i = lo + tid; i < hi; i += nt) {
+        const uint32_t h = q_h(w, i);
+        if (h != kKeyEmpty && s.cost[h] == q_nk(w, i)) atomicMin(&s.arc[h], q_arc(w, i));
+      }
+    });
   }
   long long base_out;
   {
@@ -1969,18 +1984,20 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   KD_LAP(s, 11);
   // ---- R2: the winning entry of each slot writes the back-pointer
   if constexpr (M != 1) {
-    for (int i = tid; i < n_q; i += nt) {
-      const uint32_t h = q_h(i);
-      if (h == kKeyEmpty) continue;
-      const uint32_t aidx = q_arc(i);
-      if (s.cost[h] == q_nk(i) && s.arc[h] == aidx) {
-        const long long g = base_out + s.key[h];
-        const uint32_t sr = q_src(i);
-        const long long prev = (sr & kSrcEps) ? base_out + s.key[sr & ~kSrcEps] : c.base_in + sr;
-        ToG(p.tok_prev)[g] = static_cast<int32_t>(prev);
-        ToG(p.tok_arc)[g] = static_cast<int32_t>(aidx);
+    split(0, n_q, [&](auto w, int lo, int hi) {
+      for (int i = lo + tid; i < hi; i += nt) {
+        const uint32_t h = q_h(w, i);
+        if (h == kKeyEmpty) continue;
+        const uint32_t aidx = q_arc(w, i);
+        if (s.cost[h] == q_nk(w, i) && s.arc[h] == aidx) {
+          const long long g = base_out + s.key[h];
+          const uint32_t sr = q_src(w, i);
+          const long long prev = (sr & kSrcEps) ? base_out + s.key[sr & ~kSrcEps] : c.base_in + sr;
+          ToG(p.tok_prev)[g] = static_cast<int32_t>(prev);
+          ToG(p.tok_arc)[g] = static_cast<int32_t>(aidx);
+        }
       }
-    }
+    });
   }
   KD_LAP(s, 16);
   // ---- forward links (see FrameBack)
@@ -1990,31 +2007,32 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     const bool full = lbase + n_emit + (n_q - q_emit) >
                       static_cast<long long>(c.utt + 1) * static_cast<long long>(p.link_cap);
     if (full) return KD_UTT_ARENA_FULL;
-    for (int i = tid; i < n_q; i += nt) {
-      const uint32_t h = q_h(i);
-      if (h == kKeyEmpty) continue;
-      const uint32_t sr = q_src(i);
-      long long at, src_tok;
-      float ac;
-      if (i < q_emit) {
-        src_tok = c.base_in + sr;
-        ac = q_ac(i);
-        at = lbase + AggInc(&s.n_emit_written);
-      } else {
-        const uint32_t hs = sr & ~kSrcEps;
-        if (q_ac(i) != KCf<M>(s.cost[hs])) continue;
-        src_tok = base_out + s.key[hs];
-        ac = 0.0f;
-        at = lbase + n_emit + AggInc(&s.n_eps_links);
+    split(0, n_q, [&](auto w, int lo, int hi) {
+      for (int i = lo + tid; i < hi; i += nt) {
+        const uint32_t h = q_h(w, i);
+        if (h == kKeyEmpty) continue;
+        const uint32_t sr = q_src(w, i);
+        long long at, src_tok;
+        float ac;
+        if (i < q_emit) {
+          src_tok = c.base_in + sr;
+          ac = q_ac(w, i);
+          at = lbase + AggInc(&s.n_emit_written);
+        } else {
+          const uint32_t hs = sr & ~kSrcEps;
+          if (q_ac(w, i) != KCf<M>(s.cost[hs])) continue;
+          src_tok = base_out + s.key[hs];
+          ac = 0.0f;
+          at = lbase + n_emit + AggInc(&s.n_eps_links);
+        }
+        ToG(p.link_src)[at] = static_cast<int32_t>(src_tok);
+        ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + s.key[h]);
+        ToG(p.link_arc)[at] = static_cast<int32_t>(q_arc(w, i));
+        ToG(p.link_ac)[at] = ac;
+        ToG(p.link_graph)[at] = q_gr(w, i);
+        ToG(p.link_delta)[at] = KCf<M>(q_nk(w, i)) - KCf<M>(s.cost[h]);
       }
-      ToG(p.link_src)[at] = static_cast<int32_t>(src_tok);
-      ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + s.key[h]);
-      ToG(p.link_arc)[at] = static_cast<int32_t>(q_arc(i));
-      ToG(p.link_ac)[at] = ac;
-      ToG(p.link_graph)[at] = q_gr(i);
-      ToG(p.link_delta)[at] =
-          KCf<M>(q_nk(i)) - KCf<M>(s.cost[h]);
-    }
+    });
   }
   KD_LAP(s, 17);
   tm.Sync(false);
