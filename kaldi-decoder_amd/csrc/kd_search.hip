@@ -172,16 +172,9 @@ struct Shared {
   long long base_out;
   double best_cost;             // the frontier's best token ...
   int32_t best_abeg, best_deg;  // ... and its emitting arc range
-  int32_t f_nlt, f_nle;
-  int32_t n_live;               // slots holding a token this frame (== live-list length)
-  int32_t q_n;                  // candidate queue length
-  int32_t n_emit_links;         // lattice: emitting entries below the final cutoff
-  int32_t n_eps_links;          // lattice: epsilon links written so far
-  int32_t n_emit_written;       // lattice: emitting links written so far
-  int32_t n_act, n_inact;       // simple: tokens kept / dropped by PruneToks
   long long link_next;          // lattice: next free link of this utterance
-  int32_t overflow;
   int32_t soft_bar;             // team barrier arrivals since the launch began
+  int32_t pad0;
   // what a tier-1 frame leaves for the waves that sat it out, by frame parity:
   // result, new frontier (size, arena base), and what a replay in the big table needs
   struct {
@@ -192,10 +185,21 @@ struct Shared {
     int32_t q_emit;
     int32_t pad;
   } ctl[2];
+  // ---- per-frame counters: one contiguous run of words, zeroed together when a frame
+  // ends (ResetFrame; kFrameZeroWords of them, from f_nlt)
+  int32_t f_nlt, f_nle;
+  int32_t n_live;               // slots holding a token this frame (== live-list length)
+  int32_t q_n;                  // candidate queue length
+  int32_t n_emit_links;         // lattice: emitting entries below the final cutoff
+  int32_t n_eps_links;          // lattice: epsilon links written so far
+  int32_t n_emit_written;       // lattice: emitting links written so far
+  int32_t n_act, n_inact;       // simple: tokens kept / dropped by PruneToks
+  int32_t overflow;
   int32_t wl_count[2];
   int32_t it_count[2], it_next[2];
   int32_t it_n32, it_n16;       // tier 1: tokens in the 32-lane and 16-lane lists
   int32_t it_next32, it_next16;
+  // ---- (end of the zeroed run)
   int32_t sel_bin, sel_k;
   int32_t frame_cnt[4];         // this frame: expanded, eps_exp, arcs, eps_arcs
   union {  // whole launch (all values are non-negative)
@@ -357,30 +361,19 @@ __device__ __forceinline__ double Uni(double v) {
 }
 __device__ __forceinline__ float Uni(float v) { return __int_as_float(Uni(__float_as_int(v))); }
 
-// Per-frame counters, reset by one thread at the end of a frame for the next one.
+// Per-frame counters, reset at the end of a frame for the next one: by the lanes of
+// one wave (`lane0` is that wave's first thread), one word each -- not word after
+// word by a single thread while the workgroup waits at the frame barrier.
+constexpr int kFrameZeroWords = 20;
 template <int M>
-__device__ __forceinline__ void ResetFrame(Shared &s) {
-  s.min_new = kCostInf<M>;
-  s.wl_count[0] = 0;
-  s.wl_count[1] = 0;
-  s.q_n = 0;
-  s.n_live = 0;
-  s.overflow = 0;
-  s.f_nlt = 0;
-  s.f_nle = 0;
-  s.n_emit_links = 0;
-  s.n_eps_links = 0;
-  s.n_emit_written = 0;
-  s.min_stored = kCostInf<M>;
-  s.n_act = 0;
-  s.n_inact = 0;
-  s.it_count[0] = 0;
-  s.it_next[0] = 0;
-  s.it_n32 = 0;
-  s.it_n16 = 0;
-  s.it_next32 = 0;
-  s.it_next16 = 0;
-  s.f_best_next = kCostDead;
+__device__ __forceinline__ void ResetFrame(Shared &s, int lane0 = 0) {
+  static_assert(offsetof(Shared, it_next16) - offsetof(Shared, f_nlt) == 4 * (kFrameZeroWords - 1),
+                "the per-frame counters are one contiguous run");
+  const int l = static_cast<int>(threadIdx.x) - lane0;
+  if (l >= 0 && l < kFrameZeroWords) (&s.f_nlt)[l] = 0;
+  if (l == kFrameZeroWords) s.min_new = kCostInf<M>;
+  if (l == kFrameZeroWords + 1) s.min_stored = kCostInf<M>;
+  if (l == kFrameZeroWords + 2) s.f_best_next = kCostDead;
 }
 
 // ---- block-wide primitives (wave64 shuffles + one LDS hop) -----------------
@@ -2037,8 +2030,9 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   KD_LAP(s, 17);
   tm.Sync(false);
   KD_LAP(s, 12);
-  // (final now; read by every lane before thread 0 resets them for the next frame)
+  // (final now; read by every lane before they are reset for the next frame)
   const int n_emit_fin = Uni(s.n_emit_links), n_eps_fin = Uni(s.n_eps_links);
+  const unsigned long long best_next = Uni(s.f_best_next);
   // ---- clear the table; publish the next frontier's arc ranges
   for (int i = tid; i < n_out; i += nt) {
     const int h = T1Live(s)[i];
@@ -2071,7 +2065,6 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     const long long fi = static_cast<long long>(c.utt) * (p.max_frames + 1) + (frame + 1);
     ToG(p.frame_base)[fi] = base_out;
     ToG(p.frame_count)[fi] = n_out;
-    const unsigned long long best = s.f_best_next;
     if (c.lattice) {
       const long long lbase = s.link_next;
       const long long fb = static_cast<long long>(c.utt) * (p.max_frames + 1);
@@ -2081,11 +2074,11 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       ToG(p.link_eps_count)[fb + frame + 1] = n_eps_fin;
       s.link_next = lbase + n_emit_fin + n_eps_fin;
     }
-    ResetFrame<M>(s);
-    s.f_best = best;
+    s.f_best = best_next;
     s.ctl[frame & 1].n_in = n_out;
     s.ctl[frame & 1].base_out = base_out;
   }
+  ResetFrame<M>(s, 128);  // (the third wave: the first two write the frame index and the counters)
   return 0;
 }
 
@@ -2306,7 +2299,7 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
   };
   // At the top of the loop the per-frame counters are reset and s.ll holds the
   // frame's log-likelihood row: a frame boundary costs one barrier.
-  if (tid == 0) ResetFrame<M>(s);
+  ResetFrame<M>(s);
   if (err == 0) row_to_lds(frame);
   __syncthreads();
   Counters tot;  // per-lane work counters of the small frames, folded when the launch ends
@@ -2379,7 +2372,7 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
         // needs this frame's row back (its place was taken by the next frame's)
         r = kRetry;
         cnt = Counters();
-        if (tid == 0) ResetFrame<M>(s);
+        ResetFrame<M>(s);
         row_to_lds(frame);
         __syncthreads();
       } else if (r == kRetry) {
@@ -2416,7 +2409,7 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
       // the next frame's start state; every wave's token stores have landed before a
       // small team reads them
       __syncthreads();
-      if (tid == 0) ResetFrame<M>(s);
+      ResetFrame<M>(s);
       if (tid < 4) s.frame_cnt[tid] = 0;
       row_to_lds(frame + 1);
       __syncthreads();
