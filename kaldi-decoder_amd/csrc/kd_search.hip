@@ -1661,18 +1661,23 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       ArcRec ar[kGroup];
       int aidx[kGroup], ref[kGroup];
       bool on[kGroup];
+      // (no branches: the list reads of the kGroup rows go out together, then their
+      // descriptor reads -- written per row under `if (q < nq)`, every LDS read waits
+      // for the one before it; entry 0 exists whenever the loop is entered)
+      bool valid[kGroup];
 #pragma unroll
       for (int g = 0; g < kGroup; ++g) {
-        on[g] = false;
-        aidx[g] = 0;
         const int q = q0 + g * kPer + lane / W;
-        ref[g] = -1;
-        if (q < nq) {
-          ref[g] = item_ref(q);
-          const int off = lane % W;
-          on[g] = off < s.it_deg[ref[g]];
-          aidx[g] = s.it_abeg[ref[g]] + off;
-        }
+        valid[g] = q < nq;
+        ref[g] = item_ref(valid[g] ? q : 0);
+      }
+#pragma unroll
+      for (int g = 0; g < kGroup; ++g) {
+        const int off = lane % W;
+        const int deg = s.it_deg[ref[g]], abeg = s.it_abeg[ref[g]];
+        on[g] = valid[g] && off < deg;
+        aidx[g] = abeg + off;
+        if (!valid[g]) ref[g] = -1;
       }
 #pragma unroll
       for (int g = 0; g < kGroup; ++g)
