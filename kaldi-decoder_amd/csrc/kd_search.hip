@@ -2007,28 +2007,44 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     if (full) return KD_UTT_ARENA_FULL;
     split(0, n_q, [&](auto w, int lo, int hi) {
       for (int i = lo + tid; i < hi; i += nt) {
-        const uint32_t h = q_h(w, i);
-        if (h == kKeyEmpty) continue;
-        const uint32_t sr = q_src(w, i);
+        // the entry's queue words together, then its table words together (read one
+        // by one behind the tests below, each waits for the one before it)
+        const uint32_t h = q_h(w, i), sr = q_src(w, i), aidx = q_arc(w, i);
+        const float qa = q_ac(w, i), qg = q_gr(w, i);
+        const unsigned long long nk = q_nk(w, i);
+        const bool ok = h != kKeyEmpty, eps = i >= q_emit;
+        const uint32_t hd = ok ? h : 0u, hs = ok && eps ? sr & ~kSrcEps : 0u;
+        const uint32_t kd = s.key[hd], ks = s.key[hs];
+        // (the lattice decoders' key is the high word; asking for the 64-bit word and
+        // letting hipcc narrow the read trips a bug in its instruction selection here)
+        float cdf, csf;
+        if constexpr (M == 1) {
+          cdf = KeyFloat(reinterpret_cast<const uint32_t *>(&s.cost[hd])[1]);
+          csf = KeyFloat(reinterpret_cast<const uint32_t *>(&s.cost[hs])[1]);
+        } else {
+          cdf = KCf<M>(s.cost[hd]);
+          csf = KCf<M>(s.cost[hs]);
+        }
+        if (!ok) continue;
         long long at, src_tok;
         float ac;
-        if (i < q_emit) {
+        if (!eps) {
           src_tok = c.base_in + sr;
-          ac = q_ac(w, i);
+          ac = qa;
           at = lbase + AggInc(&s.n_emit_written);
         } else {
-          const uint32_t hs = sr & ~kSrcEps;
-          if (q_ac(w, i) != KCf<M>(s.cost[hs])) continue;
-          src_tok = base_out + s.key[hs];
+          // source cost at generation vs its final cost (its slot's cost word is intact)
+          if (qa != csf) continue;
+          src_tok = base_out + ks;
           ac = 0.0f;
           at = lbase + n_emit + AggInc(&s.n_eps_links);
         }
         ToG(p.link_src)[at] = static_cast<int32_t>(src_tok);
-        ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + s.key[h]);
-        ToG(p.link_arc)[at] = static_cast<int32_t>(q_arc(w, i));
+        ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + kd);
+        ToG(p.link_arc)[at] = static_cast<int32_t>(aidx);
         ToG(p.link_ac)[at] = ac;
-        ToG(p.link_graph)[at] = q_gr(w, i);
-        ToG(p.link_delta)[at] = KCf<M>(q_nk(w, i)) - KCf<M>(s.cost[h]);
+        ToG(p.link_graph)[at] = qg;
+        ToG(p.link_delta)[at] = KCf<M>(nk) - cdf;
       }
     });
   }
