@@ -230,33 +230,42 @@ __global__ __launch_bounds__(kLBlock) void LatticePruneKernel(const LatticeParam
       }
       // this lane's epsilon links: source, destination (frame-relative) and the
       // cost difference of :257-260
+      // (every lane issues every load -- a lane without a link reads the arena's first
+      // record -- so the epsilon links and the first round of emitting links are in
+      // flight together; loads behind `if (i < pn)` complete one after the other)
       int e_src[kEpsRegs], e_dst[kEpsRegs];
       float e_delta[kEpsRegs];
 #pragma unroll
       for (int r = 0; r < kEpsRegs; ++r) {
         const int i = tid + r * kLBlock;
-        e_src[r] = -1;
-        e_dst[r] = -1;
-        e_delta[r] = 0.0f;
-        if (i < pn) {
-          const long long at = pb + i;
-          const int32_t dst = ToG(p.link_dst)[at];
-          const int32_t src = ToG(p.link_src)[at];
-          const float delta = ToG(p.link_delta)[at];
-          if (dst >= 0) {
-            e_delta[r] = delta;
-            e_src[r] = static_cast<int>(src - base);
-            e_dst[r] = static_cast<int>(dst - base);
-          }
+        const long long at = i < pn ? pb + i : 0;
+        e_dst[r] = ToG(p.link_dst)[at];
+        e_src[r] = ToG(p.link_src)[at];
+        e_delta[r] = ToG(p.link_delta)[at];
+      }
+      const long long at0 = tid < en ? eb + tid : 0;
+      const int32_t m_dst0 = ToG(p.link_dst)[at0], m_src0 = ToG(p.link_src)[at0];
+      const float m_delta0 = ToG(p.link_delta)[at0];
+#pragma unroll
+      for (int r = 0; r < kEpsRegs; ++r) {
+        const int i = tid + r * kLBlock;
+        if (i < pn && e_dst[r] >= 0) {
+          e_src[r] = static_cast<int>(e_src[r] - base);
+          e_dst[r] = static_cast<int>(e_dst[r] - base);
+        } else {
+          e_src[r] = -1;
+          e_dst[r] = -1;
+          e_delta[r] = 0.0f;
         }
       }
       LdsBarrier();
       // emitting links, into A
       for (int i = tid; i < en; i += kLBlock) {
         const long long at = eb + i;
-        const int32_t dst = ToG(p.link_dst)[at];
-        const int32_t src = ToG(p.link_src)[at];
-        const float delta = ToG(p.link_delta)[at];
+        const bool first = i == tid;  // (the first round was requested above)
+        const int32_t dst = first ? m_dst0 : ToG(p.link_dst)[at];
+        const int32_t src = first ? m_src0 : ToG(p.link_src)[at];
+        const float delta = first ? m_delta0 : ToG(p.link_delta)[at];
         if (dst < 0) continue;  // already excised
         const float next_extra = next_b ? KeyFloat(next_b[dst - next_base]) : ToG(p.tok_extra)[dst];
         float link_extra_cost = next_extra + delta;  // :257-260
