@@ -108,6 +108,8 @@ constexpr int kT1Narrow = 0;  // ... of which frames up to this size run on four
                                // measured slower on MI355X: fewer loads in flight per round trip)
 constexpr int kQL = kT1Slots / 2;
 constexpr int kT1W16 = 512;    // tokens of at most 16 arcs (in Shared::hist)
+constexpr int kSecondPart = 0x8000;  // 16-lane list entry: arcs 32..47 of a token of 33..48 arcs
+static_assert(KD_T1_FRONT <= kSecondPart, "work-list entries are frontier indices below the flag");
 static_assert(kBlock >= 256 && kT1Front >= kBlock && kSlots == 2 * kT1Slots && 2 * kQL == kT1Slots,
               "tier-1 LDS overlay");
 // Cost keys: order-preserving 64-bit images of costs, so that one integer atomicMin
@@ -1594,6 +1596,17 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       T1Heads(s)[kT1Front - 1 - AggInc(&s.it_n32)] = static_cast<uint16_t>(ref);
       return;
     }
+    if (deg <= 48) {
+      // 33..48 arcs (the bulk of an HLG frontier: a token inside a word, ~38 arcs): a
+      // 32-lane slot for the first 32 and a 16-lane slot (kSecondPart: arcs 32..47) for
+      // the rest -- 48 lanes instead of a 64-lane row that would be 40 % idle
+      const int at = AggInc(&s.it_n16);
+      if (at < kT1W16) {
+        T1W16(s)[at] = static_cast<uint16_t>(ref | kSecondPart);
+        T1Heads(s)[kT1Front - 1 - AggInc(&s.it_n32)] = static_cast<uint16_t>(ref);
+        return;
+      }
+    }
     T1Heads(s)[AggInc(&s.it_count[0])] = static_cast<uint16_t>(ref);
   };
   // Scores N arcs per lane (`on[g]`: this lane holds arc g) and appends the survivors
@@ -1673,7 +1686,9 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       }
 #pragma unroll
       for (int g = 0; g < kGroup; ++g) {
-        const int off = lane % W;
+        int off = lane % W;
+        if (W == 16 && (ref[g] & kSecondPart)) off += 32;
+        ref[g] &= kSecondPart - 1;
         const int deg = s.it_deg[ref[g]], abeg = s.it_abeg[ref[g]];
         on[g] = valid[g] && off < deg;
         aidx[g] = abeg + off;
