@@ -728,85 +728,90 @@ __device__ __forceinline__ void ScoreBatchBig(const FrameCtx<M> &c, const ArcRec
 // time, lanes over consecutive arcs; the first 64 arcs of all kGroup tokens are
 // loaded before any is scored so their latencies overlap.  `range(q, abeg, deg)`
 // and `source(q, cost, srcid)` describe queue item q.
-template <bool EPS, bool T1, int M, class Range, class Source>
-__device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int par, int nq, Range range,
+template <bool EPS, bool T1, int W, int M, class Range, class Source>
+__device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int32_t *next, int nq, Range range,
                                         Source source) {
+  static_assert(W == 64 || W == 32, "one token per row, or two of at most 32 arcs");
+  constexpr int kPer = 64 / W;
   CParams &p = c.p;
   Shared &s = c.s;
   const int lane = threadIdx.x & 63;
   while (true) {
     int q0 = 0;
-    if (lane == 0) q0 = atomicAdd(&s.it_next[par], kGroup);
+    if (lane == 0) q0 = atomicAdd(next, kGroup * kPer);
     q0 = __builtin_amdgcn_readfirstlane(q0);
     if (q0 >= nq) break;
     ArcRec ar[kGroup];
-    int abeg[kGroup], deg[kGroup];
+    int abeg[kGroup], deg[kGroup], item[kGroup];
 #pragma unroll
     for (int g = 0; g < kGroup; ++g) {
-      deg[g] = 0;
-      abeg[g] = 0;
-      if (q0 + g < nq) range(q0 + g, abeg[g], deg[g]);
-      ar[g] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg[g] + lane), lane < deg[g], 0u);
+      const int q = q0 + g * kPer + lane / W;
+      item[g] = q < nq ? q : q0;  // (entry q0 exists: a slot past the end reads it)
+      range(item[g], abeg[g], deg[g]);
+      if (q >= nq) deg[g] = 0;
     }
+#pragma unroll
+    for (int g = 0; g < kGroup; ++g)
+      ar[g] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg[g] + lane % W), lane % W < deg[g], 0u);
     if constexpr (!T1 && (EPS || M != 2)) {
       uint32_t aidx[kGroup], src[kGroup];
       bool on[kGroup];
       double cst[kGroup];
 #pragma unroll
       for (int g = 0; g < kGroup; ++g) {
-        on[g] = lane < deg[g];
-        aidx[g] = static_cast<uint32_t>(abeg[g] + lane);
-        cst[g] = 0.0;
-        src[g] = 0;
-        if (q0 + g < nq) source(q0 + g, cst[g], src[g]);
+        on[g] = lane % W < deg[g];
+        aidx[g] = static_cast<uint32_t>(abeg[g] + lane % W);
+        source(item[g], cst[g], src[g]);
       }
       ScoreBatchBig<EPS>(c, ar, aidx, on, cst, src);
     } else {
 #pragma unroll
       for (int g = 0; g < kGroup; ++g)
-        if (lane < deg[g]) {
+        if (lane % W < deg[g]) {
           double cst;
           uint32_t srcid;
-          source(q0 + g, cst, srcid);
-          FilterArc<EPS, T1>(c, ar[g], static_cast<uint32_t>(abeg[g] + lane), cst, srcid);
+          source(item[g], cst, srcid);
+          FilterArc<EPS, T1>(c, ar[g], static_cast<uint32_t>(abeg[g] + lane % W), cst, srcid);
         }
     }
     if constexpr (!EPS) PublishMin(c);
-    // tails of tokens with more than 64 arcs, four wave-rows in flight
+    if constexpr (W == 64) {
+      // tails of tokens with more than 64 arcs, four wave-rows in flight
 #pragma unroll 1
-    for (int g = 0; g < kGroup; ++g) {
-      if (deg[g] <= 64) continue;
-      double cst;
-      uint32_t srcid;
-      source(q0 + g, cst, srcid);
-      for (int r0 = 64; r0 < deg[g]; r0 += 256) {  // (wave-uniform: every lane takes every round)
-        const int a0 = r0 + lane;
-        ArcRec tr[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          tr[u] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg[g] + a0 + 64 * u),
-                               a0 + 64 * u < deg[g], static_cast<uint32_t>(abeg[g]));
-        if constexpr (!T1 && (EPS || M != 2)) {
-          uint32_t aidx[4], src[4];
-          bool on[4];
-          double cs[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            on[u] = a0 + 64 * u < deg[g];
-            aidx[u] = static_cast<uint32_t>(abeg[g] + a0 + 64 * u);
-            cs[u] = cst;
-            src[u] = srcid;
-          }
-          ScoreBatchBig<EPS>(c, tr, aidx, on, cs, src);
-        } else {
+      for (int g = 0; g < kGroup; ++g) {
+        if (deg[g] <= 64) continue;
+        double cst;
+        uint32_t srcid;
+        source(item[g], cst, srcid);
+        for (int r0 = 64; r0 < deg[g]; r0 += 256) {  // (wave-uniform: every lane takes every round)
+          const int a0 = r0 + lane;
+          ArcRec tr[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u)
-            if (a0 + 64 * u < deg[g])
-              FilterArc<EPS, T1>(c, tr[u], static_cast<uint32_t>(abeg[g] + a0 + 64 * u), cst, srcid);
+            tr[u] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg[g] + a0 + 64 * u),
+                                 a0 + 64 * u < deg[g], static_cast<uint32_t>(abeg[g]));
+          if constexpr (!T1 && (EPS || M != 2)) {
+            uint32_t aidx[4], src[4];
+            bool on[4];
+            double cs[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              on[u] = a0 + 64 * u < deg[g];
+              aidx[u] = static_cast<uint32_t>(abeg[g] + a0 + 64 * u);
+              cs[u] = cst;
+              src[u] = srcid;
+            }
+            ScoreBatchBig<EPS>(c, tr, aidx, on, cs, src);
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (a0 + 64 * u < deg[g])
+                FilterArc<EPS, T1>(c, tr[u], static_cast<uint32_t>(abeg[g] + a0 + 64 * u), cst, srcid);
+          }
         }
       }
+      if constexpr (!EPS) PublishMin(c);
     }
-    if constexpr (!EPS) PublishMin(c);
   }
 }
 
@@ -822,7 +827,11 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
   Shared &s = c.s;
   const int tid = threadIdx.x, lane = tid & 63;
   int par = 0;
-  if (tid == 0) { s.it_count[0] = 0; s.it_next[0] = 0; }
+  // Tokens with more than kSmallDeg arcs are queued in LDS for whole waves: those of
+  // more than 32 arcs from the front of the it_* arrays (a 64-lane row each), the
+  // others from the back (two per row).  Counters and cursors of the second list,
+  // by chunk parity: (it_n32, it_next32) and (it_n16, it_next16).
+  if (tid == 0) { s.it_count[0] = 0; s.it_next[0] = 0; s.it_n32 = 0; s.it_next32 = 0; }
   LdsBarrier();
   for (int chunk = 0; chunk < n_items; chunk += kBlock, par ^= 1) {
     const int i = chunk + tid;
@@ -849,7 +858,8 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
         if (EPS) { cnt.eps_exp += 1; cnt.eps_arcs += deg; }
         else { cnt.tokens_expanded += 1; cnt.arcs_scanned += deg; }
         if (deg > kSmallDeg) {
-          const int q = AggInc(&s.it_count[par]);
+          const int q = deg > 32 ? AggInc(&s.it_count[par])
+                                 : kT1Front - 1 - AggInc(par ? &s.it_n16 : &s.it_n32);
           s.it_abeg[q] = abeg;
           s.it_deg[q] = deg;
           s.it_cost[q] = cst;
@@ -869,15 +879,28 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
     if constexpr (!EPS) PublishMin(c);
     LdsBarrier();  // the big-token queue is LDS; queue stores keep draining
     KD_LAP(s, EPS ? 7 : 3);
-    const int nq = s.it_count[par];
-    if (tid == 0) { s.it_count[par ^ 1] = 0; s.it_next[par ^ 1] = 0; }
-    BigLoop<EPS, false>(c, par, nq, [&](int q, int &abeg, int &deg) {
-      abeg = s.it_abeg[q];
-      deg = s.it_deg[q];
-    }, [&](int q, double &cst, uint32_t &srcid) {
-      cst = s.it_cost[q];
-      srcid = s.it_src[q];
-    });
+    const int nq = s.it_count[par], nq2 = par ? s.it_n16 : s.it_n32;
+    if (tid == 0) {
+      s.it_count[par ^ 1] = 0;
+      s.it_next[par ^ 1] = 0;
+      if (par) { s.it_n32 = 0; s.it_next32 = 0; } else { s.it_n16 = 0; s.it_next16 = 0; }
+    }
+    if (nq > 0)
+      BigLoop<EPS, false, 64>(c, &s.it_next[par], nq, [&](int q, int &abeg, int &deg) {
+        abeg = s.it_abeg[q];
+        deg = s.it_deg[q];
+      }, [&](int q, double &cst, uint32_t &srcid) {
+        cst = s.it_cost[q];
+        srcid = s.it_src[q];
+      });
+    if (nq2 > 0)
+      BigLoop<EPS, false, 32>(c, par ? &s.it_next16 : &s.it_next32, nq2, [&](int q, int &abeg, int &deg) {
+        abeg = s.it_abeg[kT1Front - 1 - q];
+        deg = s.it_deg[kT1Front - 1 - q];
+      }, [&](int q, double &cst, uint32_t &srcid) {
+        cst = s.it_cost[kT1Front - 1 - q];
+        srcid = s.it_src[kT1Front - 1 - q];
+      });
     if (chunk + kBlock < n_items) LdsBarrier();  // it_* arrays are reused by the next chunk
     KD_LAP(s, EPS ? 8 : 4);
   }
