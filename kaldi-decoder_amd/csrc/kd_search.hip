@@ -1779,14 +1779,50 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   KD_LAP(s, 1);
 
   // ---- emitting filter over the LDS frontier (faster-decoder.cc:195-236)
-  for (int i = tid; i < n_in; i += nt) {
-    const double cst = s.it_cost[i];
-    if (!(cst < c.weight_cutoff)) continue;  // :202
-    const int abeg = s.it_abeg[i], deg = s.it_deg[i];
-    cnt.tokens_expanded += 1;
-    cnt.arcs_scanned += deg;
-    if (deg <= kSmallDeg) lane_arcs(EpsNo{}, abeg, deg, cst, static_cast<uint32_t>(i));
-    else push_items(EpsNo{}, i, abeg, deg, cst, static_cast<uint32_t>(i));
+  // The frontier's best token goes first (faster-decoder.cc:176-189 does the same to
+  // bound the cutoff early): the wave that holds it scores its arcs as one row right
+  // here and publishes the lowest new cost, so the work-item loops below start under a
+  // cutoff close to the final one and queue few arcs that the insert pass would drop.
+  const unsigned long long best_key = Uni(s.f_best);
+  for (int i0 = 0; i0 < n_in; i0 += nt) {  // (every wave takes every round)
+    const int i = i0 + tid;
+    int abeg = 0, deg = 0;
+    double cst = 0.0;
+    bool ok = false;
+    if (i < n_in) {
+      cst = s.it_cost[i];
+      ok = cst < c.weight_cutoff;  // :202
+      if (ok) {
+        abeg = s.it_abeg[i];
+        deg = s.it_deg[i];
+        cnt.tokens_expanded += 1;
+        cnt.arcs_scanned += deg;
+      }
+    }
+    const unsigned long long first =
+        __ballot(ok && deg > kSmallDeg && deg <= 64 && CK<M>(cst) == best_key);
+    const int leader = first ? __builtin_ctzll(first) : -1;
+    if (leader >= 0) {
+      const int b_abeg = __shfl(abeg, leader, 64), b_deg = __shfl(deg, leader, 64);
+      const int b_i = __shfl(i, leader, 64);
+      const double b_cst = s.it_cost[b_i];
+      ArcRec ar1[1];
+      int aidx1[1];
+      bool on1[1];
+      double cst1[1];
+      uint32_t src1[1];
+      on1[0] = lane < b_deg;
+      aidx1[0] = b_abeg + lane;
+      cst1[0] = b_cst;
+      src1[0] = static_cast<uint32_t>(b_i);
+      ar1[0] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(aidx1[0]), on1[0], 0u);
+      score_batch(EpsNo{}, std::integral_constant<int, 1>{}, ar1, aidx1, on1, cst1, src1);
+      LaneMin(&s.min_new, c.run_min, c.run_min != kCostInf<M>);
+    }
+    if (ok && lane != leader) {
+      if (deg <= kSmallDeg) lane_arcs(EpsNo{}, abeg, deg, cst, static_cast<uint32_t>(i));
+      else push_items(EpsNo{}, i, abeg, deg, cst, static_cast<uint32_t>(i));
+    }
   }
   PublishMin(c);
   tm.Sync(false);
