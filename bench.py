@@ -190,18 +190,20 @@ def cpu_baseline(g, lps, wl, gpu_out, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=56)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="hlg-lattice", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--streams", type=int, default=6,
+    ap.add_argument("--streams", type=int, default=7,
                     help="independent batches in flight per GPU (each step is still one batch of "
                          "B utterances; a batch occupies B of the 256 CUs)")
     ap.add_argument("--arena-tokens-per-utt", type=int, default=0,
                     help="token records reserved per utterance (0: the library default, 2^21)")
-    ap.add_argument("--arena-links-per-utt", type=int, default=0,
-                    help="lattice decoders: forward links reserved per utterance (0: default)")
+    ap.add_argument("--arena-links-per-utt", type=int, default=1 << 22,
+                    help="lattice decoders: forward links reserved per utterance (0: the library "
+                         "default, four per token record = 2^23; this workload keeps 1.05 links per "
+                         "token, and 2^22 lets seven batches of 22 GB share the HBM)")
     ap.add_argument("--search-only", action="store_true",
                     help="diagnostic: time InitDecoding + AdvanceDecoding only (not a bench line)")
     args = ap.parse_args()
