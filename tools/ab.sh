@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B: tools/ab.sh libA.so libB.so ...   (each: kernel alone, six streams, tier-1 phase profile if built)
+# same-box A/B: tools/ab.sh libA.so libB.so ...   (each: kernel alone, six batches in flight, tier-1 phase profile if built)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/ab.log
 : > $out

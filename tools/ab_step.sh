@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/ab_step.sh libA.so libB.so ...  same-box A/B of whole steps: per-piece host timing (tools/step_timing.py),
-# the bench with six streams, then the GPU test suite with the default library.
+# the bench with six batches in flight, then the GPU test suite with the default library.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 out=gpurun_out/ab.log
 : > $out
