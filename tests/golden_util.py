@@ -34,3 +34,62 @@ def assert_path(p, z, prefix, tag):
 def lattice_rows(lat):
     rows = sorted(lat.arc_set())
     return np.array(rows, np.float64).reshape(len(rows), -1)
+
+
+def lattice_forward_costs(rows, start_state):
+    """Forward (alpha) cost of every lattice state, in the decoder's own float32
+    arithmetic: emitting arcs `(cur + ac) + graph` (ref lattice-simple-decoder.cc:383-385),
+    epsilon arcs `cur + graph` (:170-172).  `rows` are arc rows (src frame, src graph
+    state, dst frame, dst graph state, ilabel, olabel, graph, ac).  A token's best
+    incoming link has link_extra_cost == its own extra cost, so it survives whenever the
+    token does: on a pruned raw lattice these are exactly the tokens' tot_cost."""
+    alpha = {(0, int(start_state)): np.float32(0.0)}
+    by_frame = {}
+    for r in rows:
+        by_frame.setdefault(int(r[2]), []).append(r)
+    inf = np.float32(np.inf)
+    for f in sorted(by_frame):
+        arcs = by_frame[f]
+        changed = True
+        first = True
+        while changed:
+            changed = False
+            for r in arcs:
+                eps = int(r[0]) == int(r[2])
+                if not first and not eps:
+                    continue
+                cur = alpha.get((int(r[0]), int(r[1])), inf)
+                if cur == inf:
+                    continue
+                if eps:
+                    c = np.float32(cur + np.float32(r[6]))
+                else:
+                    c = np.float32(np.float32(cur + np.float32(r[7])) + np.float32(r[6]))
+                k = (int(r[2]), int(r[3]))
+                if c < alpha.get(k, inf):
+                    alpha[k] = c
+                    changed = True
+            first = False
+    return alpha
+
+
+def assert_extras_beyond_cutoff(ref_rows, got_rows, frame_best, beam, start_state, tag=""):
+    """SURVEY section 7 ("order-dependent pruning"): every arc the reference-order lattice
+    has and the order-free one lacks was created under a looser running cutoff -- its
+    forward cost is at or beyond (best cost of the destination frame) + beam, the value the
+    reference's running cutoff ends the frame at."""
+    got = {tuple(r) for r in np.asarray(got_rows).tolist()}
+    ref = [tuple(r) for r in np.asarray(ref_rows).tolist()]
+    alpha = lattice_forward_costs(ref, start_state)
+    n_extra = 0
+    for r in ref:
+        if r in got:
+            continue
+        n_extra += 1
+        cur = alpha[(int(r[0]), int(r[1]))]
+        eps = int(r[0]) == int(r[2])
+        fwd = np.float32(cur + np.float32(r[6])) if eps else \
+            np.float32(np.float32(cur + np.float32(r[7])) + np.float32(r[6]))
+        cutoff = np.float32(np.float32(frame_best[int(r[2])]) + np.float32(beam))
+        assert fwd >= cutoff, (tag, r, float(fwd), float(cutoff))
+    return n_extra
