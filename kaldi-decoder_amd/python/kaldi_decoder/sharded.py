@@ -71,12 +71,30 @@ def lattice_blob(lat):
                            lat.final_graph.view(np.int32)]).astype(np.int32, copy=False)
 
 
-def gather_lattices(lats, dst=0, group=None):
-    """Gathers every rank's pruned raw lattices to `dst` (as blobs, see lattice_blob)."""
-    blobs = [(lattice_blob(lat), np.zeros(0, np.int32)) for lat in lats]
-    # pack_paths stores two arrays of one common length per item: use the blob once
-    # and an empty second array by packing the blob as ilabel with a zero-length twin
-    return gather_paths([(b, b[:0]) for b, _ in blobs], dst=dst, group=group, _single=True)
+def lattice_from_blob(blob):
+    """Inverse of lattice_blob: a cabi.RawLattice whose arrays are views into `blob`."""
+    from .cabi import RawLattice
+    blob = np.asarray(blob, np.int32)
+    ns, na, nf, start = (int(x) for x in blob[:4])
+    pos = 4
+    fields = []
+    for n in (na, na, na, na, na, na, ns, ns, nf, nf):
+        fields.append(blob[pos:pos + n])
+        pos += n
+    src, dst, il, ol, gc, ac, sf, sg, fs, fg = fields
+    return RawLattice(ns > 0, ns, start, src, dst, il, ol, gc.view(np.float32), ac.view(np.float32),
+                      sf, sg, fs, fg.view(np.float32))
+
+
+def gather_lattices(lats, dst=0, group=None, as_lattices=False):
+    """Gathers every rank's pruned raw lattices to `dst` in rank order: a list of int32
+    blobs (see lattice_blob), or of RawLattice objects with `as_lattices`; None on the
+    other ranks."""
+    got = gather_paths([(lattice_blob(lat), None) for lat in lats], dst=dst, group=group,
+                       _single=True)
+    if got is None or not as_lattices:
+        return got
+    return [lattice_from_blob(b) for b in got]
 
 
 def gather_paths(paths, dst=0, group=None, _single=False):

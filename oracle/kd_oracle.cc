@@ -1879,6 +1879,29 @@ int32_t kdo_canonlat_frame_tokens(void *hv, int32_t f, int32_t cap, int32_t *sta
   for (int32_t i = 0; i < n && i < cap; ++i) { state[i] = fr[i].state; tot[i] = fr[i].tot; extra[i] = fr[i].extra; }
   return n;
 }
+// Every forward link the decoder created, pruned or not, one row of 8 doubles each:
+// (src frame, src graph state, dst frame, dst graph state, ilabel, olabel, graph, ac).
+// Returns the number of links; writes at most `cap` rows.
+int64_t kdo_canonlat_created_links(void *hv, int64_t cap, double *rows) {
+  auto &d = static_cast<CanonHandle *>(hv)->dec;
+  int64_t n = 0;
+  for (size_t f = 0; f < d.links.size(); ++f)
+    for (const auto &l : d.links[f]) {
+      if (n < cap) {
+        double *r = rows + 8 * n;
+        r[0] = static_cast<double>(f);
+        r[1] = d.toks[f][l.src].state;
+        r[2] = l.dst_frame;
+        r[3] = d.toks[l.dst_frame][l.dst].state;
+        r[4] = d.g.ilabel[l.arc];
+        r[5] = d.g.olabel[l.arc];
+        r[6] = l.graph;
+        r[7] = l.ac;
+      }
+      ++n;
+    }
+  return n;
+}
 int kdo_canonlat_raw_lattice(void *hv, int32_t *sizes4) {
   auto *h = static_cast<CanonHandle *>(hv);
   bool ok = false;

@@ -97,6 +97,8 @@ def lib():
     L.kdo_canonlat_links_created.argtypes = [C.c_void_p]
     L.kdo_canonlat_frame_tokens.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, _f32p, _f32p]
     L.kdo_canonlat_raw_lattice.argtypes = [C.c_void_p, _i32p]
+    L.kdo_canonlat_created_links.restype = C.c_int64
+    L.kdo_canonlat_created_links.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     L.kdo_canonlat_copy_lattice.argtypes = lat_copy
     L.kdo_canonlat_best_path.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), _i32p, _i32p,
                                          _i32p, _f32p, _f32p, _f32p]
@@ -423,6 +425,14 @@ class CanonLatticeDecoder:
         ex = np.zeros(cap, np.float32)
         n = lib().kdo_canonlat_frame_tokens(self.h, f, cap, st, tot, ex)
         return st[:n].copy(), tot[:n].copy(), ex[:n].copy()
+
+    def created_links(self):
+        """Every forward link created (before any pruning) as rows of
+        (src frame, src state, dst frame, dst state, ilabel, olabel, graph, ac)."""
+        n = lib().kdo_canonlat_created_links(self.h, 0, None)
+        rows = np.zeros((n, 8), np.float64)
+        lib().kdo_canonlat_created_links(self.h, n, rows.ctypes.data)
+        return rows
 
     def get_raw_lattice(self):
         sizes = np.zeros(4, np.int32)

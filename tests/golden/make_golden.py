@@ -17,6 +17,8 @@ decoders the raw lattice as sorted arc rows.  `ref_*` keys come from the
 reference-order restatement (policy 0), `canon_*` keys from the order-free
 semantics the GPU implements.
 """
+import hashlib
+import json
 import os
 import sys
 
@@ -46,13 +48,36 @@ def lattice_rows(lat):
     return np.array(rows, np.float64).reshape(len(rows), -1)
 
 
-def faster_case(name, g, lex, T, peak, opts, chunk=0, offset=0, utt=0):
+def inputs_digest(g, lp):
+    h = hashlib.sha256()
+    for k in GRAPH_KEYS:
+        h.update(np.ascontiguousarray(g[k]).tobytes())
+    h.update(np.ascontiguousarray(lp).tobytes())
+    return h.hexdigest()
+
+
+def case_inputs(g, lp, opts, gen):
+    """The inputs of a fixture: the arrays themselves, or (large cases) the call that
+    regenerates them -- `gen` = (synth graph function, kwargs, make_logprobs kwargs) --
+    with a digest of the arrays so that a drift of the generator is detected."""
+    if gen is None:
+        out = {k: np.asarray(g[k]) for k in GRAPH_KEYS}
+        out.update(num_states=np.array(g["num_states"]), start=np.array(g["start"]), logprobs=lp)
+    else:
+        out = dict(gen=np.array(json.dumps(dict(graph=gen[0], graph_kwargs=gen[1], logprobs=gen[2]))),
+                   gen_sha256=np.array(inputs_digest(g, lp)))
+    out.update(opt_names=np.array(sorted(opts)),
+               opt_values=np.array([opts[k] for k in sorted(opts)], np.float64))
+    return out
+
+
+def faster_case(name, g, lex, T, peak, opts, chunk=0, offset=0, utt=0, gen=None):
     V = int(g["ilabel"].max())
     lp = synth.make_logprobs(T, V, utt, peak=peak, lexicon=lex)
-    out = {k: np.asarray(g[k]) for k in GRAPH_KEYS}
-    out.update(num_states=np.array(g["num_states"]), start=np.array(g["start"]), logprobs=lp,
-               opt_names=np.array(sorted(opts)), opt_values=np.array([opts[k] for k in sorted(opts)], np.float64),
-               chunk=np.array(chunk))
+    if gen is not None:
+        gen = (gen[0], gen[1], dict(T=T, V=V, utt_id=utt, peak=peak, lexicon=lex is not None))
+    out = case_inputs(g, lp, opts, gen)
+    out.update(chunk=np.array(chunk))
     OG = oracle.Graph(g)
     for tag, policy in (("ref_", 0), ("canon_", 1)):
         d = oracle.FasterDecoder(OG, policy=policy, **opts)
@@ -75,19 +100,25 @@ def faster_case(name, g, lex, T, peak, opts, chunk=0, offset=0, utt=0):
 def lattice_case(name, g, lex, T, peak, opts, utt=0):
     V = int(g["ilabel"].max())
     lp = synth.make_logprobs(T, V, utt, peak=peak, lexicon=lex)
-    out = {k: np.asarray(g[k]) for k in GRAPH_KEYS}
-    out.update(num_states=np.array(g["num_states"]), start=np.array(g["start"]), logprobs=lp,
-               opt_names=np.array(sorted(opts)), opt_values=np.array([opts[k] for k in sorted(opts)], np.float64))
+    out = case_inputs(g, lp, opts, None)
     OG = oracle.Graph(g)
-    ref = oracle.LatticeSimpleDecoder(OG, beam=opts["beam"], lattice_beam=opts["lattice_beam"],
-                                      prune_interval=25)
-    ref.decode(lp)
-    out["ref_arcs"] = lattice_rows(ref.get_raw_lattice())
+    # the reference-order decoder at both prune intervals of SURVEY 8(c): the periodic
+    # PruneActiveTokens must not change the finalized lattice
+    for pi, key in ((25, "ref_arcs"), (1, "ref_pi1_arcs")):
+        ref = oracle.LatticeSimpleDecoder(OG, beam=opts["beam"], lattice_beam=opts["lattice_beam"],
+                                          prune_interval=pi)
+        ref.decode(lp)
+        out[key] = lattice_rows(ref.get_raw_lattice())
+        bp = ref.get_best_path()
+        out[key[:-4] + "isyms"], out[key[:-4] + "osyms"] = bp.isyms, bp.osyms
     out["ref_final_relative_cost"] = np.array(ref.final_relative_cost(), np.float32)
     can = oracle.CanonLatticeDecoder(OG, **opts)
     can.decode(lp)
     cl = can.get_raw_lattice()
     out["canon_arcs"] = lattice_rows(cl)
+    # best cost of every frame's tokens: (that + beam) is the value the reference's running
+    # cutoff ends the frame at (golden_util.assert_extras_beyond_cutoff)
+    out["canon_frame_best"] = np.array([can.frame_tokens(f)[1].min() for f in range(T + 1)], np.float32)
     out["canon_num_states"] = np.array(cl.num_states)
     out["canon_final_relative_cost"] = np.array(can.final_relative_cost(), np.float32)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
@@ -101,6 +132,10 @@ def main():
             for ma in (INT_MAX, 8):
                 faster_case(f"g1_h{V}_b{int(beam)}_ma{'inf' if ma == INT_MAX else ma}", synth.ctc_topo(V),
                             None, T, 6.0, dict(beam=beam, max_active=ma, min_active=0))
+    # G2: the full-size CTC topology (H, V = 500, T = 250), library defaults
+    faster_case("g2_h500", synth.ctc_topo(500), None, 250, 6.0,
+                dict(beam=16.0, max_active=INT_MAX, min_active=20), utt=9,
+                gen=("ctc_topo", dict(V=500)))
     # G3: HL- and HLG-like graphs with epsilon arcs
     g = synth.hl_graph(V=40, n_words=300, seed=3)
     for beam, mi, ma in ((8.0, 0, INT_MAX), (15.0, 20, 300)):
@@ -110,6 +145,16 @@ def main():
     for beam, mi in ((8.0, 0), (15.0, 20)):
         faster_case(f"g3_hlg_b{int(beam)}_mi{mi}", g, g["lexicon"], 60, 8.0,
                     dict(beam=beam, min_active=mi, max_active=INT_MAX))
+    # G3 at the configs-of-record's beams: beam 17, and max_active = 3000 binding (the
+    # frontier of this HL graph under dense posteriors is 15-19 k tokens)
+    kw = dict(V=100, n_words=4000, seed=7)
+    g = synth.hl_graph(**kw)
+    faster_case("g3_hl_b17_ma3000", g, g["lexicon"], 80, 3.0,
+                dict(beam=17.0, max_active=3000, min_active=20), utt=5, gen=("hl_graph", kw))
+    kw = dict(V=60, n_words=400, n_hist=400, avg_succ=10, seed=8)
+    g = synth.hlg_graph(**kw)
+    faster_case("g3_hlg_b17", g, g["lexicon"], 80, 6.0,
+                dict(beam=17.0, max_active=INT_MAX, min_active=20), utt=6, gen=("hlg_graph", kw))
     # G5: nothing reaches a final state / nothing survives
     g5 = synth.random_graph(120, 3.0, 16, 0.2, 77)
     g5 = dict(g5)

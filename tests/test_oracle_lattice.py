@@ -5,6 +5,7 @@ sets of arcs keyed by (frame, graph state) of both ends."""
 import numpy as np
 import pytest
 
+import golden_util as gu
 from kaldi_decoder import synth
 
 
@@ -44,6 +45,11 @@ def test_canonical_lattice_is_the_reference_lattice_minus_extras(oracle, prune_i
             assert abs(sum(pr.total_cost) - sum(pc.total_cost)) < 1e-3
             # reference-only arcs are the order-dependent extras: few, and never on the best path
             assert len(ra - ca) <= 0.15 * len(ra) + 5
+            # exactly: a reference arc lies below (frame best + beam), the value the running
+            # cutoff ends the frame at, iff the order-free decoder created that link as well
+            frame_best = [can.frame_tokens(f)[1].min() for f in range(61)]
+            gu.assert_extras_beyond_cutoff(gu.lattice_rows(rl), can.created_links(), frame_best,
+                                           beam, g["start"], (prune_interval, utt))
 
 
 def test_canonical_lattice_contains_faster_decoder_best_path(oracle):

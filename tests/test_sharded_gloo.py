@@ -99,3 +99,69 @@ def test_blob_roundtrip_and_single_process_lattice_gather():
     assert blob[4 + 8:4 + 10].view(np.float32).tolist() == [0.5, 1.5]
     got = sharded.gather_lattices([Lat, Lat])
     assert len(got) == 2 and got[0].tolist() == blob.tolist()
+
+
+def _fake_lattice(utt):
+    """A RawLattice-shaped object with random contents (what lattice_blob reads)."""
+    from kaldi_decoder.cabi import RawLattice
+    rng = np.random.default_rng(100 + utt)
+    ns, na = int(rng.integers(1, 60)), int(rng.integers(0, 200))
+    nf = int(rng.integers(0, 4))
+    i32 = lambda n, hi: rng.integers(0, hi, n).astype(np.int32)  # noqa: E731
+    f32 = lambda n: rng.standard_normal(n).astype(np.float32)  # noqa: E731
+    return RawLattice(True, ns, int(rng.integers(0, ns)), i32(na, ns), i32(na, ns), i32(na, 500),
+                      i32(na, 20000), f32(na), f32(na), i32(ns, 250), i32(ns, 1 << 22),
+                      i32(nf, ns), f32(nf))
+
+
+_LAT_FIELDS = ("src", "dst", "ilabel", "olabel", "graph_cost", "ac_cost", "state_frame",
+               "state_graph", "final_state", "final_graph")
+
+
+def _same_lattice(a, b):
+    return (a.ok == b.ok and a.num_states == b.num_states and a.start == b.start and
+            all(getattr(a, k).dtype == getattr(b, k).dtype and
+                getattr(a, k).tobytes() == getattr(b, k).tobytes() for k in _LAT_FIELDS))
+
+
+def test_lattice_blob_roundtrip():
+    for u in range(6):
+        lat = _fake_lattice(u)
+        assert _same_lattice(sharded.lattice_from_blob(sharded.lattice_blob(lat)), lat)
+
+
+def _lattice_worker(rank, world, port, spans, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = spans[rank]
+    got = sharded.gather_lattices([_fake_lattice(u) for u in range(lo, hi)], dst=0,
+                                  as_lattices=True)
+    if rank == 0:
+        total = spans[-1][1]
+        q.put(len(got) == total and all(_same_lattice(got[u], _fake_lattice(u)) for u in range(total)))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("spans", [((0, 7), (7, 9)),     # unequal shards
+                                   ((0, 5), (5, 5)),     # rank 1 has nothing
+                                   ((0, 0), (0, 6))])    # the destination has nothing
+def test_gather_lattices_world2_gloo(spans):
+    """The lattice gather of north_star ("RCCL only for gather of final lattices"): the blob
+    branch of gather_paths, with shards of different sizes and an empty shard; rank 0 must
+    reassemble every RawLattice field bit for bit, in rank order."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_lattice_worker, args=(r, 2, port, spans, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
