@@ -32,12 +32,14 @@ extern "C" {
 #define KD_E_INVALID -1    /* bad argument / failed reference-style assertion */
 #define KD_E_HIP -2        /* a HIP runtime call failed (no GPU, OOM, ...)     */
 #define KD_E_STATE -3      /* call order violated (AdvanceDecoding before Init) */
-#define KD_E_CAPACITY -4   /* token arena / table / frame index exhausted      */
+#define KD_E_CAPACITY -4   /* a pool / table / frame index is full and cannot grow */
 
 /* bits of kd_batch_status()[i] */
 #define KD_UTT_ARENA_FULL 1u
 #define KD_UTT_TABLE_FULL 2u
 #define KD_UTT_FRAMES_FULL 4u
+#define KD_UTT_LINKS_FULL 8u
+#define KD_UTT_OUT_FULL 16u
 
 typedef struct kd_graph kd_graph;
 typedef struct kd_batch kd_batch;
@@ -80,9 +82,16 @@ typedef struct kd_faster_options {
   float beam_delta;
   float hash_ratio;
   /* capacity knobs (not in the reference) */
-  int64_t arena_tokens;  /* back-pointer records shared by the whole batch      */
-  int32_t table_slots;   /* per-utterance spill table, power of two             */
-  int32_t max_frames;    /* frames an utterance can be advanced over            */
+  /* capacity knobs (not in the reference).  They are STARTING sizes: whatever a decode
+   * exhausts is doubled and the search resumes where it stopped (the reference, too, is
+   * limited only by the machine's memory).  0 picks the default. */
+  int64_t arena_tokens;  /* token pool shared by the batch's utterances (default
+                            max(2^20, 2^17 per utterance); at most 2^31 - 1)     */
+  int32_t table_slots;   /* spill table per resident utterance, power of two
+                            (default 2^17, at most 2^19)                         */
+  int32_t max_frames;    /* frames an utterance can be advanced over (default 2048) */
+  int32_t no_grow;       /* 1: never grow; a full pool / table / frame index is
+                            KD_E_CAPACITY, naming the knob to raise              */
 } kd_faster_options;
 
 void kd_faster_options_default(kd_faster_options *o);
@@ -133,6 +142,21 @@ int kd_batch_advance_async(kd_batch *b, const float *const *loglikes_dev,
                            int32_t num_cols, int64_t row_stride,
                            int32_t max_num_frames);
 int kd_batch_sync(kd_batch *b);
+
+/* FasterDecoder::Decode / LatticeSimpleDecoder::Decode (ref: csrc/faster-decoder.cc:121-124,
+ * csrc/lattice-simple-decoder.cc:53-73) for utterances [0, batch) as ONE kernel launch:
+ * InitDecoding, AdvanceDecoding over every row and -- lattice batches, as `want` asks --
+ * FinalizeDecoding (the reference's Decode() always finalizes, :68) and GetRawLattice
+ * (use_final_probs = true) into the batch's output pool, each by the workgroup that
+ * decoded the utterance.  Device pointers only; enqueues and returns, pair with
+ * kd_batch_sync.  Afterwards kd_batch_raw_lattice_prepare / _copy (or the best-path
+ * calls) only move results; no further kernel runs.  The batch may hold any number of
+ * utterances: one launch keeps one workgroup per CU busy from a work queue. */
+#define KD_DECODE_FINALIZE 1
+#define KD_DECODE_LATTICE 2
+int kd_batch_decode_async(kd_batch *b, int32_t batch, const float *const *loglikes_dev,
+                          const int32_t *num_rows, const int32_t *offset, int32_t num_cols,
+                          int64_t row_stride, int32_t want);
 
 /* FasterDecoder::NumFramesDecoded per utterance (ref: csrc/faster-decoder.h:104). */
 int kd_batch_num_frames_decoded(kd_batch *b, int32_t *out);
@@ -219,11 +243,12 @@ typedef struct kd_lattice_options {
   float beam_delta;
   float hash_ratio;
   float prune_scale;
-  /* capacity knobs (not in the reference); 0 picks a default */
+  /* capacity knobs as in kd_faster_options: starting sizes, grown on demand */
   int64_t arena_tokens;
-  int64_t arena_links;
+  int64_t arena_links;   /* forward-link pool (default two per token record)    */
   int32_t table_slots;
   int32_t max_frames;
+  int32_t no_grow;
 } kd_lattice_options;
 
 /* LatticeFasterDecoderConfig defaults (ref: csrc/lattice-faster-decoder.h:48-66). */
@@ -266,6 +291,11 @@ int kd_batch_phase_cycles(kd_batch *b, int64_t *out /* [batch][20] */);
 int kd_batch_last_kernel_ms(kd_batch *b, float *ms);
 
 size_t kd_batch_device_bytes(const kd_batch *b);
+
+/* Current capacities and use: out[0..7] = token pool records, link pool links, spill
+ * table slots, max_frames, token records in use, links in use, number of times anything
+ * was grown since creation, persistent workgroups per launch. */
+int kd_batch_capacity(const kd_batch *b, int64_t *out);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ struct kd_graph {
   int device = 0;
   int32_t num_states = 0, start = -1;
   int64_t num_arcs = 0;
+  int32_t max_ilabel = 0;  // a log-likelihood matrix needs at least this many columns
   DevBuf<StateRec> states;
   DevBuf<ArcRec> arcs;
 };
@@ -63,71 +64,93 @@ struct kd_batch {
   int32_t max_batch = 0, batch = 0;
   hipStream_t stream = nullptr;
   int g_log2_slots = 17;
-  // device state
+  int workgroups = 1;  // persistent workgroups of a launch == owners of the scratch regions
+  // ---- pools (shared by the utterances; grown on demand, see GrowPools)
+  uint64_t tok_cap = 0, link_cap = 0, out_cap = 0;
   DevBuf<int32_t> tok_state, tok_prev, tok_arc;
   DevBuf<double> tok_cost;
-  DevBuf<unsigned long long> arena_top;
-  DevBuf<long long> frame_base;
-  DevBuf<int32_t> frame_count, frames_decoded;
+  DevBuf<float> tok_extra;
+  DevBuf<int32_t> tok_newid;
+  DevBuf<uint32_t> lat_scratch;
+  DevBuf<int32_t> link_src, link_dst, link_arc;
+  DevBuf<float> link_ac, link_graph, link_delta;
+  DevBuf<unsigned long long> out_pool;
+  // ---- per utterance
+  DevBuf<long long> frame_base, link_emit_base, link_eps_base;
+  DevBuf<int32_t> frame_count, link_emit_count, link_eps_count, frame_state_off, frame_arc_off;
+  DevBuf<int32_t> frames_decoded;
   DevBuf<uint32_t> status;
+  DevBuf<UttMem> mem;
   DevBuf<long long> stats;
+  DevBuf<float> lat_fbc, lat_frel;
+  DevBuf<int32_t> lat_any_final, lat_finalized;
+  // ---- per workgroup: spill table, candidate queue, live list, worklists
   DevBuf<uint32_t> g_key, g_arc, g_used, g_wl, g_log_h, g_log_arc, g_log_src;
   DevBuf<unsigned long long> g_cost, g_log_nk;
-  // lattice mode
-  bool lattice = false, finalized = false, lat_stats_valid = false, lat_sizes_valid = false;
-  bool simple = false;
-  DevBuf<float> final_rel;
-  std::vector<float> h_final_rel;
-  int32_t lat_use_final = -1;
+  DevBuf<float> g_log_ac, g_log_gr;
+  // ---- launch control: UttCtl[B] | order[B] | BatchCtl | UttOut[B], device + pinned mirror
+  DevBuf<unsigned char> ctl_dev;
+  unsigned char *ctl_host = nullptr;
+  size_t off_order = 0, off_bctl = 0, off_out = 0, ctl_bytes = 0;
+  UttCtl *h_ctl() const { return reinterpret_cast<UttCtl *>(ctl_host); }
+  int32_t *h_order() const { return reinterpret_cast<int32_t *>(ctl_host + off_order); }
+  BatchCtl *h_bctl() const { return reinterpret_cast<BatchCtl *>(ctl_host + off_bctl); }
+  UttOut *h_out() const { return reinterpret_cast<UttOut *>(ctl_host + off_out); }
+  // cursors of the pools as of the last read-back
+  uint64_t h_tok_top = 0, h_link_top = 0, h_out_top = 0;
+  // the launch in flight (what a relaunch after growing a pool repeats)
+  int32_t l_num_cols = 0;
+  int64_t l_row_stride = 0;
+  uint32_t l_tail_flags = 0;
+  // lattice state
+  bool lattice = false, finalized = false, simple = false;
+  bool lat_stats_valid = false;  // h_final_rel is current
+  int32_t exported_use_final = -1;  // the output pool holds GetRawLattice(use_final_probs = this)
+  bool out_fetched = false;         // ... and out_host holds its words [0, h_out_top)
   kd_lattice_options lo{};
-  int64_t link_cap = 0;  // per utterance
-  DevBuf<float> g_log_ac, g_log_gr, tok_extra, link_ac, link_graph, link_delta, lat_frc, lat_fbc;
-  DevBuf<int32_t> link_src, link_dst, link_arc, link_emit_count, link_eps_count, tok_newid,
-      lat_any_final, lat_sizes;
-  DevBuf<long long> link_emit_base, link_eps_base, lat_state_off, lat_arc_off, lat_final_off;
-  DevBuf<unsigned long long> link_top;
-  DevBuf<uint32_t> lat_scratch;
-  // GetRawLattice output: the ten arrays back to back in one device buffer, read
-  // back with one copy into pinned host memory
-  DevBuf<int32_t> lo_blob;
-  int32_t *lo_host = nullptr;
-  size_t lo_host_words = 0;
-  size_t lo_na = 0, lo_ns = 0, lo_nf = 0;  // layout of the blob: 6 x na, 2 x ns, 2 x nf words
+  unsigned long long *out_host = nullptr;  // pinned
+  size_t out_host_words = 0, out_spec_words = 0, out_last_words = 0;
+  std::vector<float> h_final_rel;
   std::vector<int32_t> h_lat_sizes;
-  DevBuf<UttDesc> utt;
+  std::vector<long long> h_lat_off;
   DevBuf<float> staging;
-  DevBuf<const float *> unused_;
   // path outputs
   DevBuf<int32_t> reached_final, path_len;
   DevBuf<long long> best_tok, path_offset;
-  DevBuf<float> final_weight;
+  DevBuf<float> final_weight, final_rel;
   DevBuf<int32_t> o_ilabel, o_olabel, o_state;
   DevBuf<float> o_graph, o_ac;
   // host mirrors
   std::vector<int32_t> h_decoded, h_path_len, h_reached;
   std::vector<uint32_t> h_status;
-  std::vector<float> h_final_weight;
-  std::vector<UttDesc> h_utt;
+  std::vector<float> h_final_weight, h_path_final_rel;
   bool initialized = false, path_valid = false, pending = false;
   int32_t path_use_final = -1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  int grow_events = 0;
 
   ~kd_batch() {
-    if (lo_host) (void)hipHostFree(lo_host);
+    if (out_host) (void)hipHostFree(out_host);
+    if (ctl_host) (void)hipHostFree(ctl_host);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
   }
 
   size_t DeviceBytes() const {
     return tok_state.bytes() + tok_prev.bytes() + tok_arc.bytes() + tok_cost.bytes() +
-           frame_base.bytes() + frame_count.bytes() + g_key.bytes() + g_arc.bytes() +
-           g_log_h.bytes() + g_log_arc.bytes() + g_log_src.bytes() + g_log_nk.bytes() +
-           g_used.bytes() + g_wl.bytes() + g_cost.bytes() +
-           staging.bytes() + stats.bytes();
+           tok_extra.bytes() + tok_newid.bytes() + lat_scratch.bytes() + link_src.bytes() +
+           link_dst.bytes() + link_arc.bytes() + link_ac.bytes() + link_graph.bytes() +
+           link_delta.bytes() + out_pool.bytes() + frame_base.bytes() + frame_count.bytes() +
+           link_emit_base.bytes() + link_eps_base.bytes() + link_emit_count.bytes() +
+           link_eps_count.bytes() + frame_state_off.bytes() + frame_arc_off.bytes() +
+           g_key.bytes() + g_arc.bytes() + g_log_h.bytes() + g_log_arc.bytes() +
+           g_log_src.bytes() + g_log_nk.bytes() + g_log_ac.bytes() + g_log_gr.bytes() +
+           g_used.bytes() + g_wl.bytes() + g_cost.bytes() + staging.bytes() + stats.bytes() +
+           ctl_dev.bytes();
   }
 
-  SearchParams Params(int do_init) const {
+  SearchParams Params() const {
     SearchParams p{};
     p.states = g->states.p;
     p.arcs = g->arcs.p;
@@ -140,13 +163,17 @@ struct kd_batch {
     p.tok_cost = tok_cost.p;
     p.tok_prev = tok_prev.p;
     p.tok_arc = tok_arc.p;
-    p.arena_cap = static_cast<unsigned long long>(o.arena_tokens / std::max(max_batch, 1));
-    p.arena_top = arena_top.p;
+    p.tok_cap = tok_cap;
+    // a chunk is what an utterance takes from a pool at a time: large enough that the
+    // atomic is rare, small enough that what is left over when the utterance ends is
+    // nothing against the pool
+    p.tok_chunk = static_cast<int32_t>(std::min<uint64_t>(8192, std::max<uint64_t>(64, tok_cap / (8ull * workgroups))));
     p.frame_base = frame_base.p;
     p.frame_count = frame_count.p;
     p.max_frames = o.max_frames;
     p.frames_decoded = frames_decoded.p;
     p.status = status.p;
+    p.mem = mem.p;
     p.stats = stats.p;
     p.g_key = g_key.p;
     p.g_cost = g_cost.p;
@@ -158,8 +185,11 @@ struct kd_batch {
     p.g_log_src = g_log_src.p;
     p.g_log_nk = g_log_nk.p;
     p.g_log2_slots = g_log2_slots;
-    p.utt = utt.p;
-    p.do_init = do_init;
+    p.batch = batch;
+    p.utt = reinterpret_cast<const UttCtl *>(ctl_dev.p);
+    p.order = reinterpret_cast<const int32_t *>(ctl_dev.p + off_order);
+    p.ctl = reinterpret_cast<BatchCtl *>(ctl_dev.p + off_bctl);
+    p.out = reinterpret_cast<UttOut *>(ctl_dev.p + off_out);
     p.lattice = lattice ? 1 : 0;
     p.simple = simple ? 1 : 0;
     p.g_log_ac = g_log_ac.p;
@@ -171,57 +201,24 @@ struct kd_batch {
     p.link_ac = link_ac.p;
     p.link_graph = link_graph.p;
     p.link_delta = link_delta.p;
-    p.link_cap = static_cast<unsigned long long>(link_cap);
-    p.link_top = link_top.p;
+    p.link_cap = link_cap;
+    p.link_chunk = static_cast<int32_t>(std::min<uint64_t>(16384, std::max<uint64_t>(64, link_cap / (8ull * workgroups))));
     p.link_emit_base = link_emit_base.p;
     p.link_emit_count = link_emit_count.p;
     p.link_eps_base = link_eps_base.p;
     p.link_eps_count = link_eps_count.p;
-    return p;
-  }
-
-  LatticeParams LParams() const {
-    LatticeParams p{};
-    p.states = g->states.p;
-    p.arcs = g->arcs.p;
-    p.start = g->start;
-    p.lattice_beam = lo.lattice_beam;
-    p.tok_state = tok_state.p;
-    p.tok_cost = tok_cost.p;
-    p.tok_extra = tok_extra.p;
-    p.tok_newid = tok_newid.p;
-    p.frame_base = frame_base.p;
-    p.frame_count = frame_count.p;
-    p.max_frames = o.max_frames;
-    p.frames_decoded = frames_decoded.p;
-    p.link_src = link_src.p;
-    p.link_dst = link_dst.p;
-    p.link_arc = link_arc.p;
-    p.link_ac = link_ac.p;
-    p.link_graph = link_graph.p;
-    p.link_delta = link_delta.p;
-    p.link_emit_base = link_emit_base.p;
-    p.link_emit_count = link_emit_count.p;
-    p.link_eps_base = link_eps_base.p;
-    p.link_eps_count = link_eps_count.p;
-    p.scratch = lat_scratch.p;
-    p.scratch_stride = static_cast<long long>(o.arena_tokens / std::max(max_batch, 1));
-    p.final_relative_cost = lat_frc.p;
-    p.final_best_cost = lat_fbc.p;
-    p.any_final = lat_any_final.p;
-    p.finalized = finalized ? 1 : 0;
-    p.sizes = lat_sizes.p;
-    p.out_state_off = lat_state_off.p;
-    p.out_arc_off = lat_arc_off.p;
-    p.out_final_off = lat_final_off.p;
-    int32_t *w = lo_blob.p;
-    p.o_src = w; p.o_dst = w + lo_na; p.o_ilabel = w + 2 * lo_na; p.o_olabel = w + 3 * lo_na;
-    p.o_graph = reinterpret_cast<float *>(w + 4 * lo_na);
-    p.o_ac = reinterpret_cast<float *>(w + 5 * lo_na);
-    w += 6 * lo_na;
-    p.o_state_frame = w; p.o_state_graph = w + lo_ns;
-    w += 2 * lo_ns;
-    p.o_final_state = w; p.o_final_graph = reinterpret_cast<float *>(w + lo_nf);
+    p.lat.lattice_beam = lo.lattice_beam;
+    p.lat.tok_extra = tok_extra.p;
+    p.lat.tok_newid = tok_newid.p;
+    p.lat.scratch = lat_scratch.p;
+    p.lat.final_best_cost = lat_fbc.p;
+    p.lat.final_rel = lat_frel.p;
+    p.lat.any_final = lat_any_final.p;
+    p.lat.finalized = lat_finalized.p;
+    p.lat.frame_state_off = frame_state_off.p;
+    p.lat.frame_arc_off = frame_arc_off.p;
+    p.lat.out = out_pool.p;
+    p.lat.out_cap = out_cap;
     return p;
   }
 
@@ -259,6 +256,11 @@ struct kd_batch {
 
 namespace {
 
+constexpr uint32_t kRecoverable =
+    KD_UTT_ARENA_FULL | KD_UTT_LINKS_FULL | KD_UTT_TABLE_FULL | KD_UTT_OUT_FULL;
+constexpr uint64_t kIndexLimit = (1ull << 31) - 1;  // tokens and links are indexed with int32
+constexpr int kMaxLog2Slots = 19;  // the spill table's worklist bitmask lives in 64 KiB of LDS
+
 int CheckOptions(const kd_faster_options &o) {
   // faster-decoder.cc:24-28
   if (!(o.hash_ratio >= 1.0f)) return Fail(KD_E_INVALID, "Check failed: config_.hash_ratio >= 1.0");
@@ -268,65 +270,322 @@ int CheckOptions(const kd_faster_options &o) {
   return KD_OK;
 }
 
-int ReadBack(kd_batch *b) {
-  KD_HIP_TRY(hipMemcpyAsync(b->h_decoded.data(), b->frames_decoded.p, b->batch * sizeof(int32_t),
-                            hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(b->h_status.data(), b->status.p, b->batch * sizeof(uint32_t),
-                            hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipStreamSynchronize(b->stream));
-  b->pending = false;
-  for (int i = 0; i < b->batch; ++i) {
-    if (b->h_status[i]) {
-      std::string m = "utterance " + std::to_string(i) + " stopped at frame " +
-                      std::to_string(b->h_decoded[i]) + ":";
-      if (b->h_status[i] & KD_UTT_ARENA_FULL) m += " token arena full (raise arena_tokens)";
-      if (b->h_status[i] & KD_UTT_TABLE_FULL) m += " token table full (raise table_slots)";
-      if (b->h_status[i] & KD_UTT_FRAMES_FULL) m += " frame index full (raise max_frames)";
-      return Fail(KD_E_CAPACITY, m);
-    }
-  }
+// ---- capacity: everything below grows on demand ---------------------------------
+// A pool, the spill tables or the frame index that turn out too small do not fail the
+// decode (the reference keeps going until the host runs out of memory): the utterances
+// that could not commit a frame stop at that frame boundary with a KD_UTT_* bit, the
+// host doubles what was exhausted and launches again; the search resumes from the
+// arena.  `no_grow` restores the hard limits (KD_E_CAPACITY).
+
+template <class T>
+hipError_t GrowBuf(DevBuf<T> &b, size_t new_count, size_t keep, hipStream_t st) {
+  if (!b.p) return hipSuccess;  // (not allocated in this mode)
+  T *np = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&np), std::max<size_t>(new_count, 1) * sizeof(T));
+  if (e != hipSuccess) return e;
+  if (keep) e = hipMemcpyAsync(np, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { (void)hipFree(np); return e; }
+  (void)hipFree(b.p);
+  b.p = np;
+  b.n = new_count;
+  return hipSuccess;
+}
+
+int GrowTokens(kd_batch *b) {
+  if (b->tok_cap >= kIndexLimit)
+    return Fail(KD_E_CAPACITY, "token pool full at 2^31 - 1 records (32-bit token indices)");
+  const uint64_t cap = std::min<uint64_t>(kIndexLimit, b->tok_cap * 2);
+  const size_t keep = static_cast<size_t>(std::min<uint64_t>(b->h_tok_top, b->tok_cap));
+  hipError_t e = GrowBuf(b->tok_state, cap, keep, b->stream);
+  if (e == hipSuccess) e = GrowBuf(b->tok_cost, cap, keep, b->stream);
+  if (e == hipSuccess) e = GrowBuf(b->tok_prev, cap, keep, b->stream);
+  if (e == hipSuccess) e = GrowBuf(b->tok_arc, cap, keep, b->stream);
+  if (e == hipSuccess) e = GrowBuf(b->tok_extra, cap, keep, b->stream);
+  if (e == hipSuccess) e = GrowBuf(b->tok_newid, cap, 0, b->stream);
+  if (e == hipSuccess) e = GrowBuf(b->lat_scratch, cap, 0, b->stream);
+  if (e != hipSuccess)
+    return Fail(KD_E_CAPACITY, std::string("token pool full and cannot grow: ") + hipGetErrorString(e));
+  b->tok_cap = cap;
+  b->grow_events++;
   return KD_OK;
 }
 
-int Launch(kd_batch *b, int do_init, int32_t num_cols, int64_t row_stride) {
-  SearchParams p = b->Params(do_init);
-  p.num_cols = num_cols;
-  p.row_stride = row_stride;
+int GrowLinks(kd_batch *b) {
+  if (b->link_cap >= kIndexLimit)
+    return Fail(KD_E_CAPACITY, "link pool full at 2^31 - 1 links (32-bit link indices)");
+  const uint64_t cap = std::min<uint64_t>(kIndexLimit, b->link_cap * 2);
+  const size_t keep = static_cast<size_t>(std::min<uint64_t>(b->h_link_top, b->link_cap));
+  hipError_t e = GrowBuf(b->link_src, cap, keep, b->stream);
+  if (e == hipSuccess) e = GrowBuf(b->link_dst, cap, keep, b->stream);
+  if (e == hipSuccess) e = GrowBuf(b->link_arc, cap, keep, b->stream);
+  if (e == hipSuccess) e = GrowBuf(b->link_ac, cap, keep, b->stream);
+  if (e == hipSuccess) e = GrowBuf(b->link_graph, cap, keep, b->stream);
+  if (e == hipSuccess) e = GrowBuf(b->link_delta, cap, keep, b->stream);
+  if (e != hipSuccess)
+    return Fail(KD_E_CAPACITY, std::string("link pool full and cannot grow: ") + hipGetErrorString(e));
+  b->link_cap = cap;
+  b->grow_events++;
+  return KD_OK;
+}
+
+int GrowOut(kd_batch *b) {
+  const uint64_t cap = b->out_cap * 2;
+  // (what the pool holds is exported again after growing: nothing to keep)
+  hipError_t e = GrowBuf(b->out_pool, cap, 0, b->stream);
+  if (e != hipSuccess)
+    return Fail(KD_E_CAPACITY, std::string("lattice output pool cannot grow: ") + hipGetErrorString(e));
+  b->out_cap = cap;
+  b->grow_events++;
+  return KD_OK;
+}
+
+hipError_t AllocTables(kd_batch *b, int lg) {
+  const size_t gs = static_cast<size_t>(b->workgroups) << lg;
+  hipError_t e = hipSuccess;
+  auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  A(b->g_key.Alloc(gs));
+  A(b->g_cost.Alloc(gs));
+  A(b->g_arc.Alloc(gs));
+  A(b->g_used.Alloc(gs));
+  A(b->g_wl.Alloc(2 * gs));
+  A(b->g_log_h.Alloc(2 * gs));
+  A(b->g_log_arc.Alloc(2 * gs));
+  A(b->g_log_src.Alloc(2 * gs));
+  A(b->g_log_nk.Alloc(2 * gs));
+  if (b->lattice || b->simple) A(b->g_log_ac.Alloc(2 * gs));
+  if (b->lattice) A(b->g_log_gr.Alloc(2 * gs));
+  if (e == hipSuccess) e = hipMemsetAsync(b->g_key.p, 0xFF, b->g_key.bytes(), b->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(b->g_cost.p, 0xFF, b->g_cost.bytes(), b->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(b->g_arc.p, 0xFF, b->g_arc.bytes(), b->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  if (e == hipSuccess) b->g_log2_slots = lg;
+  return e;
+}
+
+int GrowTables(kd_batch *b) {
+  if (b->g_log2_slots >= kMaxLog2Slots)
+    return Fail(KD_E_CAPACITY, "token table full at 2^19 slots per utterance: a frame holds more "
+                               "than 393216 tokens (tighten beam / max_active)");
+  // the tables are empty between frames: nothing to carry over
+  if (hipError_t e = AllocTables(b, b->g_log2_slots + 1); e != hipSuccess)
+    return Fail(KD_E_CAPACITY, std::string("token table full and cannot grow: ") + hipGetErrorString(e));
+  b->o.table_slots = 1 << b->g_log2_slots;
+  b->grow_events++;
+  return KD_OK;
+}
+
+// Per-utterance, per-frame index arrays: rows of (max_frames + 1) entries.
+template <class T>
+hipError_t GrowRows(DevBuf<T> &buf, int rows, int old_w, int new_w, hipStream_t st) {
+  if (!buf.p) return hipSuccess;
+  T *np = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&np), static_cast<size_t>(rows) * new_w * sizeof(T));
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(np, 0, static_cast<size_t>(rows) * new_w * sizeof(T), st);
+  if (e == hipSuccess)
+    e = hipMemcpy2DAsync(np, new_w * sizeof(T), buf.p, old_w * sizeof(T), old_w * sizeof(T), rows,
+                         hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { (void)hipFree(np); return e; }
+  (void)hipFree(buf.p);
+  buf.p = np;
+  buf.n = static_cast<size_t>(rows) * new_w;
+  return hipSuccess;
+}
+
+int GrowFrames(kd_batch *b, int32_t need) {
+  if (b->o.no_grow) return Fail(KD_E_CAPACITY, "frame index full (raise max_frames)");
+  int32_t nm = b->o.max_frames;
+  while (nm < need) nm = nm < (1 << 29) ? nm * 2 : need;
+  const int ow = b->o.max_frames + 1, nw = nm + 1, rows = b->max_batch;
+  hipError_t e = GrowRows(b->frame_base, rows, ow, nw, b->stream);
+  if (e == hipSuccess) e = GrowRows(b->frame_count, rows, ow, nw, b->stream);
+  if (e == hipSuccess) e = GrowRows(b->link_emit_base, rows, ow, nw, b->stream);
+  if (e == hipSuccess) e = GrowRows(b->link_emit_count, rows, ow, nw, b->stream);
+  if (e == hipSuccess) e = GrowRows(b->link_eps_base, rows, ow, nw, b->stream);
+  if (e == hipSuccess) e = GrowRows(b->link_eps_count, rows, ow, nw, b->stream);
+  if (e == hipSuccess) e = GrowRows(b->frame_state_off, rows, ow, nw, b->stream);
+  if (e == hipSuccess) e = GrowRows(b->frame_arc_off, rows, ow, nw, b->stream);
+  if (e != hipSuccess)
+    return Fail(KD_E_CAPACITY, std::string("frame index full and cannot grow: ") + hipGetErrorString(e));
+  b->o.max_frames = nm;
+  b->grow_events++;
+  return KD_OK;
+}
+
+// ---- launch -----------------------------------------------------------------------
+// The utterances' UttCtl entries (ll, num_rows, offset, target, flags) are in the pinned
+// mirror.  One H2D copy (control prefix), one kernel, one D2H copy (BatchCtl + results),
+// and -- when the launch exports lattices -- a speculative D2H of as much of the output
+// pool as the previous export filled, so that a steady stream of batches needs no
+// second round trip for the lattices.
+int Enqueue(kd_batch *b) {
+  // work queue order: most frames to decode first, so the launch does not end on a
+  // long utterance started late
+  int32_t *order = b->h_order();
+  for (int i = 0; i < b->batch; ++i) order[i] = i;
+  const UttCtl *uc = b->h_ctl();
+  const std::vector<int32_t> &dec = b->h_decoded;
+  std::stable_sort(order, order + b->batch, [&](int32_t x, int32_t y) {
+    const int fx = uc[x].target - ((uc[x].flags & kUttInit) ? 0 : std::max(dec[x], 0));
+    const int fy = uc[y].target - ((uc[y].flags & kUttInit) ? 0 : std::max(dec[y], 0));
+    return fx > fy;
+  });
+  BatchCtl *bc = b->h_bctl();
+  bc->work_ctr = 0;
+  bc->any_status = 0;
+  bc->tok_top = b->h_tok_top;
+  bc->link_top = b->h_link_top;
+  bc->out_top = b->h_out_top;
+  KD_HIP_TRY(hipMemcpyAsync(b->ctl_dev.p, b->ctl_host, b->off_out, hipMemcpyHostToDevice, b->stream));
+  SearchParams p = b->Params();
+  p.num_cols = b->l_num_cols;
+  p.row_stride = b->l_row_stride;
   KD_HIP_TRY(hipEventRecord(b->ev0, b->stream));
-  KD_HIP_TRY(LaunchSearch(p, b->batch, b->stream));
+  KD_HIP_TRY(LaunchSearch(p, std::min(b->batch, b->workgroups), b->stream));
   KD_HIP_TRY(hipEventRecord(b->ev1, b->stream));
+  KD_HIP_TRY(hipMemcpyAsync(b->ctl_host + b->off_bctl, b->ctl_dev.p + b->off_bctl,
+                            sizeof(BatchCtl) + static_cast<size_t>(b->batch) * sizeof(UttOut),
+                            hipMemcpyDeviceToHost, b->stream));
+  b->out_spec_words = 0;
+  if (b->l_tail_flags & (kUttExport | kUttExportNoFinal)) {
+    size_t spec = std::min<size_t>(b->out_cap, b->out_last_words + b->out_last_words / 4);
+    if (spec && spec <= b->out_host_words) {
+      KD_HIP_TRY(hipMemcpyAsync(b->out_host, b->out_pool.p, spec * 8, hipMemcpyDeviceToHost, b->stream));
+      b->out_spec_words = spec;
+    }
+  }
   b->timed = true;
   b->pending = true;
   b->path_valid = false;
-  b->lat_stats_valid = false;
-  b->lat_sizes_valid = false;
   return KD_OK;
 }
 
-// Validates the per-utterance frame windows and fills b->h_utt (ll pointers are
-// set by the caller).  faster-decoder.cc:126-144.
+std::string StatusMessage(const kd_batch *b, int i) {
+  std::string m = "utterance " + std::to_string(i) + " stopped at frame " +
+                  std::to_string(b->h_decoded[i]) + ":";
+  const uint32_t st = b->h_status[i];
+  if (st & KD_UTT_ARENA_FULL) m += " token pool full (raise arena_tokens)";
+  if (st & KD_UTT_LINKS_FULL) m += " link pool full (raise arena_links)";
+  if (st & KD_UTT_TABLE_FULL) m += " token table full (raise table_slots)";
+  if (st & KD_UTT_FRAMES_FULL) m += " frame index full (raise max_frames)";
+  if (st & KD_UTT_OUT_FULL) m += " lattice output pool full";
+  return m;
+}
+
+// Waits for the launch in flight and takes its results; grows whatever a stopped
+// utterance ran out of and launches again until every utterance is where it was sent.
+int ReadBack(kd_batch *b) {
+  while (true) {
+    KD_HIP_TRY(hipStreamSynchronize(b->stream));
+    b->pending = false;
+    const BatchCtl bc = *b->h_bctl();
+    const UttOut *uo = b->h_out();
+    b->h_tok_top = bc.tok_top;
+    b->h_link_top = bc.link_top;
+    b->h_out_top = bc.out_top;
+    uint32_t any = 0;
+    int first_bad = -1;
+    for (int i = 0; i < b->batch; ++i) {
+      b->h_decoded[i] = uo[i].frames_decoded;
+      b->h_status[i] = uo[i].status;
+      if (uo[i].status && first_bad < 0) first_bad = i;
+      any |= uo[i].status;
+    }
+    if (b->lattice && (b->l_tail_flags & (kUttFinalStats | kUttFinalize | kUttExport | kUttExportNoFinal)) && !any) {
+      for (int i = 0; i < b->batch; ++i) b->h_final_rel[i] = uo[i].final_rel;
+      b->lat_stats_valid = true;
+      if (b->l_tail_flags & kUttFinalize) b->finalized = true;
+      if (b->l_tail_flags & (kUttExport | kUttExportNoFinal)) {
+        for (int i = 0; i < b->batch; ++i) {
+          for (int k = 0; k < 4; ++k) b->h_lat_sizes[4 * i + k] = uo[i].sizes[k];
+          b->h_lat_off[i] = uo[i].out_off;
+        }
+        b->exported_use_final = (b->l_tail_flags & kUttExport) ? 1 : 0;
+        b->out_fetched = b->h_out_top <= b->out_spec_words;
+        b->out_last_words = static_cast<size_t>(b->h_out_top);
+      }
+    }
+    if (!any) return KD_OK;
+    if (b->o.no_grow || (any & ~kRecoverable)) return Fail(KD_E_CAPACITY, StatusMessage(b, first_bad));
+    if (any & KD_UTT_ARENA_FULL)
+      if (int r = GrowTokens(b)) return r;
+    if (any & KD_UTT_LINKS_FULL)
+      if (int r = GrowLinks(b)) return r;
+    if (any & KD_UTT_TABLE_FULL)
+      if (int r = GrowTables(b)) return r;
+    if (any & KD_UTT_OUT_FULL) {
+      if (int r = GrowOut(b)) return r;
+      b->h_out_top = 0;  // every utterance exports again, into the larger pool
+    }
+    // resume: utterances that never got past InitDecoding start over, the others go on
+    // from their last committed frame
+    UttCtl *uc = b->h_ctl();
+    for (int i = 0; i < b->batch; ++i)
+      if (b->h_decoded[i] >= 0) uc[i].flags &= ~kUttInit;
+    if (int r = Enqueue(b)) return r;
+  }
+}
+
+// Validates the per-utterance frame windows and fills the UttCtl entries (ll pointers
+// are set by the caller).  faster-decoder.cc:126-144.
 int PlanAdvance(kd_batch *b, const int32_t *num_rows, const int32_t *offset,
-                int32_t max_num_frames) {
-  if (!b->initialized)
+                int32_t max_num_frames, bool with_init) {
+  if (!with_init && !b->initialized)
     return Fail(KD_E_STATE, "Check failed: num_frames_decoded_ >= 0 && "
                             "\"You must call InitDecoding() before AdvanceDecoding()\"");
-  if (b->finalized)
+  if (!with_init && b->finalized)
     return Fail(KD_E_STATE, "FinalizeDecoding() has been called: cannot decode further");
+  int32_t need = 0;
+  UttCtl *uc = b->h_ctl();
   for (int i = 0; i < b->batch; ++i) {
+    const int32_t done = with_init ? 0 : b->h_decoded[i];
     const int32_t off = offset ? offset[i] : 0;
     const int32_t ready = off + num_rows[i];
-    if (!(ready >= b->h_decoded[i]))
+    if (!(ready >= done))
       return Fail(KD_E_INVALID, "Check failed: num_frames_ready >= num_frames_decoded_");
     int32_t target = ready;
-    if (max_num_frames >= 0) target = std::min(target, b->h_decoded[i] + max_num_frames);
-    if (target > b->h_decoded[i] && b->h_decoded[i] < off)
+    if (max_num_frames >= 0) target = std::min(target, done + max_num_frames);
+    if (target > done && done < off)
       return Fail(KD_E_INVALID, "decodable offset is beyond the next frame to decode");
-    if (target > b->o.max_frames) return Fail(KD_E_CAPACITY, "frame index full (raise max_frames)");
-    b->h_utt[i].num_rows = num_rows[i];
-    b->h_utt[i].offset = off;
-    b->h_utt[i].target = target;
+    need = std::max(need, target);
+    uc[i].num_rows = num_rows[i];
+    uc[i].offset = off;
+    uc[i].target = target;
+    uc[i].flags = with_init ? kUttInit : 0u;
   }
+  if (need > b->o.max_frames)
+    if (int r = GrowFrames(b, need)) return r;
   return KD_OK;
+}
+
+// A launch that decodes nothing: only the lattice tail (`tail`) of every utterance.
+int LaunchTail(kd_batch *b, uint32_t tail) {
+  UttCtl *uc = b->h_ctl();
+  for (int i = 0; i < b->batch; ++i) {
+    uc[i].ll = nullptr;
+    uc[i].num_rows = 0;
+    uc[i].offset = 0;
+    uc[i].target = b->h_decoded[i];
+    uc[i].flags = tail;
+  }
+  b->l_num_cols = 1;
+  b->l_row_stride = 1;
+  b->l_tail_flags = tail;
+  if (int r = Enqueue(b)) return r;
+  return ReadBack(b);
+}
+
+void ResetForInit(kd_batch *b, int32_t batch) {
+  b->batch = batch;
+  b->finalized = false;
+  b->lat_stats_valid = false;
+  b->exported_use_final = -1;
+  b->out_fetched = false;
+  b->h_tok_top = 0;
+  b->h_link_top = 0;
+  b->h_out_top = 0;
 }
 
 }  // namespace
@@ -349,8 +608,12 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
   if (num_states <= 0 || !row_ptr) return Fail(KD_E_INVALID, "empty graph");
   if (start < 0 || start >= num_states)
     return Fail(KD_E_INVALID, "Check failed: start_state != fst::kNoStateId");
+  if (row_ptr[0] != 0) return Fail(KD_E_INVALID, "row_ptr[0] != 0");
   const int64_t na = row_ptr[num_states];
+  if (na > 0 && (!ilabel || !olabel || !weight || !nextstate)) return Fail(KD_E_INVALID, "arc arrays are NULL");
+  if (!final_cost) return Fail(KD_E_INVALID, "final_cost is NULL");
   std::vector<uint8_t> has_eps(num_states, 0);
+  int32_t max_ilabel = 0;
   for (int32_t s = 0; s < num_states; ++s) {
     if (row_ptr[s + 1] < row_ptr[s]) return Fail(KD_E_INVALID, "row_ptr not monotone");
     for (int32_t a = row_ptr[s]; a < row_ptr[s + 1]; ++a) {
@@ -358,6 +621,7 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
         return Fail(KD_E_INVALID, "arc nextstate out of range");
       if (ilabel[a] < 0) return Fail(KD_E_INVALID, "negative ilabel");
       if (ilabel[a] == 0) has_eps[s] = 1;
+      max_ilabel = std::max(max_ilabel, ilabel[a]);
     }
   }
   std::vector<StateRec> st(num_states);
@@ -382,6 +646,7 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
   g->num_states = num_states;
   g->start = start;
   g->num_arcs = na;
+  g->max_ilabel = max_ilabel;
   hipError_t e = g->states.Alloc(num_states);
   if (e == hipSuccess) e = g->arcs.Alloc(ar.size());
   if (e == hipSuccess) e = hipMemcpy(g->states.p, st.data(), st.size() * sizeof(StateRec), hipMemcpyHostToDevice);
@@ -409,11 +674,12 @@ void kd_faster_options_default(kd_faster_options *o) {
   o->arena_tokens = 0;
   o->table_slots = 0;
   o->max_frames = 0;
+  o->no_grow = 0;
 }
 
 static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
-                       const kd_lattice_options *lopts, int32_t max_batch, void *stream,
-                       kd_batch **out) {
+                       const kd_lattice_options *lopts, bool simple, int32_t max_batch,
+                       void *stream, kd_batch **out) {
   KD_HIP_TRY(hipSetDevice(g->device));
   kd_batch *b = new (std::nothrow) kd_batch;
   if (!b) return Fail(KD_E_INVALID, "out of host memory");
@@ -421,53 +687,93 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   b->o = *opts;
   b->max_batch = max_batch;
   b->stream = static_cast<hipStream_t>(stream);
-  if (b->o.arena_tokens <= 0)
-    b->o.arena_tokens = std::min<int64_t>((1ll << 31) - 1, static_cast<int64_t>(max_batch) << 21);
-  b->o.arena_tokens = std::min<int64_t>(b->o.arena_tokens, (1ll << 31) - 1);
-  if (b->o.max_frames <= 0) b->o.max_frames = 8192;
+  b->lattice = lopts != nullptr;
+  b->simple = simple;
+  if (lopts) b->lo = *lopts;
+  // one persistent workgroup per CU takes utterances from the work queue
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device) != hipSuccess || cus <= 0)
+    cus = 256;
+  b->workgroups = std::min<int>(max_batch, cus);
+  // pools: 2^17 token records per utterance to begin with (an HLG decode at beam 15 writes
+  // about 10^5 per 10 s utterance), two links per token; both grow on demand
+  uint64_t tok = b->o.arena_tokens > 0 ? static_cast<uint64_t>(b->o.arena_tokens)
+                                        : std::max<uint64_t>(1ull << 20, static_cast<uint64_t>(max_batch) << 17);
+  b->tok_cap = std::min<uint64_t>(tok, kIndexLimit);
+  b->o.arena_tokens = static_cast<int64_t>(b->tok_cap);
+  if (b->o.max_frames <= 0) b->o.max_frames = 2048;
   int slots = b->o.table_slots <= 0 ? (1 << 17) : b->o.table_slots;
   int lg = 14;
-  while ((1 << lg) < slots && lg < 19) ++lg;
-  b->g_log2_slots = lg;
+  while ((1 << lg) < slots && lg < kMaxLog2Slots) ++lg;
   b->o.table_slots = 1 << lg;
-  const size_t gs = static_cast<size_t>(max_batch) << lg;
   const size_t nf = static_cast<size_t>(max_batch) * (b->o.max_frames + 1);
   hipError_t e = hipSuccess;
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-  A(b->tok_state.Alloc(b->o.arena_tokens));
-  A(b->tok_prev.Alloc(b->o.arena_tokens));
-  A(b->tok_arc.Alloc(b->o.arena_tokens));
-  A(b->tok_cost.Alloc(b->o.arena_tokens));
-  A(b->arena_top.Alloc(max_batch));
+  A(b->tok_state.Alloc(b->tok_cap));
+  A(b->tok_cost.Alloc(b->tok_cap));
+  if (!b->lattice) {  // (lattice tokens keep forward links, not back-pointers)
+    A(b->tok_prev.Alloc(b->tok_cap));
+    A(b->tok_arc.Alloc(b->tok_cap));
+  }
+  if (b->lattice || b->simple) A(b->tok_extra.Alloc(b->tok_cap));
   A(b->frame_base.Alloc(nf));
   A(b->frame_count.Alloc(nf));
   A(b->frames_decoded.Alloc(max_batch));
   A(b->status.Alloc(max_batch));
+  A(b->mem.Alloc(max_batch));
   A(b->stats.Alloc(static_cast<size_t>(max_batch) * kStatStride));
-  A(b->g_key.Alloc(gs));
-  A(b->g_cost.Alloc(gs));
-  A(b->g_arc.Alloc(gs));
-  A(b->g_used.Alloc(gs));
-  A(b->g_wl.Alloc(2 * gs));
-  A(b->g_log_h.Alloc(2 * gs));
-  A(b->g_log_arc.Alloc(2 * gs));
-  A(b->g_log_src.Alloc(2 * gs));
-  A(b->g_log_nk.Alloc(2 * gs));
-  A(b->utt.Alloc(max_batch));
+  A(AllocTables(b, lg));
   A(b->reached_final.Alloc(max_batch));
   A(b->path_len.Alloc(max_batch));
   A(b->best_tok.Alloc(max_batch));
   A(b->path_offset.Alloc(max_batch));
   A(b->final_weight.Alloc(2 * static_cast<size_t>(max_batch)));
   A(b->final_rel.Alloc(max_batch));
-  if (e == hipSuccess) e = hipMemset(b->g_key.p, 0xFF, b->g_key.bytes());
-  if (e == hipSuccess) e = hipMemset(b->g_cost.p, 0xFF, b->g_cost.bytes());
-  if (e == hipSuccess) e = hipMemset(b->g_arc.p, 0xFF, b->g_arc.bytes());
+  // launch control block and its pinned mirror
+  b->off_order = static_cast<size_t>(max_batch) * sizeof(UttCtl);
+  b->off_bctl = (b->off_order + static_cast<size_t>(max_batch) * sizeof(int32_t) + 15) & ~size_t(15);
+  b->off_out = b->off_bctl + ((sizeof(BatchCtl) + 15) & ~size_t(15));
+  b->ctl_bytes = b->off_out + static_cast<size_t>(max_batch) * sizeof(UttOut);
+  A(b->ctl_dev.Alloc(b->ctl_bytes));
+  if (e == hipSuccess)
+    e = hipHostMalloc(reinterpret_cast<void **>(&b->ctl_host), b->ctl_bytes, hipHostMallocDefault);
+  if (e == hipSuccess) std::memset(b->ctl_host, 0, b->ctl_bytes);
   if (e == hipSuccess) e = hipMemset(b->frames_decoded.p, 0xFF, b->frames_decoded.bytes());
   if (e == hipSuccess) e = hipMemset(b->status.p, 0, b->status.bytes());
   if (e == hipSuccess) e = hipMemset(b->stats.p, 0, b->stats.bytes());
+  if (e == hipSuccess) e = hipMemset(b->mem.p, 0, b->mem.bytes());
   if (e == hipSuccess) e = hipEventCreate(&b->ev0);
   if (e == hipSuccess) e = hipEventCreate(&b->ev1);
+  if (e == hipSuccess && lopts) {
+    uint64_t links = lopts->arena_links > 0 ? static_cast<uint64_t>(lopts->arena_links) : 2 * b->tok_cap;
+    b->link_cap = std::min<uint64_t>(links, kIndexLimit);
+    b->lo.arena_links = static_cast<int64_t>(b->link_cap);
+    b->out_cap = std::max<uint64_t>(1ull << 16, static_cast<uint64_t>(max_batch) << 13);
+    A(b->tok_newid.Alloc(b->tok_cap));
+    A(b->lat_scratch.Alloc(b->tok_cap));
+    A(b->link_src.Alloc(b->link_cap));
+    A(b->link_dst.Alloc(b->link_cap));
+    A(b->link_arc.Alloc(b->link_cap));
+    A(b->link_ac.Alloc(b->link_cap));
+    A(b->link_graph.Alloc(b->link_cap));
+    A(b->link_delta.Alloc(b->link_cap));
+    A(b->out_pool.Alloc(b->out_cap));
+    A(b->link_emit_base.Alloc(nf));
+    A(b->link_emit_count.Alloc(nf));
+    A(b->link_eps_base.Alloc(nf));
+    A(b->link_eps_count.Alloc(nf));
+    A(b->frame_state_off.Alloc(nf));
+    A(b->frame_arc_off.Alloc(nf));
+    A(b->lat_fbc.Alloc(max_batch));
+    A(b->lat_frel.Alloc(max_batch));
+    A(b->lat_any_final.Alloc(max_batch));
+    A(b->lat_finalized.Alloc(max_batch));
+    if (e == hipSuccess) e = hipMemset(b->link_emit_count.p, 0, b->link_emit_count.bytes());
+    if (e == hipSuccess) e = hipMemset(b->link_eps_count.p, 0, b->link_eps_count.bytes());
+    if (e == hipSuccess) e = hipMemset(b->lat_finalized.p, 0, b->lat_finalized.bytes());
+    b->h_lat_sizes.assign(4 * static_cast<size_t>(max_batch), 0);
+    b->h_lat_off.assign(max_batch, -1);
+  }
   if (e != hipSuccess) {
     delete b;
     return Fail(KD_E_HIP, std::string("batch allocation: ") + hipGetErrorString(e));
@@ -477,48 +783,8 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   b->h_path_len.assign(max_batch, -1);
   b->h_reached.assign(max_batch, 0);
   b->h_final_weight.assign(2 * static_cast<size_t>(max_batch), 0.f);
+  b->h_path_final_rel.assign(max_batch, 0.f);
   b->h_final_rel.assign(max_batch, 0.f);
-  b->h_utt.assign(max_batch, UttDesc{});
-  if (lopts) {
-    b->lattice = true;
-    b->lo = *lopts;
-    int64_t links = lopts->arena_links > 0 ? lopts->arena_links : 4 * b->o.arena_tokens;
-    links = std::min<int64_t>(links, (1ll << 31) - 1);
-    b->link_cap = links / max_batch;
-    const size_t nl = static_cast<size_t>(b->link_cap) * max_batch;
-    hipError_t e2 = hipSuccess;
-    auto A2 = [&](hipError_t r) { if (e2 == hipSuccess) e2 = r; };
-    A2(b->g_log_ac.Alloc(2 * gs));
-    A2(b->g_log_gr.Alloc(2 * gs));
-    A2(b->tok_extra.Alloc(b->o.arena_tokens));
-    A2(b->tok_newid.Alloc(b->o.arena_tokens));
-    A2(b->lat_scratch.Alloc(b->o.arena_tokens));
-    A2(b->link_src.Alloc(nl));
-    A2(b->link_dst.Alloc(nl));
-    A2(b->link_arc.Alloc(nl));
-    A2(b->link_ac.Alloc(nl));
-    A2(b->link_graph.Alloc(nl));
-    A2(b->link_delta.Alloc(nl));
-    A2(b->link_top.Alloc(max_batch));
-    A2(b->link_emit_base.Alloc(nf));
-    A2(b->link_emit_count.Alloc(nf));
-    A2(b->link_eps_base.Alloc(nf));
-    A2(b->link_eps_count.Alloc(nf));
-    A2(b->lat_frc.Alloc(max_batch));
-    A2(b->lat_fbc.Alloc(max_batch));
-    A2(b->lat_any_final.Alloc(max_batch));
-    A2(b->lat_sizes.Alloc(4 * static_cast<size_t>(max_batch)));
-    A2(b->lat_state_off.Alloc(max_batch));
-    A2(b->lat_arc_off.Alloc(max_batch));
-    A2(b->lat_final_off.Alloc(max_batch));
-    if (e2 == hipSuccess) e2 = hipMemset(b->link_emit_count.p, 0, b->link_emit_count.bytes());
-    if (e2 == hipSuccess) e2 = hipMemset(b->link_eps_count.p, 0, b->link_eps_count.bytes());
-    if (e2 != hipSuccess) {
-      delete b;
-      return Fail(KD_E_HIP, std::string("lattice batch allocation: ") + hipGetErrorString(e2));
-    }
-    b->h_lat_sizes.assign(4 * static_cast<size_t>(max_batch), 0);
-  }
   *out = b;
   return KD_OK;
 }
@@ -529,7 +795,7 @@ int kd_batch_create(const kd_graph *g, const kd_faster_options *opts, int32_t ma
   *out = nullptr;
   if (!g || !opts || max_batch <= 0) return Fail(KD_E_INVALID, "bad argument");
   if (int r = CheckOptions(*opts)) return r;
-  return CreateBatch(g, opts, nullptr, max_batch, stream, out);
+  return CreateBatch(g, opts, nullptr, false, max_batch, stream, out);
 }
 
 int kd_batch_create_simple(const kd_graph *g, float beam, int64_t arena_tokens,
@@ -545,18 +811,7 @@ int kd_batch_create_simple(const kd_graph *g, float beam, int64_t arena_tokens,
   fo.arena_tokens = arena_tokens;
   fo.table_slots = table_slots;
   fo.max_frames = max_frames;
-  if (int r = CreateBatch(g, &fo, nullptr, max_batch, stream, out)) return r;
-  kd_batch *b = *out;
-  const size_t gs = static_cast<size_t>(max_batch) << b->g_log2_slots;
-  hipError_t e = b->g_log_ac.Alloc(2 * gs);
-  if (e == hipSuccess) e = b->tok_extra.Alloc(b->o.arena_tokens);
-  if (e != hipSuccess) {
-    delete b;
-    *out = nullptr;
-    return Fail(KD_E_HIP, std::string("simple batch allocation: ") + hipGetErrorString(e));
-  }
-  b->simple = true;
-  return KD_OK;
+  return CreateBatch(g, &fo, nullptr, true, max_batch, stream, out);
 }
 
 void kd_lattice_options_default(kd_lattice_options *o) {
@@ -573,6 +828,7 @@ void kd_lattice_options_default(kd_lattice_options *o) {
   o->arena_links = 0;
   o->table_slots = 0;
   o->max_frames = 0;
+  o->no_grow = 0;
 }
 
 int kd_batch_create_lattice(const kd_graph *g, const kd_lattice_options *lo, int32_t max_batch,
@@ -599,7 +855,8 @@ int kd_batch_create_lattice(const kd_graph *g, const kd_lattice_options *lo, int
   fo.arena_tokens = lo->arena_tokens;
   fo.table_slots = lo->table_slots;
   fo.max_frames = lo->max_frames;
-  return CreateBatch(g, &fo, lo, max_batch, stream, out);
+  fo.no_grow = lo->no_grow;
+  return CreateBatch(g, &fo, lo, false, max_batch, stream, out);
 }
 
 void kd_batch_destroy(kd_batch *b) {
@@ -622,20 +879,51 @@ int kd_batch_set_options(kd_batch *b, const kd_faster_options *opts) {
 int kd_batch_init_decoding(kd_batch *b, int32_t batch) {
   if (!b || batch <= 0 || batch > b->max_batch) return Fail(KD_E_INVALID, "bad batch size");
   KD_HIP_TRY(hipSetDevice(b->g->device));
-  b->batch = batch;
-  KD_HIP_TRY(hipMemsetAsync(b->arena_top.p, 0, b->arena_top.bytes(), b->stream));
-  if (b->lattice) KD_HIP_TRY(hipMemsetAsync(b->link_top.p, 0, b->link_top.bytes(), b->stream));
-  KD_HIP_TRY(hipMemsetAsync(b->frames_decoded.p, 0xFF, b->frames_decoded.bytes(), b->stream));
-  KD_HIP_TRY(hipMemsetAsync(b->status.p, 0, b->status.bytes(), b->stream));
-  KD_HIP_TRY(hipMemsetAsync(b->stats.p, 0, b->stats.bytes(), b->stream));
-  b->finalized = false;
-  for (auto &u : b->h_utt) u = UttDesc{};
-  KD_HIP_TRY(hipMemcpyAsync(b->utt.p, b->h_utt.data(), batch * sizeof(UttDesc),
-                            hipMemcpyHostToDevice, b->stream));
-  if (int r = Launch(b, 1, 0, 0)) return r;
+  if (b->pending) (void)ReadBack(b);  // (results of a launch nobody waited for are dropped)
+  ResetForInit(b, batch);
+  UttCtl *uc = b->h_ctl();
+  for (int i = 0; i < batch; ++i) uc[i] = UttCtl{nullptr, 0, 0, 0, kUttInit};
+  b->l_num_cols = 1;
+  b->l_row_stride = 1;
+  b->l_tail_flags = 0;
+  if (int r = Enqueue(b)) return r;
   if (int r = ReadBack(b)) return r;
   b->initialized = true;
   return KD_OK;
+}
+
+static uint32_t TailFlags(const kd_batch *b, int32_t want) {
+  uint32_t t = 0;
+  if (!b->lattice) return 0;
+  if (want & KD_DECODE_FINALIZE) t |= kUttFinalize;
+  if (want & KD_DECODE_LATTICE) t |= kUttExport;
+  return t;
+}
+
+int kd_batch_decode_async(kd_batch *b, int32_t batch, const float *const *loglikes_dev,
+                          const int32_t *num_rows, const int32_t *offset, int32_t num_cols,
+                          int64_t row_stride, int32_t want) {
+  if (!b || !loglikes_dev || !num_rows || num_cols <= 0) return Fail(KD_E_INVALID, "bad argument");
+  if (batch <= 0 || batch > b->max_batch) return Fail(KD_E_INVALID, "bad batch size");
+  if (row_stride < num_cols) return Fail(KD_E_INVALID, "row_stride < num_cols");
+  if (num_cols < b->g->max_ilabel)
+    return Fail(KD_E_INVALID, "log-likelihood matrix has " + std::to_string(num_cols) +
+                              " columns but the graph's largest ilabel is " + std::to_string(b->g->max_ilabel));
+  KD_HIP_TRY(hipSetDevice(b->g->device));
+  if (b->pending) (void)ReadBack(b);
+  ResetForInit(b, batch);
+  if (int r = PlanAdvance(b, num_rows, offset, -1, true)) return r;
+  const uint32_t tail = TailFlags(b, want);
+  UttCtl *uc = b->h_ctl();
+  for (int i = 0; i < batch; ++i) {
+    uc[i].ll = loglikes_dev[i];
+    uc[i].flags |= tail;
+  }
+  b->l_num_cols = num_cols;
+  b->l_row_stride = row_stride;
+  b->l_tail_flags = tail;
+  b->initialized = true;
+  return Enqueue(b);
 }
 
 int kd_batch_advance_async(kd_batch *b, const float *const *loglikes_dev, const int32_t *num_rows,
@@ -643,19 +931,27 @@ int kd_batch_advance_async(kd_batch *b, const float *const *loglikes_dev, const 
                            int32_t max_num_frames) {
   if (!b || !loglikes_dev || !num_rows || num_cols <= 0) return Fail(KD_E_INVALID, "bad argument");
   if (row_stride < num_cols) return Fail(KD_E_INVALID, "row_stride < num_cols");
+  if (num_cols < b->g->max_ilabel)
+    return Fail(KD_E_INVALID, "log-likelihood matrix has " + std::to_string(num_cols) +
+                              " columns but the graph's largest ilabel is " + std::to_string(b->g->max_ilabel));
   KD_HIP_TRY(hipSetDevice(b->g->device));
   if (b->pending)
     if (int r = ReadBack(b)) return r;
-  if (int r = PlanAdvance(b, num_rows, offset, max_num_frames)) return r;
-  for (int i = 0; i < b->batch; ++i) b->h_utt[i].ll = loglikes_dev[i];
-  KD_HIP_TRY(hipMemcpyAsync(b->utt.p, b->h_utt.data(), b->batch * sizeof(UttDesc),
-                            hipMemcpyHostToDevice, b->stream));
-  return Launch(b, 0, num_cols, row_stride);
+  if (int r = PlanAdvance(b, num_rows, offset, max_num_frames, false)) return r;
+  UttCtl *uc = b->h_ctl();
+  for (int i = 0; i < b->batch; ++i) uc[i].ll = loglikes_dev[i];
+  b->l_num_cols = num_cols;
+  b->l_row_stride = row_stride;
+  b->l_tail_flags = 0;
+  b->lat_stats_valid = false;
+  b->exported_use_final = -1;
+  return Enqueue(b);
 }
 
 int kd_batch_sync(kd_batch *b) {
   if (!b) return Fail(KD_E_INVALID, "bad argument");
   KD_HIP_TRY(hipSetDevice(b->g->device));
+  if (!b->pending) return KD_OK;
   return ReadBack(b);
 }
 
@@ -674,17 +970,20 @@ int kd_batch_advance(kd_batch *b, const float *const *loglikes, const int32_t *n
   KD_HIP_TRY(hipSetDevice(b->g->device));
   if (b->pending)
     if (int r = ReadBack(b)) return r;
-  if (int r = PlanAdvance(b, num_rows, offset, max_num_frames)) return r;
+  if (int r = PlanAdvance(b, num_rows, offset, max_num_frames, false)) return r;
+  UttCtl *uc = b->h_ctl();
   // stage only the rows this call will read, packed to num_cols
   size_t total = 0;
   std::vector<size_t> first(b->batch), count(b->batch);
   for (int i = 0; i < b->batch; ++i) {
-    const UttDesc &u = b->h_utt[i];
-    const int32_t f0 = b->h_decoded[i], f1 = u.target;
-    first[i] = f1 > f0 ? static_cast<size_t>(f0 - u.offset) : 0;
+    const int32_t f0 = b->h_decoded[i], f1 = uc[i].target;
+    first[i] = f1 > f0 ? static_cast<size_t>(f0 - uc[i].offset) : 0;
     count[i] = f1 > f0 ? static_cast<size_t>(f1 - f0) : 0;
     total += count[i] * num_cols;
   }
+  if (total > 0 && num_cols < b->g->max_ilabel)
+    return Fail(KD_E_INVALID, "log-likelihood matrix has " + std::to_string(num_cols) +
+                              " columns but the graph's largest ilabel is " + std::to_string(b->g->max_ilabel));
   KD_HIP_TRY(b->staging.Reserve(total));
   size_t pos = 0;
   for (int i = 0; i < b->batch; ++i) {
@@ -695,12 +994,15 @@ int kd_batch_advance(kd_batch *b, const float *const *loglikes, const int32_t *n
                                   b->stream));
     }
     // row (frame - offset) of the caller's matrix == row (frame - f0) of the staged block
-    b->h_utt[i].ll = b->staging.p + pos - first[i] * static_cast<size_t>(num_cols);
+    uc[i].ll = b->staging.p + pos - first[i] * static_cast<size_t>(num_cols);
     pos += count[i] * num_cols;
   }
-  KD_HIP_TRY(hipMemcpyAsync(b->utt.p, b->h_utt.data(), b->batch * sizeof(UttDesc),
-                            hipMemcpyHostToDevice, b->stream));
-  if (int r = Launch(b, 0, num_cols, num_cols)) return r;
+  b->l_num_cols = num_cols;
+  b->l_row_stride = num_cols;
+  b->l_tail_flags = 0;
+  b->lat_stats_valid = false;
+  b->exported_use_final = -1;
+  if (int r = Enqueue(b)) return r;
   return ReadBack(b);
 }
 
@@ -732,7 +1034,7 @@ static int PreparePath(kd_batch *b, int32_t use_final_probs) {
                             hipMemcpyDeviceToHost, b->stream));
   KD_HIP_TRY(hipMemcpyAsync(b->h_final_weight.data(), b->final_weight.p,
                             2 * b->batch * sizeof(float), hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(b->h_final_rel.data(), b->final_rel.p, b->batch * sizeof(float),
+  KD_HIP_TRY(hipMemcpyAsync(b->h_path_final_rel.data(), b->final_rel.p, b->batch * sizeof(float),
                             hipMemcpyDeviceToHost, b->stream));
   KD_HIP_TRY(hipStreamSynchronize(b->stream));
   b->path_valid = true;
@@ -830,33 +1132,16 @@ int kd_batch_frame_tokens(kd_batch *b, int32_t utt, int32_t frame_plus_one, int3
   return KD_OK;
 }
 
-static int PreparePath(kd_batch *b, int32_t use_final_probs);
-
-static int LatticeStats(kd_batch *b) {
-  if (b->lat_stats_valid) return KD_OK;
-  LatticeParams p = b->LParams();
-  p.stats_only = 1;
-  KD_HIP_TRY(LaunchLatticePrune(p, b->batch, b->stream));
-  b->lat_stats_valid = true;
-  return KD_OK;
-}
-
 int kd_batch_finalize_decoding(kd_batch *b) {
   if (!b) return Fail(KD_E_INVALID, "bad argument");
   if (!b->lattice) return Fail(KD_E_STATE, "not a lattice batch");
   if (!b->initialized) return Fail(KD_E_STATE, "InitDecoding() has not been called");
-  if (b->finalized) return Fail(KD_E_STATE, "Check failed: !decoding_finalized_");
   KD_HIP_TRY(hipSetDevice(b->g->device));
   if (b->pending)
     if (int r = ReadBack(b)) return r;
-  LatticeParams p = b->LParams();
-  p.stats_only = 0;
-  KD_HIP_TRY(LaunchLatticePrune(p, b->batch, b->stream));
-  KD_HIP_TRY(hipStreamSynchronize(b->stream));
-  b->finalized = true;
-  b->lat_stats_valid = true;
-  b->lat_sizes_valid = false;
-  return KD_OK;
+  if (b->finalized) return Fail(KD_E_STATE, "Check failed: !decoding_finalized_");
+  b->exported_use_final = -1;
+  return LaunchTail(b, kUttFinalize);
 }
 
 int kd_batch_final_relative_cost(kd_batch *b, float *out) {
@@ -864,16 +1149,15 @@ int kd_batch_final_relative_cost(kd_batch *b, float *out) {
   if (!b->initialized) return Fail(KD_E_STATE, "InitDecoding() has not been called");
   if (!b->lattice) {  // SimpleDecoder::FinalRelativeCost, simple-decoder.cc:78-100
     if (int r = PreparePath(b, b->path_valid ? b->path_use_final : 1)) return r;
-    for (int i = 0; i < b->batch; ++i) out[i] = b->h_final_rel[i];
+    for (int i = 0; i < b->batch; ++i) out[i] = b->h_path_final_rel[i];
     return KD_OK;
   }
   KD_HIP_TRY(hipSetDevice(b->g->device));
   if (b->pending)
     if (int r = ReadBack(b)) return r;
-  if (int r = LatticeStats(b)) return r;
-  KD_HIP_TRY(hipMemcpyAsync(out, b->lat_frc.p, b->batch * sizeof(float), hipMemcpyDeviceToHost,
-                            b->stream));
-  KD_HIP_TRY(hipStreamSynchronize(b->stream));
+  if (!b->lat_stats_valid)
+    if (int r = LaunchTail(b, kUttFinalStats)) return r;
+  for (int i = 0; i < b->batch; ++i) out[i] = b->h_final_rel[i];
   return KD_OK;
 }
 
@@ -881,24 +1165,19 @@ int kd_batch_raw_lattice_prepare(kd_batch *b, int32_t use_final_probs, int32_t *
   if (!b || !sizes) return Fail(KD_E_INVALID, "bad argument");
   if (!b->lattice) return Fail(KD_E_STATE, "not a lattice batch");
   if (!b->initialized) return Fail(KD_E_STATE, "InitDecoding() has not been called");
-  if (b->finalized && !use_final_probs)  // lattice-simple-decoder.cc:594-597
-    return Fail(KD_E_STATE, "You cannot call FinalizeDecoding() and then call "
-                            "GetRawLattice() with use_final_probs == false");
   KD_HIP_TRY(hipSetDevice(b->g->device));
   if (b->pending)
     if (int r = ReadBack(b)) return r;
+  if (b->finalized && !use_final_probs)  // lattice-simple-decoder.cc:594-597
+    return Fail(KD_E_STATE, "You cannot call FinalizeDecoding() and then call "
+                            "GetRawLattice() with use_final_probs == false");
   for (int i = 0; i < b->batch; ++i)
     if (!(b->h_decoded[i] > 0)) return Fail(KD_E_STATE, "Check failed: num_frames > 0");
-  if (int r = LatticeStats(b)) return r;
-  if (!(b->lat_sizes_valid && b->lat_use_final == (use_final_probs ? 1 : 0))) {
-    LatticeParams p = b->LParams();
-    p.use_final_probs = use_final_probs ? 1 : 0;
-    KD_HIP_TRY(LaunchLatticeCount(p, b->batch, b->stream));
-    KD_HIP_TRY(hipMemcpyAsync(b->h_lat_sizes.data(), b->lat_sizes.p, 4 * b->batch * sizeof(int32_t),
-                              hipMemcpyDeviceToHost, b->stream));
-    KD_HIP_TRY(hipStreamSynchronize(b->stream));
-    b->lat_sizes_valid = true;
-    b->lat_use_final = use_final_probs ? 1 : 0;
+  const int want = use_final_probs ? 1 : 0;
+  if (b->exported_use_final != want) {
+    b->h_out_top = 0;  // the pool is rewritten from its start
+    b->out_fetched = false;
+    if (int r = LaunchTail(b, use_final_probs ? kUttExport : kUttExportNoFinal)) return r;
   }
   std::memcpy(sizes, b->h_lat_sizes.data(), 4 * b->batch * sizeof(int32_t));
   return KD_OK;
@@ -910,62 +1189,52 @@ int kd_batch_raw_lattice_copy(kd_batch *b, const int64_t *state_off, const int64
                               float *ac_cost, int32_t *state_frame, int32_t *state_graph,
                               int32_t *final_state, float *final_graph) {
   if (!b || !state_off || !arc_off || !final_off) return Fail(KD_E_INVALID, "bad argument");
-  if (!b->lattice || !b->lat_sizes_valid)
+  if (!b->lattice || b->exported_use_final < 0 || b->pending)
     return Fail(KD_E_STATE, "call kd_batch_raw_lattice_prepare first");
   KD_HIP_TRY(hipSetDevice(b->g->device));
-  std::vector<long long> so(b->batch), ao(b->batch), fo(b->batch);
-  size_t ns = 0, na = 0, nfn = 0;
-  for (int i = 0; i < b->batch; ++i) {
-    so[i] = static_cast<long long>(ns);
-    ao[i] = static_cast<long long>(na);
-    fo[i] = static_cast<long long>(nfn);
-    ns += b->h_lat_sizes[4 * i];
-    na += b->h_lat_sizes[4 * i + 1];
-    nfn += b->h_lat_sizes[4 * i + 2];
+  const size_t words = static_cast<size_t>(b->h_out_top);
+  if (words == 0) return KD_OK;
+  if (!b->out_fetched) {
+    if (b->out_host_words < words) {
+      if (b->out_host) (void)hipHostFree(b->out_host);
+      b->out_host = nullptr;
+      b->out_host_words = 0;
+      const size_t want = words + words / 2;
+      if (hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&b->out_host), want * 8, hipHostMallocDefault);
+          e != hipSuccess)
+        return Fail(KD_E_HIP, std::string("lattice output (host): ") + hipGetErrorString(e));
+      b->out_host_words = want;
+    }
+    KD_HIP_TRY(hipMemcpyAsync(b->out_host, b->out_pool.p, words * 8, hipMemcpyDeviceToHost, b->stream));
+    KD_HIP_TRY(hipStreamSynchronize(b->stream));
+    b->out_fetched = true;
   }
-  if (ns == 0) return KD_OK;
-  const size_t words = 6 * na + 2 * ns + 2 * nfn;
-  b->lo_na = na;
-  b->lo_ns = ns;
-  b->lo_nf = nfn;
-  if (hipError_t e = b->lo_blob.Reserve(words); e != hipSuccess)
-    return Fail(KD_E_HIP, std::string("lattice output: ") + hipGetErrorString(e));
-  if (b->lo_host_words < words) {
-    if (b->lo_host) (void)hipHostFree(b->lo_host);
-    b->lo_host = nullptr;
-    b->lo_host_words = 0;
-    const size_t want = words + words / 2;
-    if (hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&b->lo_host), want * 4, hipHostMallocDefault);
-        e != hipSuccess)
-      return Fail(KD_E_HIP, std::string("lattice output (host): ") + hipGetErrorString(e));
-    b->lo_host_words = want;
-  }
-  KD_HIP_TRY(hipMemcpyAsync(b->lat_state_off.p, so.data(), b->batch * 8, hipMemcpyHostToDevice, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(b->lat_arc_off.p, ao.data(), b->batch * 8, hipMemcpyHostToDevice, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(b->lat_final_off.p, fo.data(), b->batch * 8, hipMemcpyHostToDevice, b->stream));
-  LatticeParams p = b->LParams();
-  p.use_final_probs = b->lat_use_final;
-  KD_HIP_TRY(LaunchLatticeFill(p, b->batch, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(b->lo_host, b->lo_blob.p, words * 4, hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipStreamSynchronize(b->stream));
-  const int32_t *hw = b->lo_host;
-  const int32_t *hsrc = hw, *hdst = hw + na, *hil = hw + 2 * na, *hol = hw + 3 * na;
-  const int32_t *hgc = hw + 4 * na, *hac = hw + 5 * na;
-  const int32_t *hsf = hw + 6 * na, *hsg = hsf + ns, *hfs = hsg + ns, *hfg = hfs + nfn;
+  // an utterance's region: states {frame, graph state} | finals {state, weight} |
+  // arcs {src, dst, ilabel, olabel, graph, ac}
   for (int i = 0; i < b->batch; ++i) {
-    const size_t s1 = b->h_lat_sizes[4 * i], a1 = b->h_lat_sizes[4 * i + 1],
-                 f1 = b->h_lat_sizes[4 * i + 2];
-    auto C4 = [&](void *d, const void *s2, size_t n) { if (d && n) std::memcpy(d, s2, n * 4); };
-    C4(src ? src + arc_off[i] : nullptr, hsrc + ao[i], a1);
-    C4(dst ? dst + arc_off[i] : nullptr, hdst + ao[i], a1);
-    C4(ilabel ? ilabel + arc_off[i] : nullptr, hil + ao[i], a1);
-    C4(olabel ? olabel + arc_off[i] : nullptr, hol + ao[i], a1);
-    C4(graph_cost ? graph_cost + arc_off[i] : nullptr, hgc + ao[i], a1);
-    C4(ac_cost ? ac_cost + arc_off[i] : nullptr, hac + ao[i], a1);
-    C4(state_frame ? state_frame + state_off[i] : nullptr, hsf + so[i], s1);
-    C4(state_graph ? state_graph + state_off[i] : nullptr, hsg + so[i], s1);
-    C4(final_state ? final_state + final_off[i] : nullptr, hfs + fo[i], f1);
-    C4(final_graph ? final_graph + final_off[i] : nullptr, hfg + fo[i], f1);
+    const size_t ns = b->h_lat_sizes[4 * i], na = b->h_lat_sizes[4 * i + 1], nf = b->h_lat_sizes[4 * i + 2];
+    if (ns == 0 || b->h_lat_off[i] < 0) continue;
+    const int32_t *w = reinterpret_cast<const int32_t *>(b->out_host + b->h_lat_off[i]);
+    for (size_t k = 0; k < ns; ++k) {
+      if (state_frame) state_frame[state_off[i] + k] = w[2 * k];
+      if (state_graph) state_graph[state_off[i] + k] = w[2 * k + 1];
+    }
+    w += 2 * ns;
+    for (size_t k = 0; k < nf; ++k) {
+      if (final_state) final_state[final_off[i] + k] = w[2 * k];
+      if (final_graph) std::memcpy(final_graph + final_off[i] + k, w + 2 * k + 1, 4);
+    }
+    w += 2 * nf;
+    for (size_t k = 0; k < na; ++k) {
+      const int32_t *a = w + 6 * k;
+      const size_t at = static_cast<size_t>(arc_off[i]) + k;
+      if (src) src[at] = a[0];
+      if (dst) dst[at] = a[1];
+      if (ilabel) ilabel[at] = a[2];
+      if (olabel) olabel[at] = a[3];
+      if (graph_cost) std::memcpy(graph_cost + at, a + 4, 4);
+      if (ac_cost) std::memcpy(ac_cost + at, a + 5, 4);
+    }
   }
   return KD_OK;
 }
@@ -1008,5 +1277,18 @@ int kd_batch_last_kernel_ms(kd_batch *b, float *ms) {
 }
 
 size_t kd_batch_device_bytes(const kd_batch *b) { return b ? b->DeviceBytes() : 0; }
+
+int kd_batch_capacity(const kd_batch *b, int64_t *out) {
+  if (!b || !out) return Fail(KD_E_INVALID, "bad argument");
+  out[0] = static_cast<int64_t>(b->tok_cap);
+  out[1] = static_cast<int64_t>(b->link_cap);
+  out[2] = 1ll << b->g_log2_slots;
+  out[3] = b->o.max_frames;
+  out[4] = static_cast<int64_t>(b->h_tok_top);
+  out[5] = static_cast<int64_t>(b->h_link_top);
+  out[6] = b->grow_events;
+  out[7] = b->workgroups;
+  return KD_OK;
+}
 
 }  // extern "C"

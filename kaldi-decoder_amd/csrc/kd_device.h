@@ -5,9 +5,10 @@
 //   graph    StateRec[S] (16 B)  + ArcRec[A] (16 B), arcs of a state contiguous,
 //            emitting arcs first (stable) so the emitting and epsilon passes
 //            each read one contiguous, 16-byte-aligned range per token.
-//   arena    append-only back-pointer records of the whole batch as four
-//            parallel arrays (state, cost, prev, arc); one contiguous block per
-//            (utterance, frame), allocated with a single atomicAdd.
+//   tokens   append-only records of the whole batch as parallel arrays (state,
+//            cost, prev, arc / extra): one pool shared by the utterances; an
+//            utterance takes a chunk at a time (one atomic) and cuts one contiguous
+//            block per frame from it.  The link pool works the same way.
 //   frames   frame_base/frame_count[utt][frame_plus_one] index the blocks.
 #ifndef KD_DEVICE_H_
 #define KD_DEVICE_H_
@@ -41,12 +42,67 @@ constexpr unsigned long long kCostDead = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kProfSlots = 20;   // diagnostic cycle buckets (KD_PROFILE builds)
 constexpr int kStatStride = 32;  // KD_NUM_STATS counters + kProfSlots, padded
 
-struct UttDesc {
+// ---- launch control ------------------------------------------------------------
+// One device buffer per batch, laid out  UttCtl[B] | order[B] | BatchCtl | UttOut[B].
+// The host uploads the prefix up to and including BatchCtl before every launch (it
+// knows every value: cursors come back with the previous launch's results) and reads
+// BatchCtl | UttOut[B] back afterwards: one copy each way per launch.
+struct UttCtl {
   const float *ll;     // row 0 of this utterance's log-likelihood matrix
   int32_t num_rows;
   int32_t offset;      // frame index of row 0 (DecodableCtc offset)
   int32_t target;      // decode until frames_decoded == target
-  int32_t pad;
+  uint32_t flags;      // kUtt* below
+};
+constexpr uint32_t kUttInit = 1u;        // InitDecoding before anything else
+constexpr uint32_t kUttFinalStats = 2u;  // ComputeFinalCosts / FinalRelativeCost only
+constexpr uint32_t kUttFinalize = 4u;    // FinalizeDecoding when the target is reached
+constexpr uint32_t kUttExport = 8u;      // GetRawLattice into the output pool
+constexpr uint32_t kUttExportNoFinal = 16u;  // ... with use_final_probs == false
+
+struct BatchCtl {
+  int32_t work_ctr;              // next position of `order` to take (work queue)
+  uint32_t any_status;           // OR of every utterance's status bits
+  unsigned long long tok_top;    // token pool: next free record
+  unsigned long long link_top;   // link pool: next free link
+  unsigned long long out_top;    // output pool: next free 8-byte word
+};
+
+struct UttOut {
+  int32_t frames_decoded;
+  uint32_t status;
+  int32_t sizes[4];       // exported lattice: states, arcs, finals, start state
+  long long out_off;      // its first 8-byte word in the output pool (-1: not exported)
+  float final_rel;        // FinalRelativeCost
+  int32_t phase;          // kPhase* below
+};
+constexpr int32_t kPhaseDecoding = 0, kPhaseFinalized = 1;
+
+// Per-utterance allocation state, device resident: the chunk of each pool the
+// utterance is filling.  Frames take contiguous blocks from it; a block that does not
+// fit takes a new chunk from the pool with one atomic (BatchCtl::tok_top / link_top).
+struct UttMem {
+  long long arena_next, arena_end;
+  long long link_next, link_end;
+};
+
+struct LatticeParams {
+  float lattice_beam;
+  float *tok_extra;
+  int32_t *tok_newid;        // [token pool] state id in the exported lattice, -1 if pruned
+  uint32_t *scratch;         // [token pool] per-frame extra-cost keys beyond LDS
+  // per utterance
+  float *final_best_cost;
+  float *final_rel;
+  int32_t *any_final;
+  int32_t *finalized;        // FinalizeDecoding has run
+  // per utterance and frame [max_frames + 1]: first exported state id / arc of the frame
+  int32_t *frame_state_off;
+  int32_t *frame_arc_off;
+  // output pool, 8-byte words: per utterance  states {frame, graph state} x ns |
+  // finals {state id, weight} x nf | arcs {src, dst, ilabel, olabel, graph, ac} x na
+  unsigned long long *out;
+  unsigned long long out_cap;
 };
 
 struct SearchParams {
@@ -59,14 +115,13 @@ struct SearchParams {
   int32_t max_active;
   int32_t min_active;
   float beam_delta;
-  // arena
+  // token pool (shared by the batch's utterances)
   int32_t *tok_state;
   double *tok_cost;
   int32_t *tok_prev;
   int32_t *tok_arc;
-  unsigned long long arena_cap;   // records per utterance: utterance u owns
-                                  // [u * arena_cap, (u + 1) * arena_cap)
-  unsigned long long *arena_top;  // [batch] next free record (absolute index)
+  unsigned long long tok_cap;
+  int32_t tok_chunk;              // records an utterance takes from the pool at a time
   // frame index, per utterance [max_frames + 1]
   long long *frame_base;
   int32_t *frame_count;
@@ -74,82 +129,48 @@ struct SearchParams {
   // per-utterance state
   int32_t *frames_decoded;
   uint32_t *status;
+  UttMem *mem;
   long long *stats;  // [batch][kStatStride]
-  // per-utterance spill table (global memory) and scratch, g_slots entries each
+  // per-WORKGROUP spill table (global memory) and scratch, g_slots entries each
   uint32_t *g_key;
   unsigned long long *g_cost;
   uint32_t *g_arc;
   uint32_t *g_used;
-  uint32_t *g_wl;    // two worklists per utterance
-  // per-utterance candidate log, 2 * g_slots entries (both table modes)
+  uint32_t *g_wl;    // two worklists
+  // per-workgroup candidate log, 2 * g_slots entries (both table modes)
   uint32_t *g_log_h;
   uint32_t *g_log_arc;
   uint32_t *g_log_src;
   unsigned long long *g_log_nk;
   int32_t g_log2_slots;
-  // input
-  const UttDesc *utt;
+  // launch control
+  int32_t batch;
+  const UttCtl *utt;
+  const int32_t *order;      // work queue: utterance ids, longest first
+  BatchCtl *ctl;
+  UttOut *out;
   int32_t num_cols;
   long long row_stride;
-  int32_t do_init;   // 1: run InitDecoding instead of advancing
   // lattice mode (LatticeSimpleDecoder / LatticeFasterDecoder semantics)
   int32_t lattice;           // 0: FasterDecoder (double costs), 1: lattice decoders (float costs)
   int32_t simple;            // 1: SimpleDecoder semantics (plain beam, prune after closure)
   float *g_log_ac;           // queue: acoustic cost (emitting) / source cost at generation (epsilon)
   float *g_log_gr;           // queue: graph cost of the arc (lattice mode)
-  float *tok_extra;          // [arena] extra_cost of each token
-  int32_t *link_src;         // link arena, utterance u owns [u*link_cap, (u+1)*link_cap)
+  float *tok_extra;          // [token pool] extra_cost of each token
+  int32_t *link_src;         // link pool
   int32_t *link_dst;         // -1 once pruned
   int32_t *link_arc;
   float *link_ac;
   float *link_graph;
   float *link_delta;  // (src.tot + ac + graph) - dst.tot, the constant of lattice-simple-decoder.cc:257-260
   unsigned long long link_cap;
-  unsigned long long *link_top;  // [batch] next free link (absolute index)
+  int32_t link_chunk;
   // per utterance [max_frames + 1]: links leaving frame f's tokens
   long long *link_emit_base;     // into frame f+1
   int32_t *link_emit_count;
   long long *link_eps_base;      // into frame f itself
   int32_t *link_eps_count;
-};
-
-struct LatticeParams {
-  const StateRec *states;
-  const ArcRec *arcs;
-  int32_t start;
-  float lattice_beam;
-  const int32_t *tok_state;
-  const double *tok_cost;
-  float *tok_extra;
-  int32_t *tok_newid;        // [arena] state id in the exported lattice, -1 if pruned
-  const long long *frame_base;
-  const int32_t *frame_count;
-  int32_t max_frames;
-  const int32_t *frames_decoded;
-  const int32_t *link_src;
-  int32_t *link_dst;
-  const int32_t *link_arc;
-  const float *link_ac;
-  const float *link_graph;
-  const float *link_delta;
-  const long long *link_emit_base;
-  const int32_t *link_emit_count;
-  const long long *link_eps_base;
-  const int32_t *link_eps_count;
-  uint32_t *scratch;         // [batch][scratch_stride] per-frame extra-cost keys beyond LDS
-  long long scratch_stride;
-  // per utterance results
-  float *final_relative_cost;
-  float *final_best_cost;
-  int32_t *any_final;
-  int32_t stats_only;        // 1: ComputeFinalCosts only (FinalRelativeCost before finalizing)
-  int32_t use_final_probs;
-  int32_t finalized;
-  // export
-  int32_t *sizes;            // [batch][4]: states, arcs, finals, start
-  const long long *out_state_off, *out_arc_off, *out_final_off;
-  int32_t *o_src, *o_dst, *o_ilabel, *o_olabel, *o_state_frame, *o_state_graph, *o_final_state;
-  float *o_graph, *o_ac, *o_final_graph;
+  LatticeParams lat;
 };
 
 struct PathParams {
@@ -181,13 +202,11 @@ struct PathParams {
 };
 
 // Launchers implemented in kd_search.hip / kd_path.hip
-hipError_t LaunchSearch(const SearchParams &p, int batch, hipStream_t stream);
+// `workgroups` persistent workgroups take the batch's utterances from the work queue.
+hipError_t LaunchSearch(const SearchParams &p, int workgroups, hipStream_t stream);
 size_t SearchLdsBytes();
 hipError_t LaunchPathPrepare(const PathParams &p, int batch, hipStream_t stream);
 hipError_t LaunchPathFill(const PathParams &p, int batch, hipStream_t stream);
-hipError_t LaunchLatticePrune(const LatticeParams &p, int batch, hipStream_t stream);
-hipError_t LaunchLatticeCount(const LatticeParams &p, int batch, hipStream_t stream);
-hipError_t LaunchLatticeFill(const LatticeParams &p, int batch, hipStream_t stream);
 
 // Order-preserving map double -> uint64 (so integer atomicMin orders costs).
 __host__ __device__ inline unsigned long long CostKey(double d) {

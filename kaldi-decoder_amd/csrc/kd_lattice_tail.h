@@ -1,0 +1,561 @@
+// kaldi-decoder_amd/csrc/kd_lattice_tail.h -- lattice pruning and raw-lattice export
+// (ref: /root/reference/kaldi-decoder/csrc/lattice-simple-decoder.cc), run by the search
+// kernel's workgroup in the tail of an utterance.  Part of kd_search.hip (included inside
+// its namespace, after the LDS block, ToG / KD_G, CParams, LdsBarrier and kBlock).
+//
+//   FinalCosts   ComputeFinalCosts (:522-560), FinalRelativeCost (:562-572)
+//   Prune        PruneForwardLinksFinal (:425-520) and the backward sweep of
+//                FinalizeDecoding (:407-420) = PruneForwardLinks with delta 0 (:228-305) +
+//                PruneTokensForFrame (:310-334) for every frame
+//   Export       GetRawLattice (:584-657): sizes, state numbering, then states, final
+//                weights and arcs into ONE contiguous region of the batch's output pool
+//
+// Why here and not in kernels of their own (round 1): the workgroup that finishes an
+// utterance already owns a CU and 160 KiB of LDS; separate pruning / export launches
+// could not start while search workgroups held all the LDS, cost two extra launches, two
+// host round trips and a prefix sum on the host per batch.
+//
+// A frame's links are processed link-parallel: link_extra = next.extra + ((tok.tot + ac +
+// graph) - next.tot), links above lattice_beam are excised (dst = -1), the survivors
+// min-reduce into their source token's extra cost with ds_min_u32 on an order-preserving
+// float key held in LDS (one word per token of the frame).  Epsilon links point inside
+// the frame, so the frame is iterated to its fixpoint (from below: extras start at 0 and
+// only grow, which makes early excision safe).
+//
+// Export order is deterministic given the arena order: ids and arc positions are ranks
+// (ballot + popcount inside a frame, a prefix sum over the frames), not atomic counters.
+
+#ifndef KD_LEPS_REGS
+#define KD_LEPS_REGS 4
+#endif
+constexpr int kLdsToks = 36864;  // extra-cost keys of one frame kept in LDS (144 KiB)
+constexpr uint32_t kFInfKey = 0xFF800000u;  // FloatKey(+inf)
+constexpr int kEpsRegs = KD_LEPS_REGS;  // epsilon links of a frame a lane keeps in registers
+
+struct TailShared {
+  uint32_t ne[kLdsToks];
+  int32_t red_i[kWaves];
+  uint32_t best_key, bestwf_key;
+  int32_t any_final, changed, count, start_id, empty_frame;
+  int32_t n_finals;
+  long long out_off;
+  // results of the tail, read by the caller (RunUtterance) from here
+  int32_t r_sizes[4];
+  long long r_out_off;
+  float r_final_rel;
+};
+static_assert(sizeof(TailShared) <= sizeof(Shared), "the tail reuses the search's LDS block");
+__device__ __forceinline__ TailShared &TailLds() { return *reinterpret_cast<TailShared *>(kd_smem); }
+
+__device__ __forceinline__ float FInf() { return __int_as_float(0x7F800000); }
+
+// Exclusive prefix sum of one int per thread over the workgroup; `total` = the sum.
+__device__ __forceinline__ int BlockExclScanI(TailShared &s, int v, int &total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) s.red_i[wave] = x;
+  __syncthreads();
+  if (wave == 0) {
+    int w = lane < kWaves ? s.red_i[lane] : 0, xs = w;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      int y = __shfl_up(xs, d, 64);
+      if (lane >= d) xs += y;
+    }
+    if (lane < kWaves) s.red_i[lane] = xs - w;
+    if (lane == kWaves - 1) s.count = xs;
+  }
+  __syncthreads();
+  const int off = s.red_i[wave] + x - v;
+  total = s.count;
+  __syncthreads();
+  return off;
+}
+static_assert(kWaves <= 16, "BlockExclScanI scans at most 16 wave totals");
+
+// Applies one link block to the frame's new-extra keys (frames that do not fit the
+// LDS-resident path: thousands of tokens and links).  Four links per lane at a time:
+// their records, then the four destination extras (a gather), are requested together
+// (every lane issues every load -- a lane without a link reads a valid dummy --
+// because hipcc waits for a conditional load before it issues the next).
+__device__ __forceinline__ void ApplyLinks(CParams &p, TailShared &s, KD_G uint32_t *ne,
+                                           bool ne_in_lds, long long lb, int ln, long long base) {
+  constexpr int U = 4;
+  const float lattice_beam = p.lat.lattice_beam;
+  for (int i0 = threadIdx.x; i0 < ln; i0 += U * kBlock) {
+    int32_t dst[U], src[U];
+    float delta[U], next_extra[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * kBlock;
+      const long long at = lb + (i < ln ? i : i0);
+      dst[u] = ToG(p.link_dst)[at];
+      src[u] = ToG(p.link_src)[at];
+      delta[u] = ToG(p.link_delta)[at];
+      if (i >= ln) dst[u] = -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) next_extra[u] = ToG(p.tok_extra)[dst[u] < 0 ? base : dst[u]];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (dst[u] < 0) continue;  // already excised (or no link)
+      // lattice-simple-decoder.cc:257-260; (tok.tot + ac + graph) - next.tot was
+      // taken when the link was made (both costs were final then)
+      float link_extra_cost = next_extra[u] + delta[u];
+      if (link_extra_cost > lattice_beam) {  // :264 excise
+        ToG(p.link_dst)[lb + i0 + u * kBlock] = -1;
+        continue;
+      }
+      if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
+      const uint32_t k = FloatKey(link_extra_cost);
+      const long long li = src[u] - base;
+      if (ne_in_lds) atomicMin(&s.ne[li], k);
+      else atomicMin(ToFlat(&ne[li]), k);
+    }
+  }
+}
+
+// ComputeFinalCosts (:522-560) over the last frame's tokens.
+__device__ __forceinline__ void LatticeFinalCosts(CParams &p, TailShared &s, int utt, int F,
+                                                  float &final_best_cost, bool &any_final_out,
+                                                  float &final_rel) {
+  const int tid = threadIdx.x;
+  const long long fb = static_cast<long long>(utt) * (p.max_frames + 1);
+  const long long baseF = ToG(p.frame_base)[fb + F];
+  const int nF = ToG(p.frame_count)[fb + F];
+  if (tid == 0) { s.best_key = kFInfKey; s.bestwf_key = kFInfKey; s.any_final = 0; }
+  __syncthreads();
+  {
+    uint32_t bk = kFInfKey, bwk = kFInfKey;
+    int af = 0;
+    for (int i = tid; i < nF; i += kBlock) {
+      const float cost = static_cast<float>(ToG(p.tok_cost)[baseF + i]);
+      const float final_cost = ToG(p.states)[ToG(p.tok_state)[baseF + i]].final_cost;
+      const float cost_with_final = cost + final_cost;
+      const uint32_t k1 = FloatKey(cost), k2 = FloatKey(cost_with_final);
+      bk = k1 < bk ? k1 : bk;
+      bwk = k2 < bwk ? k2 : bwk;
+      af |= final_cost != FInf();
+    }
+    if (bk != kFInfKey) atomicMin(&s.best_key, bk);
+    if (bwk != kFInfKey) atomicMin(&s.bestwf_key, bwk);
+    if (af) s.any_final = 1;
+  }
+  __syncthreads();
+  const float best_cost = KeyFloat(s.best_key), best_wf = KeyFloat(s.bestwf_key);
+  any_final_out = s.any_final != 0;
+  final_best_cost = best_wf != FInf() ? best_wf : best_cost;  // :553-559
+  final_rel = (best_cost == FInf() && best_wf == FInf()) ? FInf() : best_wf - best_cost;  // :544-552
+  __syncthreads();
+}
+
+// FinalizeDecoding: the exact backward sweep over all frames.
+__device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt, int F,
+                                             float final_best_cost, bool any_final) {
+  const int tid = threadIdx.x;
+  const long long fb = static_cast<long long>(utt) * (p.max_frames + 1);
+  const float lattice_beam = p.lat.lattice_beam;
+  const uint32_t *next_b = nullptr;  // the next frame's final extras, while they are in LDS
+  long long next_base = 0;
+  // frame descriptors are fetched one frame ahead
+  struct Desc { long long base, eb, pb; int n, en, pn; };
+  auto describe = [&](int f) {
+    Desc d;
+    d.base = ToG(p.frame_base)[fb + f];
+    d.n = ToG(p.frame_count)[fb + f];
+    d.eb = f == F ? 0 : ToG(p.link_emit_base)[fb + f];
+    d.en = f == F ? 0 : ToG(p.link_emit_count)[fb + f];
+    d.pb = ToG(p.link_eps_base)[fb + f];
+    d.pn = ToG(p.link_eps_count)[fb + f];
+    return d;
+  };
+  Desc ahead = describe(F);
+  for (int f = F; f >= 0; --f) {
+    const Desc d = ahead;
+    if (f > 0) ahead = describe(f - 1);
+    const long long base = d.base;
+    const int n = d.n;
+    const bool last = f == F;
+    const long long eb = d.eb;
+    const int en = d.en;
+    const long long pb = d.pb;
+    const int pn = d.pn;
+    if (3 * n <= kLdsToks / 2 && pn <= kEpsRegs * kBlock) {
+      // The frame's fixpoint entirely in LDS.  Emitting links end in the next
+      // frame, whose extras are final: their contribution (A) is computed once.
+      // Epsilon links are fetched once into registers; each round recomputes
+      // C = min(A, epsilon links over the current estimate B) and B := C, as the
+      // loop below does through global memory.  Frames alternate between the two
+      // halves of the key array, so the next frame's extras are still there.
+      uint32_t *half = s.ne + (f & 1) * (kLdsToks / 2);
+      uint32_t *A = half, *B = half + n, *C = half + 2 * n;
+      for (int i = tid; i < n; i += kBlock) {
+        uint32_t k = kFInfKey;
+        if (last) {  // the token's own final term (:467)
+          const float tot = static_cast<float>(ToG(p.tok_cost)[base + i]);
+          const float fc =
+              any_final ? ToG(p.states)[ToG(p.tok_state)[base + i]].final_cost : 0.0f;
+          k = FloatKey(tot + fc - final_best_cost);
+        }
+        A[i] = k;
+        B[i] = FloatKey(0.0f);  // tok_extra as the search left it
+      }
+      // this lane's epsilon links: source, destination (frame-relative) and the
+      // cost difference of :257-260
+      // (every lane issues every load -- a lane without a link reads the pool's first
+      // record -- so the epsilon links and the first round of emitting links are in
+      // flight together; loads behind `if (i < pn)` complete one after the other)
+      int e_src[kEpsRegs], e_dst[kEpsRegs];
+      float e_delta[kEpsRegs];
+#pragma unroll
+      for (int r = 0; r < kEpsRegs; ++r) {
+        const int i = tid + r * kBlock;
+        const long long at = i < pn ? pb + i : 0;
+        e_dst[r] = ToG(p.link_dst)[at];
+        e_src[r] = ToG(p.link_src)[at];
+        e_delta[r] = ToG(p.link_delta)[at];
+      }
+      const long long at0 = tid < en ? eb + tid : 0;
+      const int32_t m_dst0 = ToG(p.link_dst)[at0], m_src0 = ToG(p.link_src)[at0];
+      const float m_delta0 = ToG(p.link_delta)[at0];
+#pragma unroll
+      for (int r = 0; r < kEpsRegs; ++r) {
+        const int i = tid + r * kBlock;
+        if (i < pn && e_dst[r] >= 0) {
+          e_src[r] = static_cast<int>(e_src[r] - base);
+          e_dst[r] = static_cast<int>(e_dst[r] - base);
+        } else {
+          e_src[r] = -1;
+          e_dst[r] = -1;
+          e_delta[r] = 0.0f;
+        }
+      }
+      LdsBarrier();
+      // emitting links, into A
+      for (int i = tid; i < en; i += kBlock) {
+        const long long at = eb + i;
+        const bool first = i == tid;  // (the first round was requested above)
+        const int32_t dst = first ? m_dst0 : ToG(p.link_dst)[at];
+        const int32_t src = first ? m_src0 : ToG(p.link_src)[at];
+        const float delta = first ? m_delta0 : ToG(p.link_delta)[at];
+        if (dst < 0) continue;  // already excised
+        const float next_extra = next_b ? KeyFloat(next_b[dst - next_base]) : ToG(p.tok_extra)[dst];
+        float link_extra_cost = next_extra + delta;  // :257-260
+        if (link_extra_cost > lattice_beam) {  // :264 excise
+          ToG(p.link_dst)[at] = -1;
+          continue;
+        }
+        if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
+        atomicMin(&A[src - base], FloatKey(link_extra_cost));
+      }
+      LdsBarrier();
+      while (true) {
+        for (int i = tid; i < n; i += kBlock) C[i] = A[i];
+        if (tid == 0) s.changed = 0;
+        LdsBarrier();
+#pragma unroll
+        for (int r = 0; r < kEpsRegs; ++r) {
+          if (e_src[r] < 0) continue;
+          float link_extra_cost = KeyFloat(B[e_dst[r]]) + e_delta[r];
+          if (link_extra_cost > lattice_beam) {  // :264 excise
+            ToG(p.link_dst)[pb + tid + r * kBlock] = -1;
+            e_src[r] = -1;
+            continue;
+          }
+          if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
+          atomicMin(&C[e_src[r]], FloatKey(link_extra_cost));
+        }
+        LdsBarrier();
+        int ch = 0;
+        for (int i = tid; i < n; i += kBlock) {
+          float v = KeyFloat(C[i]);
+          if (last && v > lattice_beam) v = FInf();  // :507-509
+          const uint32_t k = FloatKey(v);
+          if (k != B[i]) { B[i] = k; ch = 1; }
+        }
+        if (ch) s.changed = 1;
+        LdsBarrier();
+        const int changed = s.changed;
+        LdsBarrier();
+        // without epsilon links nothing in this frame depends on this frame
+        if (!changed || pn == 0) break;
+      }
+      for (int i = tid; i < n; i += kBlock) ToG(p.tok_extra)[base + i] = KeyFloat(B[i]);
+      next_b = B;
+      next_base = base;
+      // (a later frame that reads these extras from global memory -- the path below --
+      // does so behind a full barrier of its own)
+      LdsBarrier();
+      continue;
+    }
+    next_b = nullptr;  // this frame's extras go to global memory only
+    const bool ne_in_lds = n <= kLdsToks;
+    KD_G uint32_t *gne = ToG(p.lat.scratch) + base;  // (the frame's own slice of the pool-wide scratch)
+    while (true) {
+      // start value: +inf, or for the last frame the token's own final term (:467)
+      for (int i = tid; i < n; i += kBlock) {
+        uint32_t k = kFInfKey;
+        if (last) {
+          const float tot = static_cast<float>(ToG(p.tok_cost)[base + i]);
+          const float fc =
+              any_final ? ToG(p.states)[ToG(p.tok_state)[base + i]].final_cost : 0.0f;
+          k = FloatKey(tot + fc - final_best_cost);
+        }
+        if (ne_in_lds) s.ne[i] = k; else gne[i] = k;
+      }
+      if (tid == 0) s.changed = 0;
+      __syncthreads();
+      ApplyLinks(p, s, gne, ne_in_lds, eb, en, base);
+      ApplyLinks(p, s, gne, ne_in_lds, pb, pn, base);
+      __syncthreads();
+      int ch = 0;
+      for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {  // (four tokens per lane in flight)
+        float was[4];
+        uint32_t now[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * kBlock < n ? i0 + u * kBlock : i0;
+          was[u] = ToG(p.tok_extra)[base + i];
+          now[u] = ne_in_lds ? s.ne[i]
+                             : __hip_atomic_load(ToFlat(&gne[i]), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (i0 + u * kBlock >= n) continue;
+          float v = KeyFloat(now[u]);
+          if (last && v > lattice_beam) v = FInf();  // :507-509
+          if (v != was[u]) {
+            ToG(p.tok_extra)[base + i0 + u * kBlock] = v;
+            ch = 1;
+          }
+        }
+      }
+      if (ch) s.changed = 1;
+      __syncthreads();
+      const int changed = s.changed;
+      __syncthreads();
+      // without epsilon links nothing in this frame depends on this frame
+      if (!changed || pn == 0) break;
+    }
+  }
+  __syncthreads();
+}
+
+// GetRawLattice (:584-657).  Frames do not depend on one another here, so the waves of
+// the workgroup take frames independently (a wave needs no barrier to rank the items of
+// its frame: ballot and popcount).  Three passes over the frames: count live tokens and
+// links; (prefix sum over the frames; one atomic takes the utterance's region of the
+// output pool;) number the tokens and write states and final weights; write the arcs.
+// Returns 0 or KD_UTT_OUT_FULL (the host grows the pool and asks again).
+__device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int utt, int F,
+                                                  bool use_final_probs, bool finalized,
+                                                  bool any_final) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long fb = static_cast<long long>(utt) * (p.max_frames + 1);
+  if (F < 1) return 0;  // KALDI_DECODER_ASSERT(num_frames > 0), :610: the host reports it
+  KD_G int32_t *soff = ToG(p.lat.frame_state_off) + fb, *aoff = ToG(p.lat.frame_arc_off) + fb;
+  if (tid == 0) { s.start_id = -1; s.empty_frame = 0; s.n_finals = 0; }
+  __syncthreads();
+  auto alive = [&](long long g) { return !finalized || ToG(p.tok_extra)[g] != FInf(); };
+  constexpr int kT = 4;
+  // pass 1: live tokens and surviving links of every frame
+  for (int f = wave; f <= F; f += kWaves) {
+    const long long base = ToG(p.frame_base)[fb + f];
+    const int n = ToG(p.frame_count)[fb + f];
+    int cnt = 0;
+    for (int c0 = 0; c0 < n; c0 += 64 * kT) {
+      bool a[kT];
+#pragma unroll
+      for (int u = 0; u < kT; ++u) {
+        const int i = c0 + u * 64 + lane;
+        a[u] = i < n && alive(base + i);
+      }
+#pragma unroll
+      for (int u = 0; u < kT; ++u) cnt += __popcll(__ballot(a[u]));
+    }
+    int links = 0;
+    for (int blk = 0; blk < 2; ++blk) {  // links leaving this frame's tokens: epsilon, then emitting
+      if (blk == 1 && f == F) break;
+      const long long lb = blk ? ToG(p.link_emit_base)[fb + f] : ToG(p.link_eps_base)[fb + f];
+      const int ln = blk ? ToG(p.link_emit_count)[fb + f] : ToG(p.link_eps_count)[fb + f];
+      for (int c0 = 0; c0 < ln; c0 += 64 * kT) {
+        bool a[kT];
+#pragma unroll
+        for (int u = 0; u < kT; ++u) {
+          const int i = c0 + u * 64 + lane;
+          a[u] = i < ln && ToG(p.link_dst)[lb + i] >= 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kT; ++u) links += __popcll(__ballot(a[u]));
+      }
+    }
+    if (lane == 0) {
+      soff[f] = cnt;
+      aoff[f] = links;
+      if (cnt == 0) s.empty_frame = 1;  // :615-619
+    }
+  }
+  __syncthreads();
+  if (s.empty_frame) return 0;  // GetRawLattice returns false: sizes stay 0, start -1
+  // first state id / arc position of each frame (exclusive scans over the frames)
+  int ns = 0, na = 0;
+  for (int f0 = 0; f0 <= F; f0 += kBlock) {
+    const int f = f0 + tid;
+    const int v1 = f <= F ? soff[f] : 0, v2 = f <= F ? aoff[f] : 0;
+    int t1, t2;
+    const int o1 = BlockExclScanI(s, v1, t1);
+    const int o2 = BlockExclScanI(s, v2, t2);
+    if (f <= F) { soff[f] = ns + o1; aoff[f] = na + o2; }
+    ns += t1;
+    na += t2;
+  }
+  // final states: the live tokens of the last frame that are final (or all of them)
+  {
+    const long long base = ToG(p.frame_base)[fb + F];
+    const int n = ToG(p.frame_count)[fb + F];
+    int c = 0;
+    for (int i = tid; i < n; i += kBlock) {
+      if (!alive(base + i)) continue;
+      const float fc = ToG(p.states)[ToG(p.tok_state)[base + i]].final_cost;
+      c += (!(use_final_probs && any_final) || fc != FInf()) ? 1 : 0;
+    }
+    c = WaveSumInt(c);
+    if (lane == 0 && c) atomicAdd(&s.n_finals, c);
+  }
+  __syncthreads();
+  const int nf = s.n_finals;
+  // the utterance's region of the output pool: states | finals | arcs, in 8-byte words
+  if (tid == 0) {
+    const unsigned long long words = static_cast<unsigned long long>(ns) + nf + 3ull * na;
+    const unsigned long long b = atomicAdd(&p.ctl->out_top, words);
+    if (b + words > p.lat.out_cap) {
+      atomicAdd(&p.ctl->out_top, 0ull - words);
+      s.out_off = -1;
+    } else {
+      s.out_off = static_cast<long long>(b);
+    }
+  }
+  __syncthreads();
+  const long long off = s.out_off;
+  if (off < 0) return KD_UTT_OUT_FULL;
+  KD_G unsigned long long *o_state = ToG(p.lat.out) + off, *o_final = o_state + ns,
+                          *o_arc = o_final + nf;
+  auto pack = [](uint32_t lo, uint32_t hi) { return static_cast<unsigned long long>(hi) << 32 | lo; };
+  // pass 2: ids, states, final weights, the start state
+  for (int f = wave; f <= F; f += kWaves) {
+    const long long base = ToG(p.frame_base)[fb + f];
+    const int n = ToG(p.frame_count)[fb + f];
+    int before = soff[f], fin_before = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const int i = c0 + lane;
+      const bool a = i < n && alive(base + i);
+      const int32_t st = i < n ? ToG(p.tok_state)[base + i] : 0;
+      const unsigned long long m = __ballot(a);
+      const int id = before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                  __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+      if (i < n) ToG(p.lat.tok_newid)[base + i] = a ? id : -1;
+      if (a) {
+        o_state[id] = pack(static_cast<uint32_t>(f), static_cast<uint32_t>(st));
+        if (f == 0 && st == p.start) s.start_id = id;  // :623-629
+      }
+      before += __popcll(m);
+      if (f == F) {  // :645-652
+        const float fc = a ? ToG(p.states)[st].final_cost : FInf();
+        const bool is_fin = a && (!(use_final_probs && any_final) || fc != FInf());
+        const unsigned long long fm = __ballot(is_fin);
+        const int k = fin_before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(fm >> 32),
+                                       __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(fm), 0));
+        if (is_fin)
+          o_final[k] = pack(static_cast<uint32_t>(id),
+                            __float_as_uint((use_final_probs && any_final) ? fc : 0.0f));
+        fin_before += __popcll(fm);
+      }
+    }
+  }
+  __syncthreads();  // every token's id is in place
+  // pass 3: arcs
+  for (int f = wave; f <= F; f += kWaves) {
+    int before = aoff[f];
+    for (int blk = 0; blk < 2; ++blk) {
+      if (blk == 1 && f == F) break;
+      const long long lb = blk ? ToG(p.link_emit_base)[fb + f] : ToG(p.link_eps_base)[fb + f];
+      const int ln = blk ? ToG(p.link_emit_count)[fb + f] : ToG(p.link_eps_count)[fb + f];
+      for (int c0 = 0; c0 < ln; c0 += 64 * kT) {
+        int32_t dst[kT];
+#pragma unroll
+        for (int u = 0; u < kT; ++u) {
+          const int i = c0 + u * 64 + lane;
+          dst[u] = i < ln ? ToG(p.link_dst)[lb + i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kT; ++u) {
+          const unsigned long long m = __ballot(dst[u] >= 0);
+          if (dst[u] >= 0) {
+            const long long at = lb + c0 + u * 64 + lane;
+            const int k = before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                       __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+            const int32_t arc = ToG(p.link_arc)[at];
+            const ArcRec ar = LoadArcRec(p.arcs, static_cast<uint32_t>(arc));
+            KD_G unsigned long long *w = o_arc + 3ll * k;
+            w[0] = pack(static_cast<uint32_t>(ToG(p.lat.tok_newid)[ToG(p.link_src)[at]]),
+                        static_cast<uint32_t>(ToG(p.lat.tok_newid)[dst[u]]));
+            w[1] = pack(static_cast<uint32_t>(ar.ilabel), static_cast<uint32_t>(ar.olabel));
+            w[2] = pack(__float_as_uint(ToG(p.link_graph)[at]), __float_as_uint(ToG(p.link_ac)[at]));
+          }
+          before += __popcll(m);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    s.r_sizes[0] = ns;
+    s.r_sizes[1] = na;
+    s.r_sizes[2] = nf;
+    s.r_sizes[3] = s.start_id;
+    s.r_out_off = off;
+  }
+  return 0;
+}
+
+// The tail of an utterance that has reached its target frame F.
+// Results: TailShared::r_* (sizes 0 / start -1 / offset -1 when nothing was exported).
+__device__ __noinline__ uint32_t LatticeTail(CParams *pp, int utt, int F, uint32_t flags) {
+  CParams &p = *pp;
+  TailShared &s = TailLds();
+  if (threadIdx.x == 0) {
+    s.r_sizes[0] = 0; s.r_sizes[1] = 0; s.r_sizes[2] = 0; s.r_sizes[3] = -1;
+    s.r_out_off = -1;
+  }
+  const bool was_finalized = Uni(ToG(p.lat.finalized)[utt]) != 0;
+  float final_best_cost = 0.0f, final_rel = 0.0f;
+  bool any_final = false;
+  if (!was_finalized) {
+    LatticeFinalCosts(p, s, utt, F, final_best_cost, any_final, final_rel);
+    if (threadIdx.x == 0) {
+      ToG(p.lat.final_best_cost)[utt] = final_best_cost;
+      ToG(p.lat.any_final)[utt] = any_final ? 1 : 0;
+      ToG(p.lat.final_rel)[utt] = final_rel;
+    }
+  } else {  // (fixed by FinalizeDecoding, :413-417)
+    final_best_cost = ToG(p.lat.final_best_cost)[utt];
+    any_final = ToG(p.lat.any_final)[utt] != 0;
+    final_rel = ToG(p.lat.final_rel)[utt];
+  }
+  if (threadIdx.x == 0) s.r_final_rel = final_rel;
+  bool finalized = was_finalized;
+  if ((flags & kUttFinalize) && !was_finalized) {
+    LatticePrune(p, s, utt, F, final_best_cost, any_final);
+    if (threadIdx.x == 0) ToG(p.lat.finalized)[utt] = 1;
+    finalized = true;
+  }
+  if (flags & (kUttExport | kUttExportNoFinal))
+    return LatticeExport(p, s, utt, F, (flags & kUttExport) != 0, finalized, any_final);
+  return 0;
+}

@@ -170,13 +170,15 @@ struct Shared {
   unsigned long long min_stored;  // simple mode: min stored cost after the emitting insert
   unsigned long long f_best;    // CostKey of the best cost of the frontier to expand
   unsigned long long f_best_next;
-  long long arena_next;         // next free record of this utterance's arena region
+  long long arena_next;         // next free record of this utterance's token-pool chunk
+  long long arena_end;          // ... and the chunk's end
   long long base_out;
   double best_cost;             // the frontier's best token ...
   int32_t best_abeg, best_deg;  // ... and its emitting arc range
-  long long link_next;          // lattice: next free link of this utterance
+  long long link_next;          // lattice: next free link of this utterance's link-pool chunk
+  long long link_end;
   int32_t soft_bar;             // team barrier arrivals since the launch began
-  int32_t pad0;
+  int32_t alloc_ok;             // result of the last chunk allocation (0 ok, else a KD_UTT_* bit)
   // what a tier-1 frame leaves for the waves that sat it out, by frame parity:
   // result, new frontier (size, arena base), and what a replay in the big table needs
   struct {
@@ -435,6 +437,41 @@ __device__ __forceinline__ unsigned long long BlockMinU64(Shared &s, unsigned lo
   for (int w = 1; w < kWaves; ++w) r = s.red64[w] < r ? s.red64[w] : r;
   LdsBarrier();
   return r;
+}
+
+// ---- pools -----------------------------------------------------------------------
+// Token records and forward links come from two pools shared by all utterances of the
+// batch.  An utterance owns a chunk of each ([arena_next, arena_end), [link_next,
+// link_end) in LDS) and cuts one contiguous block per frame from it; when a block does
+// not fit, ONE thread takes a new chunk with one atomic on the pool cursor (the rest of
+// the old chunk is abandoned: at most one frame's worth).  Returns 0 or the KD_UTT_* bit
+// of the pool that is exhausted -- the frame is then not committed, and the host grows
+// the pool and relaunches (kd_api.hip).  Call from one thread.
+__device__ __forceinline__ uint32_t TakeChunks(CParams &p, Shared &s, long long need_tokens,
+                                               long long need_links) {
+  if (s.arena_next + need_tokens > s.arena_end) {
+    const unsigned long long want =
+        static_cast<unsigned long long>(need_tokens > p.tok_chunk ? need_tokens : p.tok_chunk);
+    const unsigned long long b = atomicAdd(&p.ctl->tok_top, want);
+    if (b + want > p.tok_cap) {
+      atomicAdd(&p.ctl->tok_top, 0ull - want);
+      return KD_UTT_ARENA_FULL;
+    }
+    s.arena_next = static_cast<long long>(b);
+    s.arena_end = static_cast<long long>(b + want);
+  }
+  if (need_links > 0 && s.link_next + need_links > s.link_end) {
+    const unsigned long long want =
+        static_cast<unsigned long long>(need_links > p.link_chunk ? need_links : p.link_chunk);
+    const unsigned long long b = atomicAdd(&p.ctl->link_top, want);
+    if (b + want > p.link_cap) {
+      atomicAdd(&p.ctl->link_top, 0ull - want);
+      return KD_UTT_LINKS_FULL;
+    }
+    s.link_next = static_cast<long long>(b);
+    s.link_end = static_cast<long long>(b + want);
+  }
+  return 0;
 }
 
 // ---- table access: LDS (ds_* ops) or global memory (L2 atomics) --------------
@@ -1273,12 +1310,12 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
     }
   }
   if (tid == 0) {
-    // each utterance owns arena[utt * arena_cap, (utt + 1) * arena_cap)
-    const long long b = s.arena_next;
-    const bool full =
-        b + n_out > static_cast<long long>(c.utt + 1) * static_cast<long long>(p.arena_cap);
-    s.base_out = full ? -1 : b;
-    if (!full) s.arena_next = b + n_out;
+    // the frame's token block, and room for its forward links (at most one per queue
+    // entry below the cutoff), from this utterance's chunks of the pools
+    const uint32_t e = TakeChunks(p, s, n_out, c.lattice ? s.n_emit_links + (n_q - q_emit) : 0);
+    s.alloc_ok = static_cast<int32_t>(e);
+    s.base_out = e ? -1 : s.arena_next;
+    if (!e) s.arena_next += n_out;
     s.f_best_next = kCostDead;
     s.best_deg = 0;
     s.best_abeg = 0;
@@ -1287,7 +1324,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
   TableBarrier<LDS>();
   KD_LAP(s, 10);
   const long long base_out = s.base_out;
-  if (base_out < 0) return KD_UTT_ARENA_FULL;
+  if (base_out < 0) return static_cast<uint32_t>(s.alloc_ok);
   // SimpleDecoder::PruneToks (simple-decoder.cc:252-281): tokens at or beyond
   // best + beam leave the frontier.  They keep their arena record (tokens that
   // survive may point back at them), placed after the kept ones.
@@ -1376,11 +1413,8 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
   // only if generated from their source token's final cost (:164-165 deletes
   // and regenerates the links of a re-expanded token).
   if (c.lattice) {
-    const long long lbase = s.link_next;
+    const long long lbase = s.link_next;  // (room was taken with the token block)
     const int n_emit = s.n_emit_links;
-    const bool full = lbase + n_emit + (n_q - q_emit) >
-                      static_cast<long long>(c.utt + 1) * static_cast<long long>(p.link_cap);
-    if (full) return KD_UTT_ARENA_FULL;
     if constexpr (LDS) {
       for (int i = tid; i < n_q; i += kBlock) {
         const uint32_t h = c.q_h[i];
@@ -1999,15 +2033,19 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       }
     });
   }
-  long long base_out;
-  {
-    // each utterance owns arena[utt * arena_cap, (utt + 1) * arena_cap)
-    const long long b = Uni(s.arena_next);
-    const bool full =
-        b + n_out > static_cast<long long>(c.utt + 1) * static_cast<long long>(p.arena_cap);
-    base_out = full ? -1 : b;
+  // the frame's token block and room for its forward links (at most one per queue entry
+  // below the cutoff) come from this utterance's chunks of the pools; a new chunk is a
+  // rare event (one in some twenty frames) with two team barriers of its own
+  const int link_room = c.lattice ? Uni(s.n_emit_links) + (n_q - q_emit) : 0;
+  if (Uni(s.arena_next) + n_out > Uni(s.arena_end) ||
+      (c.lattice && Uni(s.link_next) + link_room > Uni(s.link_end))) {
+    tm.Sync(false);
+    if (tid == 0) s.alloc_ok = static_cast<int32_t>(TakeChunks(p, s, n_out, link_room));
+    tm.Sync(false);
+    const uint32_t e = static_cast<uint32_t>(Uni(s.alloc_ok));
+    if (e) return e;
   }
-  if (base_out < 0) return KD_UTT_ARENA_FULL;
+  const long long base_out = Uni(s.arena_next);
   // ---- C1: live list -> token records; a slot's key word now holds its index in
   // the block.  Each token's state record is fetched now for the next frame's filter.
   const bool next_small = n_out <= kT1Front;
@@ -2074,11 +2112,8 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   KD_LAP(s, 16);
   // ---- forward links (see FrameBack)
   if (c.lattice) {
-    const long long lbase = Uni(s.link_next);
+    const long long lbase = Uni(s.link_next);  // (room was taken with the token block)
     const int n_emit = Uni(s.n_emit_links);
-    const bool full = lbase + n_emit + (n_q - q_emit) >
-                      static_cast<long long>(c.utt + 1) * static_cast<long long>(p.link_cap);
-    if (full) return KD_UTT_ARENA_FULL;
     split(0, n_q, [&](auto w, int lo, int hi) {
       for (int i = lo + tid; i < hi; i += nt) {
         // the entry's queue words together, then its table words together (read one
@@ -2195,18 +2230,20 @@ __device__ __forceinline__ void LoadFront(const FrameCtx<M> &c, const Team &tm) 
 }
 
 template <int M>
-__device__ __forceinline__ void InitCtx(FrameCtx<M> &c, CParams &p, int utt) {
-  const long long gslots = 1ll << p.g_log2_slots;
-  c.wl0 = ToG(p.g_wl) + (2ll * utt) * gslots;
-  c.wl1 = ToG(p.g_wl) + (2ll * utt + 1) * gslots;
-  c.live = ToG(p.g_used) + utt * gslots;
+__device__ __forceinline__ void InitCtx(FrameCtx<M> &c, CParams &p) {
+  // the spill table, the candidate queue, the live list and the worklists belong to the
+  // WORKGROUP (they are empty between frames), not to the utterance it is decoding
+  const long long gslots = 1ll << p.g_log2_slots, wg = blockIdx.x;
+  c.wl0 = ToG(p.g_wl) + (2ll * wg) * gslots;
+  c.wl1 = ToG(p.g_wl) + (2ll * wg + 1) * gslots;
+  c.live = ToG(p.g_used) + wg * gslots;
   c.q_cap = static_cast<int>(2 * gslots);
-  c.q_h = ToG(p.g_log_h) + utt * 2 * gslots;
-  c.q_arc = ToG(p.g_log_arc) + utt * 2 * gslots;
-  c.q_src = ToG(p.g_log_src) + utt * 2 * gslots;
-  c.q_nk = ToG(p.g_log_nk) + utt * 2 * gslots;
-  c.q_ac = ToG(p.g_log_ac) + utt * 2 * gslots;
-  c.q_gr = ToG(p.g_log_gr) + utt * 2 * gslots;
+  c.q_h = ToG(p.g_log_h) + wg * 2 * gslots;
+  c.q_arc = ToG(p.g_log_arc) + wg * 2 * gslots;
+  c.q_src = ToG(p.g_log_src) + wg * 2 * gslots;
+  c.q_nk = ToG(p.g_log_nk) + wg * 2 * gslots;
+  c.q_ac = ToG(p.g_log_ac) + wg * 2 * gslots;
+  c.q_gr = ToG(p.g_log_gr) + wg * 2 * gslots;
   c.min_only = false;
   c.run_min = kCostInf<M>;
   c.replay = false;
@@ -2222,7 +2259,7 @@ __device__ __noinline__ uint32_t FrameBackSpill(CParams *pp, int utt, long long 
   CParams &p = *pp;
   Shared &s = Lds();
   FrameCtx<M> c{p, s, utt};
-  InitCtx(c, p, utt);
+  InitCtx(c, p);
   c.base_in = base_in;
   c.n_in = n_in;
   c.cutoff = cutoff;
@@ -2230,9 +2267,9 @@ __device__ __noinline__ uint32_t FrameBackSpill(CParams *pp, int utt, long long 
   Counters cnt;
   cnt.tokens_expanded = n_expanded;
   cnt.arcs_scanned = n_arcs;
-  const long long gslots = 1ll << p.g_log2_slots;
-  Table<false> tg{s, ToG(p.g_key) + c.utt * gslots, ToG(p.g_cost) + c.utt * gslots,
-                  ToG(p.g_arc) + c.utt * gslots, reinterpret_cast<uint32_t *>(s.cost),
+  const long long gslots = 1ll << p.g_log2_slots, wg = blockIdx.x;
+  Table<false> tg{s, ToG(p.g_key) + wg * gslots, ToG(p.g_cost) + wg * gslots,
+                  ToG(p.g_arc) + wg * gslots, reinterpret_cast<uint32_t *>(s.cost),
                   p.g_log2_slots, static_cast<uint32_t>(gslots - 1)};
   uint32_t r = FrameBack<false>(c, tg, frame, q_emit, cnt);
   if (r != 0) {  // leave the global table clean for later frames
@@ -2262,7 +2299,7 @@ __device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long 
   const bool filtered = flags & 1, upper_dirty = flags & 2, best_stale = flags & 4;
   Table<true> tl{s, nullptr, nullptr, nullptr, s.bitmask, kLog2Slots, kSlots - 1};
   FrameCtx<M> c{p, s, utt};
-  InitCtx(c, p, utt);
+  InitCtx(c, p);
   c.base_in = base_in;
   c.n_in = n_in;
   c.cutoff = cutoff;
@@ -2330,19 +2367,32 @@ __device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long 
   return r;
 }
 
+#include "kd_lattice_tail.h"
+
+// What one workgroup does for one utterance of the work queue: InitDecoding if asked,
+// the frames up to the utterance's target, then -- lattice decoders, when asked -- the
+// tail: ComputeFinalCosts, FinalizeDecoding's backward prune and GetRawLattice into the
+// output pool (kd_lattice_tail.h), all while the utterance's LDS is still this workgroup's.
 template <int M>
-// (HIP's second bound is waves per SIMD: the workgroups sharing a CU spread over four)
-__global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) void SearchKernel(const SearchParams p_by_value) {
-  Shared &s = Lds();
-  (void)p_by_value;  // the only argument: it is the kernel-argument segment
-  CParams &p = *(CParams *)__builtin_amdgcn_kernarg_segment_ptr();
-  const int tid = threadIdx.x, utt = blockIdx.x;
+__device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int utt) {
+  const int tid = threadIdx.x;
   constexpr int KD_BUCKET = kBucketBig;
   (void)KD_BUCKET;
 
   Table<true> tl{s, nullptr, nullptr, nullptr, s.bitmask, kLog2Slots, kSlots - 1};
   FrameCtx<M> c{p, s, utt};
-  InitCtx(c, p, utt);
+  InitCtx(c, p);
+
+  UttCtl ud;
+  ud.ll = reinterpret_cast<const float *>(Uni(reinterpret_cast<unsigned long long>(ToG(p.utt)[utt].ll)));
+  ud.offset = Uni(ToG(p.utt)[utt].offset);
+  ud.target = Uni(ToG(p.utt)[utt].target);
+  ud.flags = Uni(ToG(p.utt)[utt].flags);
+  const bool do_init = (ud.flags & kUttInit) != 0;
+  uint32_t err = do_init ? 0u : Uni(ToG(p.status)[utt]);
+  int frame = do_init ? -1 : Uni(ToG(p.frames_decoded)[utt]);
+  const int target = ud.target;
+  const bool search = err == 0 && frame < target;  // (otherwise only the tail has work)
 
   if (tid < KD_NUM_STATS) s.stat[tid] = 0;
   if (tid < 4) s.frame_cnt[tid] = 0;
@@ -2351,26 +2401,19 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
   if (tid < kProfSlots) s.cyc[tid] = 0;
   if (tid == 0) s.lap_last = static_cast<long long>(__builtin_amdgcn_s_memtime());
 #endif
-  FullClear<true>(tl, s);
-
-  UttDesc ud;
-  ud.ll = reinterpret_cast<const float *>(Uni(reinterpret_cast<unsigned long long>(ToG(p.utt)[utt].ll)));
-  ud.offset = Uni(ToG(p.utt)[utt].offset);
-  ud.target = Uni(ToG(p.utt)[utt].target);
-  uint32_t err = Uni(ToG(p.status)[utt]);
-  int frame = p.do_init ? -1 : Uni(ToG(p.frames_decoded)[utt]);
-  const int target = p.do_init ? 0 : ud.target;
+  if (search) FullClear<true>(tl, s);
 
   c.base_in = 0;
   c.n_in = 0;
   if (tid == 0) {
-    s.arena_next = p.do_init ? static_cast<long long>(utt) * static_cast<long long>(p.arena_cap)
-                             : static_cast<long long>(ToG(p.arena_top)[utt]);
-    if (c.lattice)
-      s.link_next = p.do_init ? static_cast<long long>(utt) * static_cast<long long>(p.link_cap)
-                              : static_cast<long long>(ToG(p.link_top)[utt]);
+    const KD_G UttMem *m = ToG(p.mem) + utt;
+    s.arena_next = do_init ? 0 : m->arena_next;
+    s.arena_end = do_init ? 0 : m->arena_end;
+    s.link_next = do_init ? 0 : m->link_next;
+    s.link_end = do_init ? 0 : m->link_end;
   }
-  if (frame >= 0 && frame < target) {
+  if (do_init && c.lattice && tid == 0) ToG(p.lat.finalized)[utt] = 0;
+  if (search && frame >= 0) {
     const long long fi = static_cast<long long>(utt) * (p.max_frames + 1) + frame;
     c.base_in = Uni(static_cast<long long>(ToG(p.frame_base)[fi]));
     c.n_in = Uni(static_cast<int>(ToG(p.frame_count)[fi]));
@@ -2525,21 +2568,79 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
     }
   }
   __syncthreads();
+  const int frames_done = frame < 0 ? -1 : frame;
   if (tid == 0) {
-    ToG(p.frames_decoded)[utt] = frame < 0 ? -1 : frame;
+    ToG(p.frames_decoded)[utt] = frames_done;
     ToG(p.status)[utt] = err;
-    ToG(p.arena_top)[utt] = static_cast<unsigned long long>(s.arena_next);
-    if (c.lattice) ToG(p.link_top)[utt] = static_cast<unsigned long long>(s.link_next);
+    KD_G UttMem *m = ToG(p.mem) + utt;
+    m->arena_next = s.arena_next;
+    m->arena_end = s.arena_end;
+    m->link_next = s.link_next;
+    m->link_end = s.link_end;
+    if (err) atomicOr(&p.ctl->any_status, err);
   }
   if (tid < KD_NUM_STATS) {
     KD_G long long *st = ToG(p.stats) + static_cast<long long>(utt) * kStatStride;
-    if (tid == KD_STAT_MAX_TOKENS) st[tid] = s.stat[tid] > st[tid] ? s.stat[tid] : st[tid];
-    else st[tid] += s.stat[tid];
+    const long long was = do_init ? 0 : st[tid];
+    if (tid == KD_STAT_MAX_TOKENS) st[tid] = s.stat[tid] > was ? s.stat[tid] : was;
+    else st[tid] = was + s.stat[tid];
   }
 #ifdef KD_PROFILE
-  if (tid < kProfSlots)
-    ToG(p.stats)[static_cast<long long>(utt) * kStatStride + KD_NUM_STATS + tid] += s.cyc[tid];
+  if (tid < kProfSlots) {
+    KD_G long long *cy = ToG(p.stats) + static_cast<long long>(utt) * kStatStride + KD_NUM_STATS;
+    cy[tid] = (do_init ? 0 : cy[tid]) + s.cyc[tid];
+  }
 #endif
+  // ---- the tail (lattice decoders): the searching is done, the LDS is free
+  UttOut o;
+  o.frames_decoded = frames_done;
+  o.status = err;
+  o.sizes[0] = 0; o.sizes[1] = 0; o.sizes[2] = 0; o.sizes[3] = -1;
+  o.out_off = -1;
+  o.final_rel = 0.0f;
+  o.phase = kPhaseDecoding;
+  if constexpr (M == 1) {
+    if (err == 0 && frame == target && frame >= 0 &&
+        (ud.flags & (kUttFinalStats | kUttFinalize | kUttExport | kUttExportNoFinal))) {
+      __syncthreads();  // (every wave is done with the search's LDS)
+      const uint32_t e = Uni(LatticeTail(&p, utt, frame, ud.flags));
+      __syncthreads();
+      if (e && tid == 0) {
+        ToG(p.status)[utt] = e;
+        atomicOr(&p.ctl->any_status, e);
+      }
+      const TailShared &ts = TailLds();
+      o.status = e;
+      o.sizes[0] = ts.r_sizes[0]; o.sizes[1] = ts.r_sizes[1];
+      o.sizes[2] = ts.r_sizes[2]; o.sizes[3] = ts.r_sizes[3];
+      o.out_off = ts.r_out_off;
+      o.final_rel = ts.r_final_rel;
+    }
+    if (Uni(ToG(p.lat.finalized)[utt]) != 0) o.phase = kPhaseFinalized;
+  }
+  if (tid == 0) p.out[utt] = o;
+}
+
+__shared__ int kd_work_item;
+
+template <int M>
+// (HIP's second bound is waves per SIMD: the workgroups sharing a CU spread over four)
+__global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) void SearchKernel(const SearchParams p_by_value) {
+  Shared &s = Lds();
+  (void)p_by_value;  // the only argument: it is the kernel-argument segment
+  CParams &p = *(CParams *)__builtin_amdgcn_kernarg_segment_ptr();
+  // Persistent workgroups and a work queue: the launch has at most one workgroup per CU;
+  // each takes the next utterance of `order` (longest first) until none is left, so a CU
+  // that finishes a short utterance goes on with another one -- of any size of batch --
+  // instead of idling until the launch's slowest utterance is done.
+  while (true) {
+    __syncthreads();  // the previous utterance is finished by every wave
+    if (threadIdx.x == 0) kd_work_item = atomicAdd(&p.ctl->work_ctr, 1);
+    __syncthreads();
+    const int item = Uni(kd_work_item);
+    if (item >= p.batch) break;
+    RunUtterance<M>(p, s, Uni(ToG(p.order)[item]));
+  }
 }
 
 }  // namespace
@@ -2548,16 +2649,16 @@ size_t SearchLdsBytes() { return sizeof(Shared); }
 
 namespace {
 template <int M>
-hipError_t LaunchMode(const SearchParams &p, int batch, hipStream_t stream) {
-  hipLaunchKernelGGL(SearchKernel<M>, dim3(batch), dim3(kBlock), 0, stream, p);
+hipError_t LaunchMode(const SearchParams &p, int workgroups, hipStream_t stream) {
+  hipLaunchKernelGGL(SearchKernel<M>, dim3(workgroups), dim3(kBlock), 0, stream, p);
   return hipGetLastError();
 }
 }  // namespace
 
-hipError_t LaunchSearch(const SearchParams &p, int batch, hipStream_t stream) {
-  if (p.lattice) return LaunchMode<1>(p, batch, stream);
-  if (p.simple) return LaunchMode<2>(p, batch, stream);
-  return LaunchMode<0>(p, batch, stream);
+hipError_t LaunchSearch(const SearchParams &p, int workgroups, hipStream_t stream) {
+  if (p.lattice) return LaunchMode<1>(p, workgroups, stream);
+  if (p.simple) return LaunchMode<2>(p, workgroups, stream);
+  return LaunchMode<0>(p, workgroups, stream);
 }
 
 }  // namespace kd

@@ -17,6 +17,9 @@ LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("KD_HIP_LIB", "libkd_hip.so
 
 INT_MAX = 2**31 - 1
 KD_MEM_HOST, KD_MEM_DEVICE = 0, 1
+KD_DECODE_FINALIZE, KD_DECODE_LATTICE = 1, 2
+CAPACITY_NAMES = ("arena_tokens", "arena_links", "table_slots", "max_frames", "tokens_used",
+                  "links_used", "grow_events", "workgroups")
 STAT_NAMES = ("frames", "tokens_in", "tokens_expanded", "arcs_scanned", "arcs_kept",
               "tokens_out", "eps_arcs_scanned", "eps_expansions", "max_tokens", "spill_frames",
               "links", "small_frames")
@@ -33,7 +36,7 @@ SYMBOLS = (
     "kd_batch_last_kernel_ms", "kd_batch_device_bytes", "kd_batch_phase_cycles",
     "kd_lattice_options_default", "kd_batch_create_lattice", "kd_batch_finalize_decoding",
     "kd_batch_final_relative_cost", "kd_batch_raw_lattice_prepare", "kd_batch_raw_lattice_copy",
-    "kd_batch_create_simple",
+    "kd_batch_create_simple", "kd_batch_decode_async", "kd_batch_capacity",
 )
 
 
@@ -41,7 +44,7 @@ class FasterOptions(C.Structure):
     _fields_ = [("beam", C.c_float), ("max_active", C.c_int32), ("min_active", C.c_int32),
                 ("beam_delta", C.c_float), ("hash_ratio", C.c_float),
                 ("arena_tokens", C.c_int64), ("table_slots", C.c_int32),
-                ("max_frames", C.c_int32)]
+                ("max_frames", C.c_int32), ("no_grow", C.c_int32)]
 
 
 class LatticeOptions(C.Structure):
@@ -49,7 +52,7 @@ class LatticeOptions(C.Structure):
                 ("lattice_beam", C.c_float), ("prune_interval", C.c_int32),
                 ("beam_delta", C.c_float), ("hash_ratio", C.c_float), ("prune_scale", C.c_float),
                 ("arena_tokens", C.c_int64), ("arena_links", C.c_int64),
-                ("table_slots", C.c_int32), ("max_frames", C.c_int32)]
+                ("table_slots", C.c_int32), ("max_frames", C.c_int32), ("no_grow", C.c_int32)]
 
 
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -96,6 +99,9 @@ def lib():
     L.kd_batch_advance_async.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), _i32p, C.c_void_p,
                                          C.c_int32, C.c_int64, C.c_int32]
     L.kd_batch_sync.argtypes = [C.c_void_p]
+    L.kd_batch_decode_async.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), _i32p,
+                                        C.c_void_p, C.c_int32, C.c_int64, C.c_int32]
+    L.kd_batch_capacity.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int64)]
     L.kd_batch_num_frames_decoded.argtypes = [C.c_void_p, _i32p]
     L.kd_batch_status.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.uint32)]
     L.kd_batch_reached_final.argtypes = [C.c_void_p, _i32p]
@@ -282,8 +288,27 @@ class Batch:
         args.append(max_num_frames)
         _check(fn(*args))
 
+    def decode_device(self, dev_ptrs, num_rows, num_cols, row_stride=None, offsets=None,
+                      finalize=True, lattice=True, sync=True):
+        """Decode() of every utterance in one launch (kd_batch_decode_async): InitDecoding,
+        every frame and, for lattice batches, FinalizeDecoding / GetRawLattice as asked."""
+        rows = np.ascontiguousarray(num_rows, np.int32)
+        self.batch = len(rows)
+        off = None if offsets is None else np.ascontiguousarray(offsets, np.int32)
+        want = (KD_DECODE_FINALIZE if finalize else 0) | (KD_DECODE_LATTICE if lattice else 0)
+        _check(lib().kd_batch_decode_async(self.h, self.batch, self._ptrs(list(dev_ptrs)), rows,
+                                           None if off is None else off.ctypes.data, num_cols,
+                                           num_cols if row_stride is None else row_stride, want))
+        if sync:
+            self.sync()
+
     def sync(self):
         _check(lib().kd_batch_sync(self.h))
+
+    def capacity(self):
+        out = np.zeros(8, np.int64)
+        _check(lib().kd_batch_capacity(self.h, out))
+        return dict(zip(CAPACITY_NAMES, out.tolist()))
 
     def num_frames_decoded(self):
         out = np.zeros(self.batch, np.int32)
