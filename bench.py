@@ -3,8 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the hot path over one batch of synthetic utterances whose
-log-prob matrices are already resident in HBM.  Default workload (BASELINE.json
+A step is one pass of the hot path over one batch of B synthetic utterances whose
+log-prob matrices are already resident in HBM.  Steps are handed to the library
+--steps-per-call at a time (kd_batch_decode: ONE kernel launch whose persistent
+workgroups, one per CU, take utterances from a work queue until none is left).  Default workload (BASELINE.json
 configs[2], the configuration the metric is quoted on): LatticeFasterDecoder over
 an HLG-like graph, beam 15, lattice-beam 8, batch 128 per GPU, T = 250 decoder
 frames (10 s of audio at 40 ms/frame): InitDecoding, AdvanceDecoding over all
@@ -19,11 +21,6 @@ import json
 import os
 import sys
 import time
-
-# One hardware queue per stream in flight: the HIP runtime multiplexes streams onto
-# GPU_MAX_HW_QUEUES (default 4) hardware queues, and two batches that share a queue
-# run their kernels one after the other.  Must be set before the runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -193,17 +190,15 @@ def main():
     ap.add_argument("--steps", type=int, default=56)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="hlg-lattice", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch")
+    ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch (utterances per step)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--streams", type=int, default=7,
-                    help="independent batches in flight per GPU (each step is still one batch of "
-                         "B utterances; a batch occupies B of the 256 CUs)")
-    ap.add_argument("--arena-tokens-per-utt", type=int, default=0,
-                    help="token records reserved per utterance (0: the library default, 2^21)")
-    ap.add_argument("--arena-links-per-utt", type=int, default=1 << 22,
-                    help="lattice decoders: forward links reserved per utterance (0: the library "
-                         "default, four per token record = 2^23; this workload keeps 1.05 links per "
-                         "token, and 2^22 lets seven batches of 22 GB share the HBM)")
+    ap.add_argument("--steps-per-call", type=int, default=7,
+                    help="steps (batches of B utterances) handed to the library in one "
+                         "kd_batch_decode call: one kernel launch whose persistent workgroups take "
+                         "all their utterances from one work queue")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="library calls in flight (each on its own stream and host thread), so "
+                         "that one call's read-back overlaps the next one's kernel")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="repeat the K timed steps until the timed region lasts this long")
     ap.add_argument("--search-only", action="store_true",
@@ -219,57 +214,50 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)  # (before any other HIP call of this process)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
     B = args.batch or wl["batch"]
     T, V = wl["frames"], wl["V"]
+    G = max(1, args.steps_per_call)
+    n_fly = max(1, args.inflight)
     t0 = time.time()
     g = synth.hlg_graph(**wl["graph"]) if wl["kind"] == "hlg" else synth.hl_graph(**wl["graph"])
     info = synth.describe(g)
-    # this rank's utterances (weak scaling): every batch in flight decodes its OWN B
-    # utterances -- global ids (rank * n_streams + s) * B + i -- so no two launches walk
+    # this rank's utterances (weak scaling): every call in flight decodes its OWN G * B
+    # utterances -- global ids (rank * n_fly + slot) * G * B + i -- so no two launches walk
     # the same arcs or share log-prob rows in L2 / the Infinity Cache
-    n_streams = max(1, args.streams)
-    from concurrent.futures import ThreadPoolExecutor as _TPE
-    with _TPE(min(32, os.cpu_count() or 1)) as ex:
+    per_slot = G * B
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
         all_lps = list(ex.map(lambda u: synth.make_logprobs(T, V, u, peak=12.0, lexicon=g["lexicon"]),
-                              range(rank * n_streams * B, (rank + 1) * n_streams * B)))
-    lps = all_lps[:B]
-    G = cabi.Graph(g, device=local_rank)
-    devs = [torch.from_numpy(np.stack(all_lps[s * B:(s + 1) * B])).cuda() for s in range(n_streams)]
-    ptrs_of = [[d[i].data_ptr() for i in range(B)] for d in devs]
-    rows = [T] * B
-    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+                              range(rank * n_fly * per_slot, (rank + 1) * n_fly * per_slot)))
+    Gr = cabi.Graph(g, device=local_rank)
+    devs = [torch.from_numpy(np.stack(all_lps[s * per_slot:(s + 1) * per_slot])).cuda()
+            for s in range(n_fly)]
+    ptrs_of = [[d[i].data_ptr() for i in range(per_slot)] for d in devs]
+    streams = [torch.cuda.Stream() for _ in range(n_fly)]
     cls = cabi.LatticeBatch if wl["lattice"] else cabi.Batch
-    cap = {}
-    if args.arena_tokens_per_utt:
-        cap["arena_tokens"] = B * args.arena_tokens_per_utt
-    if args.arena_links_per_utt and wl["lattice"]:
-        cap["arena_links"] = B * args.arena_links_per_utt
-    bts = [cls(G, max_batch=B, max_frames=T, stream=st.cuda_stream, **wl["opts"], **cap)
+    bts = [cls(Gr, max_batch=per_slot, max_frames=T, stream=st.cuda_stream, **wl["opts"])
            for st in streams]
     setup_s = time.time() - t0
 
-    def step(bt, ptrs):
-        bt.init_decoding()
-        bt.advance_device(ptrs, rows, V, sync=False)
-        bt.sync()
-        k_ms = bt.last_kernel_ms()  # HIP events around the search kernel, on its stream
+    def call(slot, n_steps):
+        """One library call: n_steps batches of B utterances, one kernel launch."""
+        bt, n = bts[slot], n_steps * B
+        bt.decode_device(ptrs_of[slot][:n], [T] * n, V, finalize=not args.search_only,
+                         lattice=not args.search_only, sync=True)
+        k_ms = bt.last_kernel_ms()  # HIP events around the launch, on its stream
         if args.search_only:
             return None, k_ms
-        if wl["lattice"]:
-            bt.finalize_decoding()
-            out = bt.raw_lattices()
-        else:
-            out = bt.best_paths()
+        out = bt.raw_lattices() if wl["lattice"] else bt.best_paths()
         return out, k_ms
 
     def deliver(out):
         # the only exchange between ranks: finished results go to rank 0.  Issued by
-        # the main thread in step order so every rank runs its collectives alike.
+        # the main thread in call order so every rank runs its collectives alike.
         if world > 1 and out is not None:
             if wl["lattice"]:
                 sharded.gather_lattices(out, dst=0)
@@ -281,39 +269,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Steps are independent batches; with more than one stream consecutive steps
-    # overlap.  One host thread per stream owns that stream's batch and runs its
-    # steps (i, i + n_streams, ...) strictly in order -- a batch is never shared
-    # between threads; ctypes releases the GIL inside the library.
+    # A run of K steps is ceil(K / G) calls (the last one may be short).  One host thread
+    # per slot owns that slot's batch object and runs its calls (i, i + n_fly, ...) in
+    # order -- a batch is never shared between threads; ctypes releases the GIL inside
+    # the library.
     import queue
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(n_streams)
+    pool = ThreadPoolExecutor(n_fly)
 
-    def lane(si, n, done):
-        for i in range(si, n, n_streams):
+    def lane(slot, sizes, done):
+        for i in range(slot, len(sizes), n_fly):
             try:
-                done[i].put(step(bts[si], ptrs_of[si]))
+                done[i].put(call(slot, sizes[i]))
             except BaseException as e:  # hand the failure to the main thread
                 done[i].put(e)
                 raise
 
     def run_steps(n):
-        done = [queue.Queue(1) for _ in range(n)]
-        futs = [pool.submit(lane, si, n, done) for si in range(min(n_streams, n))]
+        sizes = [G] * (n // G) + ([n % G] if n % G else [])
+        done = [queue.Queue(1) for _ in sizes]
+        futs = [pool.submit(lane, sl, sizes, done) for sl in range(min(n_fly, len(sizes)))]
         res = []
-        for i in range(n):
+        for i in range(len(sizes)):
             r = done[i].get()
             if isinstance(r, BaseException):
                 raise r
-            res.append(r)
+            res.append(r + (sizes[i], i % n_fly))
             deliver(r[0])
         for f in futs:
             f.result()
         return res
 
-    # every stream's batch gets at least two untimed steps when warmup is requested
-    # (first launches fault in the arenas and size the export buffers)
-    run_steps(max(args.warmup, 2 * n_streams if args.warmup else 0))
+    # every slot's batch gets at least one untimed full call when warmup is requested
+    # (first launches fault in the pools and size the read-back buffers)
+    run_steps(max(args.warmup, 2 * n_fly * G if args.warmup else 0))
     fence()
     # The timed region is the K requested steps, repeated until it lasts at least
     # --min-seconds (a 20-step region is 90 ms: too short for any outside clock or
@@ -334,18 +322,21 @@ def main():
     results = run_steps(steps_timed)
     fence()
     elapsed = time.perf_counter() - t_start
-    out = results[-1][0]
-    kernel_ms = [k for _, k in results]
-    last_stream = (steps_timed - 1) % n_streams
-    bt = bts[last_stream]
-    lps = all_lps[last_stream * B:(last_stream + 1) * B]  # what `out` decoded
-    # one batch alone on the GPU, nothing else in flight: what a caller who submits a
-    # single batch of B utterances gets
+    launches = [(k, n) for _, k, n, _ in results]
+    # one more full call (untimed) whose output the CPU leg checks and whose counters
+    # give the algorithmic bytes of a launch
+    n_last = G
+    out, _ = call(0, G)
+    bt = bts[0]
+    lps = all_lps[:per_slot]
+    stats = bt.stats() if not args.search_only else None
+    # one batch of B utterances alone on the GPU, nothing else in flight: what a caller
+    # who submits a single batch gets
     single = []
     for _ in range(5):
         fence()
         t1 = time.perf_counter()
-        _, k1 = step(bts[0], ptrs_of[0])
+        _, k1 = call(0, 1)
         torch.cuda.synchronize()
         single.append(((time.perf_counter() - t1) * 1e3, k1))
     single_batch_ms = float(np.median([a for a, _ in single]))
@@ -357,14 +348,15 @@ def main():
 
     if rank == 0 and args.search_only:
         print(json.dumps({"diagnostic": "search only", "ms_per_step": elapsed / steps_timed * 1e3,
-                          "kernel_ms": float(np.mean(kernel_ms)), "streams": n_streams}))
+                          "launch_ms": float(np.mean([k for k, n in launches if n == G] or [0])),
+                          "steps_per_call": G, "inflight": n_fly}))
     elif rank == 0:
-        stats = bt.stats()  # counters of the last step (reset by InitDecoding)
-        alg_bytes, per_frame = algorithmic_bytes(stats, V)
-        k_ms = float(np.mean(kernel_ms))
+        alg_bytes, per_frame = algorithmic_bytes(stats, V)  # of one full launch (n_last steps)
+        k_ms = float(np.mean([k for k, n in launches if n == n_last] or [k for k, _ in launches]))
         traffic = profiled_traffic(wl["desc"])
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         frames_total = world * B * T * steps_timed
+        cap = bt.capacity()
         res = {
             "metric": "decoded audio frames/sec (whole node), LibriSpeech HLG beam=15; "
                       "1-best WER parity",
@@ -387,24 +379,32 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["desc"], "graph_states": info["states"],
                        "graph_arcs": info["arcs"], "batch_per_gpu": B, "frames": T,
-                       "streams_per_gpu": n_streams,
+                       "steps_per_call": G, "utterances_per_launch": n_last * B,
+                       "calls_in_flight": n_fly, "workgroups_per_launch": cap["workgroups"],
+                       "device_mb_per_call": bt.device_bytes / 2**20,
+                       "device_mb_per_step": bt.device_bytes / 2**20 / G,
+                       "pool_grow_events": cap["grow_events"],
                        "decoder_frames_per_s": frames_total / elapsed, **per_frame},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
-                         "kernel": "SearchKernel", "kernel_ms": k_ms,
+                         "kernel": "SearchKernel<1> (search + FinalizeDecoding + GetRawLattice "
+                                   "of every utterance of the call)" if wl["lattice"]
+                                   else "SearchKernel",
+                         "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         # launches of independent batches overlap (streams_per_gpu of
-                         # them share the CUs), which stretches each one; the device as a
-                         # whole moves this many algorithmic bytes per second of wall time
-                         "device_achieved": alg_bytes * steps_timed / elapsed / 1e9,
-                         "device_frac": alg_bytes * steps_timed / elapsed / 1e9 / HBM_PEAK_GBS},
+                         "utterance_frames_per_launch": n_last * B * T,
+                         # with more than one call in flight the launches share the CUs;
+                         # the device as a whole moves this many algorithmic bytes per
+                         # second of wall time
+                         "device_achieved": alg_bytes / (n_last * B * T) * (B * T * steps_timed) / elapsed / 1e9,
+                         "device_frac": alg_bytes / (n_last * B * T) * (B * T * steps_timed) / elapsed / 1e9 / HBM_PEAK_GBS},
             "setup_s": setup_s,
         }
         if wl["lattice"]:
-            res["config"]["lattice_arcs_per_utt"] = float(np.mean([len(lat.src) for lat in out]))
-            res["config"]["lattice_states_per_utt"] = float(np.mean([lat.num_states for lat in out]))
+            res["config"]["lattice_arcs_per_utt"] = float(np.mean(out.arcs_per_utt))
+            res["config"]["lattice_states_per_utt"] = float(np.mean(out.states_per_utt))
         if not args.no_cpu:
             cb, parity = cpu_baseline(g, lps, wl, out)
             res["cpu_baseline"] = cb

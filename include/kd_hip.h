@@ -281,10 +281,10 @@ int kd_batch_raw_lattice_copy(kd_batch *b, const int64_t *state_off, const int64
                               int32_t *final_state, float *final_graph);
 
 /* Diagnostic builds only (make -C kaldi-decoder_amd prof, -DKD_PROFILE): shader
- * clock cycles lane 0 spent per phase, 20 int64 per utterance (bucket names in
+ * clock cycles lane 0 spent per phase, 24 int64 per utterance (bucket names in
  * tools/prof_phases.py).  The shipping library executes no stamps and returns
  * KD_E_STATE. */
-int kd_batch_phase_cycles(kd_batch *b, int64_t *out /* [batch][20] */);
+int kd_batch_phase_cycles(kd_batch *b, int64_t *out /* [batch][24] */);
 
 /* Device time of the most recent search-kernel launch, from HIP events on the
  * batch's stream (valid after a sync). */

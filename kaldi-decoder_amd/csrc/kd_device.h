@@ -39,8 +39,8 @@ constexpr uint32_t kArcNone = 0xFFFFFFFFu;
 constexpr uint32_t kSrcEps = 0x80000000u;  // back-pointer source is a table slot
 constexpr uint32_t kSrcNone = 0xFFFFFFFFu;
 constexpr unsigned long long kCostDead = 0xFFFFFFFFFFFFFFFFull;
-constexpr int kProfSlots = 20;   // diagnostic cycle buckets (KD_PROFILE builds)
-constexpr int kStatStride = 32;  // KD_NUM_STATS counters + kProfSlots, padded
+constexpr int kProfSlots = 24;   // diagnostic cycle buckets (KD_PROFILE builds)
+constexpr int kStatStride = 40;  // KD_NUM_STATS counters + kProfSlots, padded
 
 // ---- launch control ------------------------------------------------------------
 // One device buffer per batch, laid out  UttCtl[B] | order[B] | BatchCtl | UttOut[B].

@@ -38,6 +38,7 @@ struct TailShared {
   uint32_t best_key, bestwf_key;
   int32_t any_final, changed, count, start_id, empty_frame;
   int32_t n_finals;
+  int32_t n_tok_staged, n_arc_staged, stage_overflow;
   long long out_off;
   // results of the tail, read by the caller (RunUtterance) from here
   int32_t r_sizes[4];
@@ -154,10 +155,45 @@ __device__ __forceinline__ void LatticeFinalCosts(CParams &p, TailShared &s, int
   __syncthreads();
 }
 
+// What survives FinalizeDecoding, noted down by the sweep itself while a frame's extras
+// and links are at hand (in LDS / registers): live tokens as (token index, frame), links
+// as (link index, frame * 2 + emitting).  GetRawLattice then costs what the PRUNED
+// lattice costs -- a thousand arcs -- not another three passes over the hundred thousand
+// tokens and links the search recorded.  The lists live in the workgroup's candidate
+// queue (idle in the tail); a lattice that outgrows them takes the general export.
+struct Stage {
+  KD_G uint32_t *tok_g, *tok_f, *arc_at, *arc_f;
+  int cap;
+  bool on;
+};
+__device__ __forceinline__ Stage TailStage(CParams &p, bool on) {
+  const long long gslots = 1ll << p.g_log2_slots, wg = blockIdx.x;
+  Stage st;
+  st.tok_g = ToG(p.g_log_h) + wg * 2 * gslots;
+  st.tok_f = ToG(p.g_log_arc) + wg * 2 * gslots;
+  st.arc_at = ToG(p.g_log_src) + wg * 2 * gslots;
+  st.arc_f = reinterpret_cast<KD_G uint32_t *>(ToG(p.g_log_nk) + wg * 2 * gslots);
+  st.cap = static_cast<int>(2 * gslots);
+  st.on = on;
+  return st;
+}
+// one list entry per active lane, one LDS atomic per wave
+__device__ __forceinline__ void StageTok(TailShared &s, const Stage &st, long long g, int f) {
+  const int pos = AggInc(&s.n_tok_staged);
+  if (pos < st.cap) { st.tok_g[pos] = static_cast<uint32_t>(g); st.tok_f[pos] = static_cast<uint32_t>(f); }
+  else s.stage_overflow = 1;
+}
+__device__ __forceinline__ void StageArc(TailShared &s, const Stage &st, long long at, int f, int emitting) {
+  const int pos = AggInc(&s.n_arc_staged);
+  if (pos < st.cap) { st.arc_at[pos] = static_cast<uint32_t>(at); st.arc_f[pos] = static_cast<uint32_t>(2 * f + emitting); }
+  else s.stage_overflow = 1;
+}
+
 // FinalizeDecoding: the exact backward sweep over all frames.
 __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt, int F,
-                                             float final_best_cost, bool any_final) {
+                                             float final_best_cost, bool any_final, const Stage &st) {
   const int tid = threadIdx.x;
+  if (tid == 0) { s.n_tok_staged = 0; s.n_arc_staged = 0; s.stage_overflow = 0; s.empty_frame = 0; }
   const long long fb = static_cast<long long>(utt) * (p.max_frames + 1);
   const float lattice_beam = p.lat.lattice_beam;
   const uint32_t *next_b = nullptr;  // the next frame's final extras, while they are in LDS
@@ -174,10 +210,44 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
     d.pn = ToG(p.link_eps_count)[fb + f];
     return d;
   };
-  Desc ahead = describe(F);
+  // The link records an LDS-resident frame starts from: this lane's epsilon links
+  // (source, destination, the cost difference of :257-260) and its first emitting link.
+  // They are requested one frame early -- while frame f iterates to its fixpoint the
+  // records of frame f - 1 are already on their way (nothing frame f does changes them),
+  // so a frame no longer begins with an exposed memory round trip; the descriptors
+  // that say where those records are come two frames ahead for the same reason.
+  // (Every lane issues every load -- a lane without a link reads the pool's first
+  // record -- so they are in flight together; loads behind `if (i < pn)` complete one
+  // after the other.)
+  struct Pre {
+    int e_dst[kEpsRegs], e_src[kEpsRegs];
+    float e_delta[kEpsRegs];
+    int m_dst0, m_src0;
+    float m_delta0;
+  };
+  auto fits_lds = [&](const Desc &d) { return 3 * d.n <= kLdsToks / 2 && d.pn <= kEpsRegs * kBlock; };
+  auto fetch = [&](const Desc &d, Pre &r) {
+#pragma unroll
+    for (int k = 0; k < kEpsRegs; ++k) {
+      const int i = tid + k * kBlock;
+      const long long at = i < d.pn ? d.pb + i : 0;
+      r.e_dst[k] = ToG(p.link_dst)[at];
+      r.e_src[k] = ToG(p.link_src)[at];
+      r.e_delta[k] = ToG(p.link_delta)[at];
+    }
+    const long long at0 = tid < d.en ? d.eb + tid : 0;
+    r.m_dst0 = ToG(p.link_dst)[at0];
+    r.m_src0 = ToG(p.link_src)[at0];
+    r.m_delta0 = ToG(p.link_delta)[at0];
+  };
+  Desc ahead = describe(F), ahead2 = F > 0 ? describe(F - 1) : ahead;
+  Pre pre;
+  bool have_pre = false;
+  if (fits_lds(ahead)) { fetch(ahead, pre); have_pre = true; }
   for (int f = F; f >= 0; --f) {
     const Desc d = ahead;
-    if (f > 0) ahead = describe(f - 1);
+    ahead = ahead2;
+    if (f > 1) ahead2 = describe(f - 2);
     const long long base = d.base;
     const int n = d.n;
     const bool last = f == F;
@@ -205,24 +275,21 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
         A[i] = k;
         B[i] = FloatKey(0.0f);  // tok_extra as the search left it
       }
-      // this lane's epsilon links: source, destination (frame-relative) and the
-      // cost difference of :257-260
-      // (every lane issues every load -- a lane without a link reads the pool's first
-      // record -- so the epsilon links and the first round of emitting links are in
-      // flight together; loads behind `if (i < pn)` complete one after the other)
+      // this frame's link records (requested a frame ago) ...
+      if (!have_pre) fetch(d, pre);
       int e_src[kEpsRegs], e_dst[kEpsRegs];
       float e_delta[kEpsRegs];
 #pragma unroll
       for (int r = 0; r < kEpsRegs; ++r) {
-        const int i = tid + r * kBlock;
-        const long long at = i < pn ? pb + i : 0;
-        e_dst[r] = ToG(p.link_dst)[at];
-        e_src[r] = ToG(p.link_src)[at];
-        e_delta[r] = ToG(p.link_delta)[at];
+        e_dst[r] = pre.e_dst[r];
+        e_src[r] = pre.e_src[r];
+        e_delta[r] = pre.e_delta[r];
       }
-      const long long at0 = tid < en ? eb + tid : 0;
-      const int32_t m_dst0 = ToG(p.link_dst)[at0], m_src0 = ToG(p.link_src)[at0];
-      const float m_delta0 = ToG(p.link_delta)[at0];
+      const int32_t m_dst0 = pre.m_dst0, m_src0 = pre.m_src0;
+      const float m_delta0 = pre.m_delta0;
+      // ... and the request for the next frame's (f - 1)
+      have_pre = f > 0 && fits_lds(ahead);
+      if (have_pre) fetch(ahead, pre);
 #pragma unroll
       for (int r = 0; r < kEpsRegs; ++r) {
         const int i = tid + r * kBlock;
@@ -252,6 +319,7 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
         }
         if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
         atomicMin(&A[src - base], FloatKey(link_extra_cost));
+        if (st.on) StageArc(s, st, at, f, 1);
       }
       LdsBarrier();
       while (true) {
@@ -285,7 +353,17 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
         // without epsilon links nothing in this frame depends on this frame
         if (!changed || pn == 0) break;
       }
-      for (int i = tid; i < n; i += kBlock) ToG(p.tok_extra)[base + i] = KeyFloat(B[i]);
+      for (int i = tid; i < n; i += kBlock) {
+        const float ex = KeyFloat(B[i]);
+        ToG(p.tok_extra)[base + i] = ex;
+        if (st.on && ex != FInf()) StageTok(s, st, base + i, f);
+      }
+      if (st.on) {
+#pragma unroll
+        for (int r = 0; r < kEpsRegs; ++r)
+          if (e_src[r] >= 0) StageArc(s, st, pb + tid + r * kBlock, f, 0);
+        if (n == 0 && tid == 0) s.empty_frame = 1;
+      }
       next_b = B;
       next_base = base;
       // (a later frame that reads these extras from global memory -- the path below --
@@ -294,6 +372,7 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
       continue;
     }
     next_b = nullptr;  // this frame's extras go to global memory only
+    have_pre = false;  // (a prefetch made for this frame is dropped: it takes the path below)
     const bool ne_in_lds = n <= kLdsToks;
     KD_G uint32_t *gne = ToG(p.lat.scratch) + base;  // (the frame's own slice of the pool-wide scratch)
     while (true) {
@@ -343,8 +422,89 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
       // without epsilon links nothing in this frame depends on this frame
       if (!changed || pn == 0) break;
     }
+    if (st.on) {  // (a frame of thousands of tokens: read back what the loop above left)
+      for (int i = tid; i < n; i += kBlock)
+        if (ToG(p.tok_extra)[base + i] != FInf()) StageTok(s, st, base + i, f);
+      for (int i = tid; i < en; i += kBlock)
+        if (ToG(p.link_dst)[eb + i] >= 0) StageArc(s, st, eb + i, f, 1);
+      for (int i = tid; i < pn; i += kBlock)
+        if (ToG(p.link_dst)[pb + i] >= 0) StageArc(s, st, pb + i, f, 0);
+      if (n == 0 && tid == 0) s.empty_frame = 1;
+    }
   }
   __syncthreads();
+}
+
+// GetRawLattice from the lists FinalizeDecoding left (Stage): states are numbered
+// frame-major (the sweep ran backwards, so list position j becomes id ns - 1 - j).
+__device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &s, int utt, int F,
+                                                        bool any_final, const Stage &st) {
+  const int tid = threadIdx.x;
+  const int ns = s.n_tok_staged, na = s.n_arc_staged;
+  if (s.empty_frame || ns == 0) return 0;  // GetRawLattice returns false (:615-619)
+  if (tid == 0) { s.n_finals = 0; s.start_id = -1; }
+  __syncthreads();
+  // the last frame's tokens were listed first: count the final ones (:645-652)
+  for (int j = tid; j < ns; j += kBlock) {
+    if (static_cast<int>(st.tok_f[j]) != F) break;  // (positions are frame-descending per lane)
+    const float fc = ToG(p.states)[ToG(p.tok_state)[st.tok_g[j]]].final_cost;
+    if (!any_final || fc != FInf()) AggAdd1(&s.n_finals);
+  }
+  __syncthreads();
+  const int nf = s.n_finals;
+  if (tid == 0) {
+    const unsigned long long words = static_cast<unsigned long long>(ns) + nf + 3ull * na;
+    const unsigned long long b = atomicAdd(&p.ctl->out_top, words);
+    if (b + words > p.lat.out_cap) {
+      atomicAdd(&p.ctl->out_top, 0ull - words);
+      s.out_off = -1;
+    } else {
+      s.out_off = static_cast<long long>(b);
+    }
+    s.count = 0;  // (finals written so far)
+  }
+  __syncthreads();
+  const long long off = s.out_off;
+  if (off < 0) return KD_UTT_OUT_FULL;
+  KD_G unsigned long long *o_state = ToG(p.lat.out) + off, *o_final = o_state + ns,
+                          *o_arc = o_final + nf;
+  auto pack = [](uint32_t lo, uint32_t hi) { return static_cast<unsigned long long>(hi) << 32 | lo; };
+  for (int j = tid; j < ns; j += kBlock) {
+    const uint32_t g = st.tok_g[j];
+    const int f = static_cast<int>(st.tok_f[j]);
+    const int id = ns - 1 - j;
+    const int32_t state = ToG(p.tok_state)[g];
+    ToG(p.lat.tok_newid)[g] = id;
+    o_state[id] = pack(static_cast<uint32_t>(f), static_cast<uint32_t>(state));
+    if (f == 0 && state == p.start) s.start_id = id;  // :623-629
+    if (f == F) {
+      const float fc = ToG(p.states)[state].final_cost;
+      if (!any_final || fc != FInf()) {
+        const int k = AggInc(&s.count);
+        o_final[k] = pack(static_cast<uint32_t>(id), __float_as_uint(any_final ? fc : 0.0f));
+      }
+    }
+  }
+  __syncthreads();  // every listed token's id is in place
+  for (int j = tid; j < na; j += kBlock) {
+    const long long at = st.arc_at[j];
+    const int32_t src = ToG(p.link_src)[at], dst = ToG(p.link_dst)[at], arc = ToG(p.link_arc)[at];
+    const float gr = ToG(p.link_graph)[at], ac = ToG(p.link_ac)[at];
+    const ArcRec ar = LoadArcRec(p.arcs, static_cast<uint32_t>(arc));
+    KD_G unsigned long long *w = o_arc + 3ll * j;
+    w[0] = pack(static_cast<uint32_t>(ToG(p.lat.tok_newid)[src]), static_cast<uint32_t>(ToG(p.lat.tok_newid)[dst]));
+    w[1] = pack(static_cast<uint32_t>(ar.ilabel), static_cast<uint32_t>(ar.olabel));
+    w[2] = pack(__float_as_uint(gr), __float_as_uint(ac));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    s.r_sizes[0] = ns;
+    s.r_sizes[1] = na;
+    s.r_sizes[2] = nf;
+    s.r_sizes[3] = s.start_id;
+    s.r_out_off = off;
+  }
+  return 0;
 }
 
 // GetRawLattice (:584-657).  Frames do not depend on one another here, so the waves of
@@ -533,6 +693,19 @@ __device__ __noinline__ uint32_t LatticeTail(CParams *pp, int utt, int F, uint32
     s.r_sizes[0] = 0; s.r_sizes[1] = 0; s.r_sizes[2] = 0; s.r_sizes[3] = -1;
     s.r_out_off = -1;
   }
+#ifdef KD_PROFILE
+  // diagnostic build: cycles of the tail's three parts, buckets 20-22 of the utterance
+  long long lap = static_cast<long long>(__builtin_amdgcn_s_memtime());
+  auto tail_lap = [&](int bucket) {
+    if (threadIdx.x == 0) {
+      const long long now = static_cast<long long>(__builtin_amdgcn_s_memtime());
+      ToG(p.stats)[static_cast<long long>(utt) * kStatStride + KD_NUM_STATS + bucket] += now - lap;
+      lap = now;
+    }
+  };
+#else
+  auto tail_lap = [](int) {};
+#endif
   const bool was_finalized = Uni(ToG(p.lat.finalized)[utt]) != 0;
   float final_best_cost = 0.0f, final_rel = 0.0f;
   bool any_final = false;
@@ -549,13 +722,22 @@ __device__ __noinline__ uint32_t LatticeTail(CParams *pp, int utt, int F, uint32
     final_rel = ToG(p.lat.final_rel)[utt];
   }
   if (threadIdx.x == 0) s.r_final_rel = final_rel;
-  bool finalized = was_finalized;
+  tail_lap(20);
+  bool finalized = was_finalized, staged = false;
+  // (Decode(): FinalizeDecoding and GetRawLattice(use_final_probs = true) in one tail)
+  const Stage st = TailStage(p, (flags & kUttFinalize) && (flags & kUttExport) && !was_finalized && F >= 1);
   if ((flags & kUttFinalize) && !was_finalized) {
-    LatticePrune(p, s, utt, F, final_best_cost, any_final);
+    LatticePrune(p, s, utt, F, final_best_cost, any_final, st);
     if (threadIdx.x == 0) ToG(p.lat.finalized)[utt] = 1;
     finalized = true;
+    staged = st.on && !s.stage_overflow;
+    tail_lap(21);
   }
-  if (flags & (kUttExport | kUttExportNoFinal))
-    return LatticeExport(p, s, utt, F, (flags & kUttExport) != 0, finalized, any_final);
-  return 0;
+  uint32_t r = 0;
+  if (flags & (kUttExport | kUttExportNoFinal)) {
+    if (staged) r = LatticeExportStaged(p, s, utt, F, any_final, st);
+    else r = LatticeExport(p, s, utt, F, (flags & kUttExport) != 0, finalized, any_final);
+    tail_lap(22);
+  }
+  return r;
 }

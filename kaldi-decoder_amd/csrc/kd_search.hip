@@ -2389,7 +2389,9 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   ud.target = Uni(ToG(p.utt)[utt].target);
   ud.flags = Uni(ToG(p.utt)[utt].flags);
   const bool do_init = (ud.flags & kUttInit) != 0;
-  uint32_t err = do_init ? 0u : Uni(ToG(p.status)[utt]);
+  // (an utterance that stopped for want of capacity is only sent back here after the
+  // host has grown what was exhausted: the status word is output, not state)
+  uint32_t err = 0u;
   int frame = do_init ? -1 : Uni(ToG(p.frames_decoded)[utt]);
   const int target = ud.target;
   const bool search = err == 0 && frame < target;  // (otherwise only the tail has work)

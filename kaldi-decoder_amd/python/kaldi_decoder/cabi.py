@@ -361,7 +361,7 @@ class Batch:
         return out
 
     def phase_cycles(self):
-        out = np.zeros((self.batch, 20), np.int64)
+        out = np.zeros((self.batch, 24), np.int64)
         _check(lib().kd_batch_phase_cycles(self.h, out))
         return out
 
@@ -397,28 +397,60 @@ class LatticeBatch(Batch):
         return out
 
     def raw_lattices(self, use_final_probs=True):
+        """GetRawLattice of every utterance: a sequence of RawLattice (built on access --
+        a call that decodes a thousand utterances hands back two dozen arrays, not
+        thirteen thousand views)."""
         sizes = np.zeros(4 * self.batch, np.int32)
         _check(lib().kd_batch_raw_lattice_prepare(self.h, int(use_final_probs), sizes))
         sz = sizes.reshape(self.batch, 4).astype(np.int64)
-        so, ao, fo = (np.zeros(self.batch, np.int64) for _ in range(3))
-        so[1:], ao[1:], fo[1:] = np.cumsum(sz[:-1, 0]), np.cumsum(sz[:-1, 1]), np.cumsum(sz[:-1, 2])
-        ns, na, nf = (max(int(sz[:, k].sum()), 1) for k in range(3))
+        so, ao, fo = (np.zeros(self.batch + 1, np.int64) for _ in range(3))
+        so[1:], ao[1:], fo[1:] = np.cumsum(sz[:, 0]), np.cumsum(sz[:, 1]), np.cumsum(sz[:, 2])
+        ns, na, nf = max(int(so[-1]), 1), max(int(ao[-1]), 1), max(int(fo[-1]), 1)
         src, dst, il, ol = (np.empty(na, np.int32) for _ in range(4))
         gc, ac = np.empty(na, np.float32), np.empty(na, np.float32)
         sf, sg = np.empty(ns, np.int32), np.empty(ns, np.int32)
         fs, fg = np.empty(nf, np.int32), np.empty(nf, np.float32)
-        _check(lib().kd_batch_raw_lattice_copy(self.h, so, ao, fo, src, dst, il, ol, gc, ac, sf,
+        _check(lib().kd_batch_raw_lattice_copy(self.h, so[:-1].copy(), ao[:-1].copy(),
+                                               fo[:-1].copy(), src, dst, il, ol, gc, ac, sf,
                                                sg, fs, fg))
-        out = []
-        for i in range(self.batch):
-            a, b = int(ao[i]), int(ao[i] + sz[i, 1])
-            s0, s1 = int(so[i]), int(so[i] + sz[i, 0])
-            f0, f1 = int(fo[i]), int(fo[i] + sz[i, 2])
-            # (views into the batch's arrays: one allocation per field, not per utterance)
-            out.append(RawLattice(bool(sz[i, 0] > 0), int(sz[i, 0]), int(sz[i, 3]),
-                                  src[a:b], dst[a:b], il[a:b], ol[a:b], gc[a:b], ac[a:b],
-                                  sf[s0:s1], sg[s0:s1], fs[f0:f1], fg[f0:f1]))
-        return out
+        return RawLattices(sz, so, ao, fo, (src, dst, il, ol, gc, ac), (sf, sg), (fs, fg))
+
+
+class RawLattices:
+    """The raw lattices of a batch: batch-wide arrays plus per-utterance offsets; item i
+    is a RawLattice of views into them."""
+
+    def __init__(self, sizes, state_off, arc_off, final_off, arc_arrays, state_arrays, final_arrays):
+        self.sizes, self.state_off, self.arc_off, self.final_off = sizes, state_off, arc_off, final_off
+        self.arc_arrays, self.state_arrays, self.final_arrays = arc_arrays, state_arrays, final_arrays
+
+    def __len__(self):
+        return len(self.sizes)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        a, b = int(self.arc_off[i]), int(self.arc_off[i + 1])
+        s0, s1 = int(self.state_off[i]), int(self.state_off[i + 1])
+        f0, f1 = int(self.final_off[i]), int(self.final_off[i + 1])
+        return RawLattice(bool(self.sizes[i, 0] > 0), int(self.sizes[i, 0]), int(self.sizes[i, 3]),
+                          *(x[a:b] for x in self.arc_arrays), *(x[s0:s1] for x in self.state_arrays),
+                          *(x[f0:f1] for x in self.final_arrays))
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    @property
+    def arcs_per_utt(self):
+        return self.sizes[:, 1]
+
+    @property
+    def states_per_utt(self):
+        return self.sizes[:, 0]
 
 
 class SimpleBatch(Batch):

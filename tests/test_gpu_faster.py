@@ -285,3 +285,24 @@ def test_candidate_queue_overflow_rescans_under_the_final_cutoff(oracle):
         so, co = dd.tokens()
         assert s.tolist() == so.tolist() and c.tolist() == co.tolist(), f
     _assert_same_path(bt.best_paths()[0], d.get_best_path(), "rescan")
+
+
+def test_one_call_decode_and_growing_pools_faster_decoder(oracle):
+    """FasterDecoder::Decode as one launch over a work queue, from a token pool that is much
+    too small to begin with; a vocabulary mismatch between graph and matrix is refused."""
+    import torch
+    g = synth.hlg_graph(V=40, n_words=200, n_hist=200, avg_succ=8, seed=4)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, V = 7, 40
+    lps = [synth.make_logprobs(30 + 9 * i, V, 50 + i, peak=5.0, lexicon=g["lexicon"]) for i in range(B)]
+    dev = [torch.from_numpy(lp).cuda() for lp in lps]
+    bt = cabi.Batch(G, max_batch=B, beam=9.0, arena_tokens=2048, max_frames=4)
+    bt.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V)
+    assert bt.capacity()["grow_events"] > 0
+    paths = bt.best_paths()
+    for i in range(B):
+        d = oracle.FasterDecoder(OG, beam=9.0, policy=1)
+        d.decode(lps[i])
+        _assert_same_path(paths[i], d.get_best_path(), i)
+    with pytest.raises(RuntimeError, match="largest ilabel"):
+        bt.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V - 1, row_stride=V)

@@ -158,3 +158,92 @@ def test_bench_size_workload_matches_canonical_oracle(oracle):
         has_in[gl.dst] = True
         has_in[gl.start] = True
         assert has_in.all()
+
+
+def _assert_same_lattice(gl, cl, tag):
+    assert gl.ok == cl.ok, tag
+    assert gl.num_states == cl.num_states, tag
+    assert gl.state_set() == cl.state_set(), tag
+    assert gl.arc_set() == cl.arc_set(), tag
+    assert len(gl.src) == len(cl.src), tag
+    assert gl.final_set() == cl.final_set(), tag
+    assert np.all(np.diff(gl.state_frame) >= 0), tag  # frame-major numbering
+
+
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+def test_one_call_decode_matches_oracle_and_stepwise_path(oracle, case):
+    """kd_batch_decode_async: InitDecoding + every frame + FinalizeDecoding + GetRawLattice in
+    one launch (the workgroup that decoded an utterance prunes and exports it from the lists
+    the backward sweep leaves) against the canonical oracle and against the call-by-call
+    path; more utterances than the launch has workgroups would need > 256, so the work
+    queue is exercised with ragged lengths and a batch object reused for a second call."""
+    import torch
+    name, g, lex, V, opts = case
+    B, T = 5, 50
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lps = [synth.make_logprobs(T - 7 * i, V, 10 + i, peak=5.0, lexicon=lex) for i in range(B)]
+    dev = [torch.from_numpy(lp).cuda() for lp in lps]
+    lb = cabi.LatticeBatch(G, max_batch=B, **opts)
+    for rep in range(2):
+        order = list(range(B)) if rep == 0 else list(reversed(range(B)))
+        lb.decode_device([dev[i].data_ptr() for i in order], [lps[i].shape[0] for i in order], V)
+        assert lb.num_frames_decoded().tolist() == [lps[i].shape[0] for i in order]
+        lats = lb.raw_lattices()
+        frc = lb.final_relative_cost()
+        step = cabi.LatticeBatch(G, max_batch=B, **opts)
+        step.init_decoding(B)
+        step.advance_host([lps[i] for i in order])
+        step.finalize_decoding()
+        slats = step.raw_lattices()
+        for k, i in enumerate(order):
+            can = oracle.CanonLatticeDecoder(OG, **opts)
+            can.decode(lps[i])
+            _assert_same_lattice(lats[k], can.get_raw_lattice(), (name, rep, i))
+            _assert_same_lattice(lats[k], slats[k], (name, rep, i, "stepwise"))
+            assert frc[k] == can.final_relative_cost()
+        # after Decode() the reference refuses use_final_probs = false (:594-597)
+        with pytest.raises(RuntimeError, match="FinalizeDecoding"):
+            lb.raw_lattices(use_final_probs=False)
+    # Decode() without the export, then GetRawLattice as a call of its own (general export)
+    lb.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V, lattice=False)
+    for i, lat in enumerate(lb.raw_lattices()):
+        can = oracle.CanonLatticeDecoder(OG, **opts)
+        can.decode(lps[i])
+        _assert_same_lattice(lat, can.get_raw_lattice(), (name, "separate export", i))
+
+
+def test_pools_and_tables_grow_on_demand(oracle):
+    """Capacities are starting sizes: a token pool, link pool, output pool, spill table and
+    frame index that are all far too small for the decode grow, the search resumes from the
+    last committed frame, and the lattices are those of a batch that never ran short."""
+    import torch
+    g = synth.hlg_graph(V=40, n_words=300, n_hist=300, avg_succ=8, seed=12)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T, V = 6, 90, 40
+    opts = dict(beam=11.0, lattice_beam=6.0, min_active=0)
+    lps = [synth.make_logprobs(T, V, 30 + i, peak=4.0, lexicon=g["lexicon"]) for i in range(B)]
+    dev = [torch.from_numpy(lp).cuda() for lp in lps]
+    small = cabi.LatticeBatch(G, max_batch=B, arena_tokens=4096, arena_links=4096, table_slots=1 << 14,
+                              max_frames=16, **opts)
+    cap0 = small.capacity()
+    small.decode_device([d.data_ptr() for d in dev], [T] * B, V)
+    cap1 = small.capacity()
+    assert cap1["grow_events"] > 0 and cap1["arena_tokens"] > cap0["arena_tokens"]
+    assert cap1["arena_links"] > cap0["arena_links"] and cap1["max_frames"] >= T
+    lats = small.raw_lattices()
+    for i in range(B):
+        can = oracle.CanonLatticeDecoder(OG, **opts)
+        can.decode(lps[i])
+        _assert_same_lattice(lats[i], can.get_raw_lattice(), i)
+    # streaming in chunks through the same small batch object (grows the frame index again)
+    small2 = cabi.LatticeBatch(G, max_batch=B, arena_tokens=4096, arena_links=4096, max_frames=8, **opts)
+    small2.init_decoding(B)
+    for t0 in range(0, T, 13):
+        small2.advance_host(lps, max_num_frames=13)
+    small2.finalize_decoding()
+    for i, lat in enumerate(small2.raw_lattices()):
+        _assert_same_lattice(lat, lats[i], ("chunks", i))
+    # no_grow restores the hard limits, naming the knob
+    fixed = cabi.LatticeBatch(G, max_batch=B, arena_tokens=4096, arena_links=4096, no_grow=1, **opts)
+    with pytest.raises(RuntimeError, match="pool full"):
+        fixed.decode_device([d.data_ptr() for d in dev], [T] * B, V)

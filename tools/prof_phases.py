@@ -23,7 +23,8 @@ NAMES = ['0 frame start/ll row', '1 GetCutoff', '2 prepass', '3 emit filter: ite
          '8 eps filter: big loop', '9 eps insert', '10 resolve R1 + alloc', '11 C1 write tokens',
          '12 stats fold + barrier', '13 clear/loop', '14 spill-mode frames', '15 aborted LDS attempts',
          '16 R2 back-pointers', '17 link records', '18 best token + frame index',
-         '19 small (LDS-resident) frames']
+         '19 small (LDS-resident) frames', '20 tail: final costs', '21 tail: FinalizeDecoding',
+         '22 tail: GetRawLattice', '23 -']
 
 
 def run(kind, B=None):
@@ -37,8 +38,7 @@ def run(kind, B=None):
     cls = cabi.LatticeBatch if wl["lattice"] else cabi.Batch
     bt = cls(G, max_batch=B, max_frames=T, **wl["opts"])
     for _ in range(2):
-        bt.init_decoding()
-        bt.advance_device([dev[i].data_ptr() for i in range(B)], [T] * B, V)
+        bt.decode_device([dev[i].data_ptr() for i in range(B)], [T] * B, V)
     cyc, st = bt.phase_cycles(), bt.stats()
     tot = cyc.sum(0)
     allc = tot.sum()
