@@ -192,14 +192,15 @@ def main():
     ap.add_argument("--workload", default="hlg-lattice", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch (utterances per step)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--steps-per-call", type=int, default=7,
+    ap.add_argument("--steps-per-call", type=int, default=4,
                     help="steps (batches of B utterances) handed to the library in one "
                          "kd_batch_decode call: one kernel launch whose persistent workgroups take "
                          "all their utterances from one work queue")
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="library calls in flight (each on its own stream and host thread), so "
-                         "that one call's read-back overlaps the next one's kernel")
-    ap.add_argument("--min-seconds", type=float, default=2.0,
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="library calls in flight, each on a batch object and stream of its own; "
+                         "one host thread enqueues them (the decode call is asynchronous) and "
+                         "collects them in order")
+    ap.add_argument("--min-seconds", type=float, default=2.5,
                     help="repeat the K timed steps until the timed region lasts this long")
     ap.add_argument("--search-only", action="store_true",
                     help="diagnostic: time InitDecoding + AdvanceDecoding only (not a bench line)")
@@ -244,20 +245,30 @@ def main():
            for st in streams]
     setup_s = time.time() - t0
 
-    def call(slot, n_steps):
-        """One library call: n_steps batches of B utterances, one kernel launch."""
-        bt, n = bts[slot], n_steps * B
-        bt.decode_device(ptrs_of[slot][:n], [T] * n, V, finalize=not args.search_only,
-                         lattice=not args.search_only, sync=True)
+    def enqueue(slot, n_steps):
+        """One library call: n_steps batches of B utterances, one kernel launch; returns at
+        once (kd_batch_decode_async)."""
+        n = n_steps * B
+        bts[slot].decode_device(ptrs_of[slot][:n], [T] * n, V, finalize=not args.search_only,
+                                lattice=not args.search_only, sync=False)
+
+    def collect(slot):
+        """Waits for the slot's call and takes its results to the host."""
+        bt = bts[slot]
+        bt.sync()
         k_ms = bt.last_kernel_ms()  # HIP events around the launch, on its stream
         if args.search_only:
             return None, k_ms
         out = bt.raw_lattices() if wl["lattice"] else bt.best_paths()
         return out, k_ms
 
+    def call(slot, n_steps):
+        enqueue(slot, n_steps)
+        return collect(slot)
+
     def deliver(out):
-        # the only exchange between ranks: finished results go to rank 0.  Issued by
-        # the main thread in call order so every rank runs its collectives alike.
+        # the only exchange between ranks: finished results go to rank 0, in call order so
+        # every rank runs its collectives alike
         if world > 1 and out is not None:
             if wl["lattice"]:
                 sharded.gather_lattices(out, dst=0)
@@ -269,34 +280,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # A run of K steps is ceil(K / G) calls (the last one may be short).  One host thread
-    # per slot owns that slot's batch object and runs its calls (i, i + n_fly, ...) in
-    # order -- a batch is never shared between threads; ctypes releases the GIL inside
-    # the library.
-    import queue
-    pool = ThreadPoolExecutor(n_fly)
-
-    def lane(slot, sizes, done):
-        for i in range(slot, len(sizes), n_fly):
-            try:
-                done[i].put(call(slot, sizes[i]))
-            except BaseException as e:  # hand the failure to the main thread
-                done[i].put(e)
-                raise
-
+    # A run of K steps is ceil(K / G) calls (the last one may be short), kept n_fly deep in
+    # flight by ONE host thread: the library's decode call only enqueues, so the thread
+    # hands over call i + n_fly before it waits for call i -- while it copies one call's
+    # lattices out, the workgroups of the next calls keep every CU busy (a launch's
+    # workgroups leave as its work queue runs dry and the next launch's take their CUs).
     def run_steps(n):
         sizes = [G] * (n // G) + ([n % G] if n % G else [])
-        done = [queue.Queue(1) for _ in sizes]
-        futs = [pool.submit(lane, sl, sizes, done) for sl in range(min(n_fly, len(sizes)))]
         res = []
+        for i in range(min(n_fly, len(sizes))):
+            enqueue(i % n_fly, sizes[i])
         for i in range(len(sizes)):
-            r = done[i].get()
-            if isinstance(r, BaseException):
-                raise r
+            r = collect(i % n_fly)
+            if i + n_fly < len(sizes):
+                enqueue(i % n_fly, sizes[i + n_fly])
             res.append(r + (sizes[i], i % n_fly))
             deliver(r[0])
-        for f in futs:
-            f.result()
         return res
 
     # every slot's batch gets at least one untimed full call when warmup is requested
@@ -330,6 +329,13 @@ def main():
     bt = bts[0]
     lps = all_lps[:per_slot]
     stats = bt.stats() if not args.search_only else None
+    # a full call alone on the GPU (no other launch sharing the CUs): what the launch's
+    # own duration is when nothing stretches it
+    alone_ms = []
+    for _ in range(3):
+        fence()
+        alone_ms.append(call(0, G)[1])
+    alone_ms = float(np.median(alone_ms))
     # one batch of B utterances alone on the GPU, nothing else in flight: what a caller
     # who submits a single batch gets
     single = []
@@ -394,6 +400,12 @@ def main():
                                    else "SearchKernel",
                          "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         # the same launch with nothing else in flight (the timed region
+                         # keeps `calls_in_flight` launches on the GPU, which share the CUs
+                         # and stretch one another)
+                         "launch_alone": {"kernel_ms": alone_ms,
+                                          "achieved": alg_bytes / (alone_ms * 1e-3) / 1e9,
+                                          "frac": alg_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          "utterance_frames_per_launch": n_last * B * T,
                          # with more than one call in flight the launches share the CUs;
                          # the device as a whole moves this many algorithmic bytes per
