@@ -38,6 +38,14 @@ WORKLOADS = {
                         batch=128, frames=250, V=500,
                         desc="LatticeFasterDecoder over synthetic LibriSpeech-like HLG (bigram G, "
                              "20k words, V=500), beam=15, lattice_beam=8, B=128/GPU, T=250"),
+    # BASELINE configs[4] on one GPU: the same generator at 200 k words -- 52.8 M states,
+    # 141 M arcs = 2.26 GB of 16-byte arc records (stresses HBM: the graph is nine times the
+    # Infinity Cache), beam 17
+    "hlg-large": dict(kind="hlg", graph=dict(V=500, n_words=200000, n_hist=200000, avg_succ=50, seed=2),
+                      lattice=True, opts=dict(beam=17.0, lattice_beam=8.0, min_active=0),
+                      batch=128, frames=250, V=500,
+                      desc="LatticeFasterDecoder over synthetic large-LM HLG (bigram G, 200k words, "
+                           "141M arcs = 2.26 GB, V=500), beam=17, lattice_beam=8, B=128/GPU, T=250"),
     "hlg-1best": dict(kind="hlg", graph=HLG, lattice=False, opts=dict(beam=15.0),
                       batch=128, frames=250, V=500,
                       desc="FasterDecoder 1-best over synthetic LibriSpeech-like HLG "

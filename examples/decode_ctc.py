@@ -23,30 +23,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "kaldi-decoder_amd", "python"))
 import kaldi_decoder as kd  # noqa: E402
 from kaldi_decoder import synth  # noqa: E402
+from kaldi_decoder.scoring import ctc_collapse, edit_distance  # noqa: E402
 
 
-def edit_distance(a, b):
-    d = np.arange(len(b) + 1)
-    for i, x in enumerate(a, 1):
-        prev, d[0] = d[0], i
-        for j, y in enumerate(b, 1):
-            prev, d[j] = d[j], min(d[j] + 1, d[j - 1] + 1, prev + (x != y))
-    return int(d[len(b)])
-
-
-def ctc_collapse(ilabels):
-    """H graph: token id = ilabel - 1; collapse repeats, drop blank (token 0)."""
-    toks = [i - 1 for i in ilabels if i > 0]
-    out = []
-    for k, t in enumerate(toks):
-        if t != 0 and (k == 0 or t != toks[k - 1]):
-            out.append(t)
-    return out
-
-
-def main():
-    kind = sys.argv[1] if len(sys.argv) > 1 else "HLG"
-    n_utts = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+def main(kind=None, n_utts=None, graph_path=None):
+    """Returns (WER, utterances on which the lattice decoder's best path equals the 1-best
+    decoder's).  With `graph_path` the graph goes through an OpenFst binary file, as a real
+    setup's HLG.fst does."""
+    kind = kind or (sys.argv[1] if len(sys.argv) > 1 else "HLG")
+    n_utts = n_utts or (int(sys.argv[2]) if len(sys.argv) > 2 else 8)
     V, T = 60, 120
     if kind == "H":
         g, lex = synth.ctc_topo(V), None
@@ -56,7 +41,10 @@ def main():
     else:
         g = synth.hlg_graph(V=V, n_words=500, n_hist=500, avg_succ=10, seed=2)
         lex = g["lexicon"]
-    fst = kd.fst_from_dict(g)  # a real setup: kd.Fst.read("HLG.fst")
+    fst = kd.fst_from_dict(g)
+    if graph_path:  # a real setup: kd.Fst.read("HLG.fst")
+        fst.write(graph_path)
+        fst = kd.Fst.read(graph_path)
     decoder = kd.FasterDecoder(fst, kd.FasterDecoderOptions(max_active=3000))
     lat_decoder = kd.LatticeFasterDecoder(fst, kd.LatticeFasterDecoderConfig(beam=16.0, lattice_beam=8.0))
     errs = words = agree = 0
@@ -73,7 +61,7 @@ def main():
         ok3, lat_best = lat_decoder.get_best_path()
         _, li, lo, _ = kd.get_linear_symbol_sequence(lat_best)
         agree += (ctc_collapse(li) if kind == "H" else list(lo)) == hyp
-        ref = synth.hidden_word_sequence(T, V, utt, lexicon=lex) if hasattr(synth, "hidden_word_sequence") else None
+        ref = synth.hidden_word_sequence(T, V, utt, lexicon=lex) if lex is not None else None
         if ref is not None:
             errs += edit_distance(ref, hyp)
             words += len(ref)
@@ -81,6 +69,7 @@ def main():
     print(f"lattice best path == 1-best on {agree}/{n_utts} utterances")
     if words:
         print(f"WER against the hidden word sequences: {100.0 * errs / words:.2f} % ({errs}/{words})")
+    return (errs / words if words else None), agree
 
 
 if __name__ == "__main__":

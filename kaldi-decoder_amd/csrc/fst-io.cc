@@ -15,43 +15,67 @@ constexpr int32_t kSymbolTableMagicNumber = 2125658996;
 constexpr int32_t kHasIsymbols = 1, kHasOsymbols = 2, kIsAligned = 4;
 constexpr int kConstAlign = 16;  // ConstFst::kStaticProperties alignment of the arrays
 
+// The whole file in memory (one read), then a cursor over it: a 500 MB HLG is three
+// memcpy-sized passes, not 10^8 four-byte stream reads.
 struct Reader {
-  std::ifstream in;
+  std::vector<char> buf;
+  size_t pos = 0;
   std::string path;
-  explicit Reader(const std::string &p) : in(p, std::ios::binary), path(p) {
+  explicit Reader(const std::string &p) : path(p) {
+    std::ifstream in(p, std::ios::binary | std::ios::ate);
     if (!in) throw std::runtime_error("ReadFst: cannot open " + p);
+    const std::streamoff n = in.tellg();
+    buf.resize(static_cast<size_t>(n));
+    in.seekg(0);
+    if (n > 0) in.read(buf.data(), n);
+    if (!in) throw std::runtime_error("ReadFst: cannot read " + p);
+  }
+  bool AtEnd() const { return pos >= buf.size(); }
+  const char *Take(size_t n) {
+    if (n > buf.size() - pos) throw std::runtime_error("ReadFst: unexpected end of file in " + path);
+    const char *p = buf.data() + pos;
+    pos += n;
+    return p;
   }
   template <class T> T Get() {
     T v;
-    in.read(reinterpret_cast<char *>(&v), sizeof(T));
-    if (!in) throw std::runtime_error("ReadFst: unexpected end of file in " + path);
+    std::memcpy(&v, Take(sizeof(T)), sizeof(T));
     return v;
   }
   std::string Str() {
     const int32_t n = Get<int32_t>();
     if (n < 0 || n > (1 << 20)) throw std::runtime_error("ReadFst: bad string length in " + path);
-    std::string s(static_cast<size_t>(n), '\0');
-    in.read(&s[0], n);
-    if (!in) throw std::runtime_error("ReadFst: unexpected end of file in " + path);
-    return s;
+    return std::string(Take(static_cast<size_t>(n)), static_cast<size_t>(n));
   }
-  void AlignTo(int a) {
-    const std::streamoff pos = in.tellg();
-    const std::streamoff pad = (a - pos % a) % a;
-    in.seekg(pad, std::ios::cur);
-  }
+  void AlignTo(int a) { Take((a - pos % a) % a); }
   void SkipSymbolTable() {  // symbol-table.cc SymbolTableImpl::Read
     if (Get<int32_t>() != kSymbolTableMagicNumber)
       throw std::runtime_error("ReadFst: bad symbol table magic in " + path);
     Str();                  // name
     Get<int64_t>();         // available_key
     const int64_t size = Get<int64_t>();
+    if (size < 0) throw std::runtime_error("ReadFst: bad symbol table size in " + path);
     for (int64_t i = 0; i < size; ++i) {
       Str();
       Get<int64_t>();
     }
   }
 };
+
+// 16-byte arc records {ilabel, olabel, weight, nextstate} -> four arrays
+void SplitArcs(const char *rec, size_t n, std::vector<int32_t> &il, std::vector<int32_t> &ol,
+               std::vector<float> &w, std::vector<int32_t> &ns) {
+  const size_t at = il.size();
+  il.resize(at + n); ol.resize(at + n); w.resize(at + n); ns.resize(at + n);
+  for (size_t a = 0; a < n; ++a) {
+    int32_t r[4];
+    std::memcpy(r, rec + 16 * a, 16);
+    il[at + a] = r[0];
+    ol[at + a] = r[1];
+    std::memcpy(&w[at + a], &r[2], 4);
+    ns[at + a] = r[3];
+  }
+}
 
 struct Writer {
   std::ofstream out;
@@ -87,58 +111,57 @@ std::unique_ptr<Fst> ReadFst(const std::string &path) {
     throw std::runtime_error("ReadFst: arc type '" + arc_type + "' (only 'standard' is supported)");
   if (fst_type != "vector" && fst_type != "const")
     throw std::runtime_error("ReadFst: fst type '" + fst_type + "' (only 'vector' and 'const')");
-  if (num_states < 0 || num_states >= (1ll << 31))
+  // (a VectorFst written to a stream that cannot seek carries num_states = -1 and
+  // is read until the file ends: vector-fst.h VectorFstImpl::Read)
+  const bool until_eof = fst_type == "vector" && num_states == -1;
+  if (!until_eof && (num_states < 0 || num_states >= (1ll << 31)))
     throw std::runtime_error("ReadFst: bad state count in " + path);
   if (flags & kHasIsymbols) r.SkipSymbolTable();
   if (flags & kHasOsymbols) r.SkipSymbolTable();
 
-  std::vector<int32_t> row_ptr(static_cast<size_t>(num_states) + 1, 0), il, ol, ns;
-  std::vector<float> w, fin(static_cast<size_t>(num_states));
+  std::vector<int32_t> row_ptr(1, 0), il, ol, ns;
+  std::vector<float> w, fin;
+  int64_t n_states = until_eof ? 0 : num_states;
   if (fst_type == "vector") {
     // VectorFstImpl::Read: per state the final weight, the arc count, the arcs
-    for (int64_t s = 0; s < num_states; ++s) {
-      fin[s] = r.Get<float>();
+    if (!until_eof) { row_ptr.reserve(static_cast<size_t>(num_states) + 1); fin.reserve(num_states); }
+    for (int64_t s = 0; until_eof ? !r.AtEnd() : s < num_states; ++s) {
+      fin.push_back(r.Get<float>());
       const int64_t narcs = r.Get<int64_t>();
-      if (narcs < 0) throw std::runtime_error("ReadFst: bad arc count in " + path);
-      for (int64_t a = 0; a < narcs; ++a) {
-        il.push_back(r.Get<int32_t>());
-        ol.push_back(r.Get<int32_t>());
-        w.push_back(r.Get<float>());
-        ns.push_back(r.Get<int32_t>());
-      }
-      if (il.size() >= (1ull << 31)) throw std::runtime_error("ReadFst: too many arcs");
-      row_ptr[s + 1] = static_cast<int32_t>(il.size());
+      if (narcs < 0 || static_cast<uint64_t>(narcs) + il.size() >= (1ull << 31))
+        throw std::runtime_error("ReadFst: bad arc count in " + path);
+      SplitArcs(r.Take(static_cast<size_t>(narcs) * 16), static_cast<size_t>(narcs), il, ol, w, ns);
+      row_ptr.push_back(static_cast<int32_t>(il.size()));
     }
+    n_states = static_cast<int64_t>(fin.size());
+    if (n_states >= (1ll << 31)) throw std::runtime_error("ReadFst: bad state count in " + path);
   } else {
-    // ConstFstImpl::Read: state array {final, pos, narcs, niepsilons, noepsilons}, then arcs
+    // ConstFstImpl::Read: state array {final, pos, narcs, niepsilons, noepsilons}, then arcs;
+    // file version 1 is the aligned layout (const-fst.h kAlignedFileVersion)
     const bool aligned = (flags & kIsAligned) != 0 || version == 1;
-    if (aligned) r.AlignTo(kConstAlign);
-    std::vector<uint32_t> pos(num_states), narcs(num_states);
-    for (int64_t s = 0; s < num_states; ++s) {
-      fin[s] = r.Get<float>();
-      pos[s] = r.Get<uint32_t>();
-      narcs[s] = r.Get<uint32_t>();
-      r.Get<uint32_t>();
-      r.Get<uint32_t>();
-    }
     if (aligned) r.AlignTo(kConstAlign);
     if (num_arcs_hdr < 0 || num_arcs_hdr >= (1ll << 31))
       throw std::runtime_error("ReadFst: bad arc count in " + path);
-    il.resize(num_arcs_hdr); ol.resize(num_arcs_hdr); w.resize(num_arcs_hdr); ns.resize(num_arcs_hdr);
-    for (int64_t a = 0; a < num_arcs_hdr; ++a) {
-      il[a] = r.Get<int32_t>();
-      ol[a] = r.Get<int32_t>();
-      w[a] = r.Get<float>();
-      ns[a] = r.Get<int32_t>();
-    }
+    const char *st = r.Take(static_cast<size_t>(num_states) * 20);
+    if (aligned) r.AlignTo(kConstAlign);
+    SplitArcs(r.Take(static_cast<size_t>(num_arcs_hdr) * 16), static_cast<size_t>(num_arcs_hdr), il, ol, w, ns);
+    row_ptr.resize(static_cast<size_t>(num_states) + 1);
+    fin.resize(static_cast<size_t>(num_states));
     for (int64_t s = 0; s < num_states; ++s) {
-      if (pos[s] != static_cast<uint32_t>(row_ptr[s]))
+      uint32_t rec[5];
+      std::memcpy(rec, st + 20 * s, 20);
+      std::memcpy(&fin[s], &rec[0], 4);
+      if (rec[1] != static_cast<uint32_t>(row_ptr[s]))
         throw std::runtime_error("ReadFst: const FST arcs are not stored state by state");
-      row_ptr[s + 1] = row_ptr[s] + static_cast<int32_t>(narcs[s]);
+      if (static_cast<uint64_t>(row_ptr[s]) + rec[2] > static_cast<uint64_t>(num_arcs_hdr))
+        throw std::runtime_error("ReadFst: const FST state arc ranges exceed the arc array");
+      row_ptr[s + 1] = row_ptr[s] + static_cast<int32_t>(rec[2]);
     }
   }
+  const int64_t num_states_final = n_states;
+  if (start >= num_states_final) throw std::runtime_error("ReadFst: start state out of range in " + path);
   for (int32_t n : ns)
-    if (n < 0 || n >= num_states) throw std::runtime_error("ReadFst: arc nextstate out of range");
+    if (n < 0 || n >= num_states_final) throw std::runtime_error("ReadFst: arc nextstate out of range");
   return std::unique_ptr<Fst>(new Fst(static_cast<int32_t>(start), std::move(row_ptr), std::move(il),
                                       std::move(ol), std::move(w), std::move(ns), std::move(fin)));
 }

@@ -5,10 +5,11 @@
 // kaldifst / OpenFst are not part of this build, so the two container formats
 // those files use are read (and written) here: "vector" and "const" FSTs over
 // "standard" (tropical, float) arcs.  Layout follows OpenFst's published
-// fst.h / vector-fst.h / const-fst.h / symbol-table.cc.  No real .fst file exists
-// in this image; tests/test_fst_io.py covers writer -> reader round trips and the
-// header fields, so interoperability with files written by OpenFst itself is
-// UNVERIFIED.
+// fst.h / vector-fst.h / const-fst.h / symbol-table.cc.  No file written by OpenFst
+// exists in this image: tests/test_fst_io.py builds vector and const files byte by
+// byte from that layout (symbol tables attached, the aligned const version 1 and the
+// unaligned version 2, a vector file without a state count) independently of the
+// writer here, and reads them back; a file from a real OpenFst build has not been read.
 #ifndef KALDI_DECODER_AMD_CSRC_FST_IO_H_
 #define KALDI_DECODER_AMD_CSRC_FST_IO_H_
 

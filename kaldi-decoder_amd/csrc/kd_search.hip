@@ -2272,11 +2272,23 @@ __device__ __noinline__ uint32_t FrameBackSpill(CParams *pp, int utt, long long 
                   ToG(p.g_arc) + wg * gslots, reinterpret_cast<uint32_t *>(s.cost),
                   p.g_log2_slots, static_cast<uint32_t>(gslots - 1)};
   uint32_t r = FrameBack<false>(c, tg, frame, q_emit, cnt);
-  if (r != 0) {  // leave the global table clean for later frames
+  if (r != 0) {
+    // Leave the global table clean: this workgroup goes on with other utterances of the
+    // work queue (and, after the host has grown what ran out, with this one).  A frame
+    // that ran out of token or link records has a complete live list; one that overflowed
+    // the table itself has claimed slots that are on no list, so all of it is wiped.
     __syncthreads();
-    const int used = s.n_live < static_cast<int>(tg.FillLimit()) ? s.n_live
-                                                                 : static_cast<int>(tg.FillLimit());
-    ClearLive<false>(c, tg, used);
+    if (r == kRetry) {
+      for (long long h = threadIdx.x; h < gslots; h += kBlock) {
+        tg.StoreKey(static_cast<uint32_t>(h), kKeyEmpty);
+        tg.StoreCost(static_cast<uint32_t>(h), kCostDead);
+        tg.StoreArc(static_cast<uint32_t>(h), kArcNone);
+      }
+    } else {
+      const int used = s.n_live < static_cast<int>(tg.FillLimit()) ? s.n_live
+                                                                   : static_cast<int>(tg.FillLimit());
+      ClearLive<false>(c, tg, used);
+    }
   }
   __syncthreads();
   return r == kRetry ? static_cast<uint32_t>(KD_UTT_TABLE_FULL) : r;

@@ -45,7 +45,50 @@ except ImportError as e:  # pragma: no cover
         "`make -C kaldi-decoder_amd` or `python __graft_entry__.py`; there is no "
         f"CPU fallback. Original error: {e}") from e
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
+
+
+def as_fst(graph):
+    """The decoding graph as this package's Fst.  The reference's constructors take
+    kaldifst's fst::Fst / VectorFst / ConstFst<StdArc> objects
+    (/root/reference/kaldi-decoder/python/csrc/faster-decoder.cc:34-42); anything that can
+    write itself as an OpenFst binary file -- kaldifst.StdVectorFst, StdConstFst, a
+    pywrapfst Fst: they all have .write(path) -- is taken through such a file
+    (csrc/fst-io.cc reads the `vector` and `const` containers); a path is read directly."""
+    if isinstance(graph, Fst):
+        return graph
+    if isinstance(graph, (str, _os.PathLike)):
+        return Fst.read(_os.fspath(graph))
+    if hasattr(graph, "write"):
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            path = _os.path.join(d, "graph.fst")
+            graph.write(path)
+            return Fst.read(path)
+    raise TypeError(f"cannot use {type(graph).__name__} as a decoding graph: expected kaldi_decoder.Fst, "
+                    "a path to an OpenFst binary file, or an object with .write(path)")
+
+
+def _taking_any_graph(cls):
+    """The decoder class with a constructor that accepts what as_fst accepts (and keeps
+    the converted graph alive: the reference borrows its graph, faster-decoder.h:179)."""
+    class _Decoder(cls):
+        def __init__(self, fst, *args, **kwargs):
+            fst = as_fst(fst)
+            cls.__init__(self, fst, *args, **kwargs)
+            self._graph = fst
+    _Decoder.__name__ = cls.__name__
+    _Decoder.__qualname__ = cls.__qualname__
+    _Decoder.__doc__ = cls.__doc__
+    return _Decoder
+
+
+FasterDecoder = _taking_any_graph(FasterDecoder)
+SimpleDecoder = _taking_any_graph(SimpleDecoder)
+LatticeSimpleDecoder = _taking_any_graph(LatticeSimpleDecoder)
+LatticeFasterDecoder = _taking_any_graph(LatticeFasterDecoder)
+BatchFasterDecoder = _taking_any_graph(BatchFasterDecoder)
+BatchLatticeDecoder = _taking_any_graph(BatchLatticeDecoder)
 
 
 def fst_from_dict(g):

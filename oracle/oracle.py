@@ -176,7 +176,8 @@ class Graph:
         self.h = C.c_void_p(L.kdo_graph_create(g["num_states"], g["start"], *self._keep))
 
     def __del__(self):
-        lib().kdo_graph_free(self.h)
+        if _LIB is not None:  # (None once the interpreter is shutting down)
+            _LIB.kdo_graph_free(self.h)
 
 
 class BestPath:
@@ -222,8 +223,8 @@ class _Decoder:
     h = None
 
     def __del__(self):
-        if self.h:
-            getattr(lib(), f"kdo_{self._pre}_free")(self.h)
+        if self.h and _LIB is not None:
+            getattr(_LIB, f"kdo_{self._pre}_free")(self.h)
 
     def init_decoding(self):
         if getattr(lib(), f"kdo_{self._pre}_init")(self.h):
@@ -355,8 +356,8 @@ class LatticeSimpleDecoder:
         self.h = C.c_void_p(h)
 
     def __del__(self):
-        if self.h:
-            lib().kdo_latsimple_free(self.h)
+        if self.h and _LIB is not None:
+            _LIB.kdo_latsimple_free(self.h)
 
     def decode(self, log_probs, offset=0):
         lp = np.ascontiguousarray(log_probs, dtype=np.float32)
@@ -400,8 +401,8 @@ class CanonLatticeDecoder:
         self.h = C.c_void_p(h)
 
     def __del__(self):
-        if self.h:
-            lib().kdo_canonlat_free(self.h)
+        if self.h and _LIB is not None:
+            _LIB.kdo_canonlat_free(self.h)
 
     def decode(self, log_probs, offset=0):
         lp = np.ascontiguousarray(log_probs, dtype=np.float32)

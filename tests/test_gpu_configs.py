@@ -1,0 +1,100 @@
+"""BASELINE.json's configurations at FULL size, a few utterances each, against the oracle
+(the canonical semantics bit for bit, the reference-order restatement for the 1-best),
+and the icefall-style driver end to end."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from kaldi_decoder import cabi, synth
+
+pytestmark = pytest.mark.gpu
+INT_MAX = 2**31 - 1
+
+
+def test_cfg2_full_size_hl_max_active_3000(oracle):
+    """configs[1]: FasterDecoder over the HL graph (20 k words, V = 500), beam 16,
+    max_active = 3000, T = 250 -- one launch for the batch; best paths equal the canonical
+    oracle's arc for arc and the reference-order decoder's (policy 0) label for label."""
+    import torch
+    import bench
+    wl = bench.WORKLOADS["hl"]
+    g = synth.hl_graph(**wl["graph"])
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T, V = 4, wl["frames"], wl["V"]
+    # two utterances as the bench draws them (peaky posteriors: the frontier stays below
+    # max_active) and two with flat posteriors, on which max_active = 3000 binds
+    lps = [synth.make_logprobs(T, V, 40 + i, peak=12.0 if i < 2 else 4.0, lexicon=g["lexicon"])
+           for i in range(B)]
+    dev = [torch.from_numpy(lp).cuda() for lp in lps]
+    bt = cabi.Batch(G, max_batch=B, **wl["opts"])
+    bt.decode_device([d.data_ptr() for d in dev], [T] * B, V)
+    assert bt.num_frames_decoded().tolist() == [T] * B
+    paths, rf = bt.best_paths(), bt.reached_final()
+    st = bt.stats()
+    assert st[:2, 8].max() < wl["opts"]["max_active"] < st[2:, 8].max()  # binds on the flat ones
+    for i in range(B):
+        can = oracle.FasterDecoder(OG, policy=1, **wl["opts"])
+        can.decode(lps[i])
+        p = can.get_best_path()
+        for k in ("ilabel", "olabel", "state", "graph_cost", "ac_cost"):
+            assert getattr(paths[i], k).tolist() == getattr(p, k).tolist(), (i, k)
+        assert tuple(paths[i].final_weight) == tuple(p.final_weight)
+        assert bool(rf[i]) == can.reached_final()
+        s, c = bt.frame_tokens(i, T)
+        so, co = can.tokens()
+        assert s.tolist() == so.tolist() and c.tolist() == co.tolist(), i
+        ref = oracle.FasterDecoder(OG, policy=0, **wl["opts"])
+        ref.decode(lps[i])
+        pr = ref.get_best_path()
+        assert paths[i].isyms.tolist() == pr.isyms.tolist(), i
+        assert paths[i].osyms.tolist() == pr.osyms.tolist(), i
+
+
+def test_cfg5_large_lm_hlg_beam17_default_capacities(oracle):
+    """configs[4]: LatticeFasterDecoder over a large-LM HLG (200 k words: 52.8 M states,
+    141 M arcs = 2.26 GB of arc records), beam 17, lattice beam 8, T = 250, library DEFAULT
+    capacities (round 1 needed 120 GB of hand-set arenas for this): lattices equal the
+    canonical oracle's, the 1-best equals the reference-order decoder's."""
+    import torch
+    import bench
+    wl = bench.WORKLOADS["hlg-large"]
+    g = synth.hlg_graph(**wl["graph"])
+    assert len(g["ilabel"]) * 16 > 2 * 10**9  # > 2 GB of 16-byte arcs
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T, V = 4, wl["frames"], wl["V"]
+    lps = [synth.make_logprobs(T, V, 70 + i, peak=12.0, lexicon=g["lexicon"]) for i in range(B)]
+    dev = [torch.from_numpy(lp).cuda() for lp in lps]
+    lb = cabi.LatticeBatch(G, max_batch=B, **wl["opts"])
+    lb.decode_device([d.data_ptr() for d in dev], [T] * B, V)
+    assert lb.num_frames_decoded().tolist() == [T] * B
+    lats, frc, st = lb.raw_lattices(), lb.final_relative_cost(), lb.stats()
+    assert st[:, 9].sum() > 0  # frames beyond the LDS table (the global-table tier) occur
+    for i in range(B):
+        can = oracle.CanonLatticeDecoder(OG, **wl["opts"])
+        can.decode(lps[i])
+        cl, gl = can.get_raw_lattice(), lats[i]
+        assert gl.state_set() == cl.state_set(), i
+        assert gl.arc_set() == cl.arc_set() and len(gl.src) == len(cl.src), i
+        assert gl.final_set() == cl.final_set(), i
+        assert frc[i] == can.final_relative_cost(), i
+        ref = oracle.LatticeSimpleDecoder(OG, beam=wl["opts"]["beam"], lattice_beam=wl["opts"]["lattice_beam"])
+        ref.decode(lps[i])
+        pr, pc = ref.get_best_path(), can.get_best_path()
+        assert pr.isyms.tolist() == pc.isyms.tolist() and pr.osyms.tolist() == pc.osyms.tolist(), i
+        assert gl.arc_set() <= ref.get_raw_lattice().arc_set(), i
+
+
+@pytest.mark.parametrize("kind", ["H", "HL", "HLG"])
+def test_icefall_style_driver_runs_end_to_end(kind, tmp_path):
+    """examples/decode_ctc.py: DecodableCtc -> FasterDecoder(max_active=3000).decode ->
+    reached_final -> get_best_path -> linear symbol sequence -> tokens / words -> WER, with
+    the graph going through an OpenFst binary file (Fst.read) on the way."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "examples"))
+    import decode_ctc
+    wer, agree = decode_ctc.main(kind, 4, graph_path=str(tmp_path / f"{kind}.fst"))
+    assert agree == 4  # the lattice decoder's best path is the 1-best decoder's
+    if kind != "H":
+        assert wer is not None and wer < 0.35  # peaky synthetic posteriors: few errors

@@ -247,3 +247,36 @@ def test_pools_and_tables_grow_on_demand(oracle):
     fixed = cabi.LatticeBatch(G, max_batch=B, arena_tokens=4096, arena_links=4096, no_grow=1, **opts)
     with pytest.raises(RuntimeError, match="pool full"):
         fixed.decode_device([d.data_ptr() for d in dev], [T] * B, V)
+
+
+def test_more_utterances_than_workgroups_and_table_growth_mid_launch(oracle):
+    """A launch has at most one workgroup per CU (256) and 300 utterances here: workgroups
+    take second utterances from the work queue.  The frontier (tens of thousands of tokens
+    on flat posteriors) overflows the 2^14-slot spill table the batch starts with, so
+    utterances stop with a full table, their workgroups go on with others -- from a table
+    that must be clean again -- and the host grows the tables and resumes the rest."""
+    import torch
+    g = synth.random_graph(40000, 4.0, 24, 0.1, 911)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T, V = 300, 7, 24
+    opts = dict(beam=30.0, lattice_beam=6.0, min_active=0)
+    rng = np.random.default_rng(5)
+    base = [synth.make_logprobs(T, V, 200 + i, peak=0.5) for i in range(6)]
+    pick = rng.integers(0, len(base), B)
+    dev = [torch.from_numpy(lp).cuda() for lp in base]
+    lb = cabi.LatticeBatch(G, max_batch=B, table_slots=1 << 14, **opts)
+    lb.decode_device([dev[k].data_ptr() for k in pick], [T] * B, V)
+    cap = lb.capacity()
+    assert cap["workgroups"] <= 256 < B and cap["table_slots"] > (1 << 14) and cap["grow_events"] > 0
+    assert lb.stats()[:, 8].max() > (1 << 14) * 3 // 4
+    lats = lb.raw_lattices()
+    want = []
+    for lp in base:
+        can = oracle.CanonLatticeDecoder(OG, **opts)
+        can.decode(lp)
+        want.append(can.get_raw_lattice())
+    for i in range(B):
+        cl, gl = want[pick[i]], lats[i]
+        assert gl.num_states == cl.num_states and len(gl.src) == len(cl.src), i
+        if i % 25 == 0:
+            _assert_same_lattice(gl, cl, i)
