@@ -125,6 +125,26 @@ def lattice_best_path(lat):
     return [x for x in il[::-1] if x], [x for x in ol[::-1] if x]
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, cut by the container's
+    CPU quota (cgroup cpu.max / cfs_quota_us) -- the GPU box reports 256 logical cores and
+    grants 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(g, lps, wl, gpu_out, pool=None, budget_s=20.0):
     """The oracle's reference-order restatement (policy 0), one thread, on a bounded
     sample of the same utterances; also checks 1-best parity with the GPU output."""
@@ -182,7 +202,9 @@ def cpu_baseline(g, lps, wl, gpu_out, pool=None, budget_s=20.0):
         allc = frames_all * SUBSAMPLING / t_all
         res["all_cores"] = dict(value=allc, unit="audio_frames/s", cores=procs,
                                 scaling_efficiency=allc / (procs * one),
-                                sample=f"{procs} processes x {per_proc} utterances of the same sample")
+                                host_logical_cores=os.cpu_count(),
+                                sample=f"{procs} processes (the cores the container grants) x "
+                                       f"{per_proc} utterances of the same sample")
     return res, par
 
 
@@ -255,7 +277,7 @@ def main():
         _CPU.update(g=g, wl=wl, og=_oracle.Graph(g),
                     lps=[synth.make_logprobs(T0, V0, u, peak=12.0, lexicon=g["lexicon"])
                          for u in range(min(n_sample, 512))])
-        cpu_pool = multiprocessing.get_context("fork").Pool(os.cpu_count() or 1)
+        cpu_pool = multiprocessing.get_context("fork").Pool(usable_cores())
 
     import torch
     import torch.distributed as dist
@@ -280,7 +302,7 @@ def main():
     # the same arcs or share log-prob rows in L2 / the Infinity Cache
     per_slot = G * B
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(min(32, usable_cores())) as ex:
         all_lps = list(ex.map(lambda u: synth.make_logprobs(T, V, u, peak=12.0, lexicon=g["lexicon"]),
                               range(rank * n_fly * per_slot, (rank + 1) * n_fly * per_slot)))
     Gr = cabi.Graph(g, device=local_rank)

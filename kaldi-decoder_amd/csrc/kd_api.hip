@@ -74,7 +74,7 @@ struct kd_batch {
   DevBuf<uint32_t> lat_scratch;
   DevBuf<int32_t> link_src, link_dst, link_arc;
   DevBuf<float> link_ac, link_graph, link_delta;
-  DevBuf<unsigned long long> out_pool;
+  unsigned long long *out_pool = nullptr;  // pinned host memory, written by the kernel
   // ---- per utterance
   DevBuf<long long> frame_base, link_emit_base, link_eps_base;
   DevBuf<int32_t> frame_count, link_emit_count, link_eps_count, frame_state_off, frame_arc_off;
@@ -88,15 +88,19 @@ struct kd_batch {
   DevBuf<uint32_t> g_key, g_arc, g_used, g_wl, g_log_h, g_log_arc, g_log_src;
   DevBuf<unsigned long long> g_cost, g_log_nk;
   DevBuf<float> g_log_ac, g_log_gr;
-  // ---- launch control: UttCtl[B] | order[B] | BatchCtl | UttOut[B], device + pinned mirror
-  DevBuf<unsigned char> ctl_dev;
+  // ---- launch control: UttCtl[B] | order[B] | UttOut[B] | HostTops in pinned host memory
+  // the GPU reads and writes in place; BatchCtl (the atomic counters) in device memory
+  DevBuf<BatchCtl> bctl;
   unsigned char *ctl_host = nullptr;
-  size_t off_order = 0, off_bctl = 0, off_out = 0, ctl_bytes = 0;
+  size_t off_order = 0, off_out = 0, off_tops = 0, ctl_bytes = 0;
   UttCtl *h_ctl() const { return reinterpret_cast<UttCtl *>(ctl_host); }
   int32_t *h_order() const { return reinterpret_cast<int32_t *>(ctl_host + off_order); }
-  BatchCtl *h_bctl() const { return reinterpret_cast<BatchCtl *>(ctl_host + off_bctl); }
   UttOut *h_out() const { return reinterpret_cast<UttOut *>(ctl_host + off_out); }
-  // cursors of the pools as of the last read-back
+  HostTops *h_tops() const { return reinterpret_cast<HostTops *>(ctl_host + off_tops); }
+  // BatchCtl's counters as of the last read-back (raw: they only ever grow), and where
+  // each pool's index 0 currently is; cursor = raw - base
+  uint32_t work_raw = 0, done_raw = 0;
+  uint64_t tok_raw = 0, link_raw = 0, out_raw = 0, tok_base = 0, link_base = 0, out_base = 0;
   uint64_t h_tok_top = 0, h_link_top = 0, h_out_top = 0;
   // the launch in flight (what a relaunch after growing a pool repeats)
   int32_t l_num_cols = 0;
@@ -106,10 +110,7 @@ struct kd_batch {
   bool lattice = false, finalized = false, simple = false;
   bool lat_stats_valid = false;  // h_final_rel is current
   int32_t exported_use_final = -1;  // the output pool holds GetRawLattice(use_final_probs = this)
-  bool out_fetched = false;         // ... and out_host holds its words [0, h_out_top)
   kd_lattice_options lo{};
-  unsigned long long *out_host = nullptr;  // pinned
-  size_t out_host_words = 0, out_spec_words = 0, out_last_words = 0;
   std::vector<float> h_final_rel;
   std::vector<int32_t> h_lat_sizes;
   std::vector<long long> h_lat_off;
@@ -131,7 +132,7 @@ struct kd_batch {
   int grow_events = 0;
 
   ~kd_batch() {
-    if (out_host) (void)hipHostFree(out_host);
+    if (out_pool) (void)hipHostFree(out_pool);
     if (ctl_host) (void)hipHostFree(ctl_host);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -141,13 +142,13 @@ struct kd_batch {
     return tok_state.bytes() + tok_prev.bytes() + tok_arc.bytes() + tok_cost.bytes() +
            tok_extra.bytes() + tok_newid.bytes() + lat_scratch.bytes() + link_src.bytes() +
            link_dst.bytes() + link_arc.bytes() + link_ac.bytes() + link_graph.bytes() +
-           link_delta.bytes() + out_pool.bytes() + frame_base.bytes() + frame_count.bytes() +
+           link_delta.bytes() + frame_base.bytes() + frame_count.bytes() +
            link_emit_base.bytes() + link_eps_base.bytes() + link_emit_count.bytes() +
            link_eps_count.bytes() + frame_state_off.bytes() + frame_arc_off.bytes() +
            g_key.bytes() + g_arc.bytes() + g_log_h.bytes() + g_log_arc.bytes() +
            g_log_src.bytes() + g_log_nk.bytes() + g_log_ac.bytes() + g_log_gr.bytes() +
            g_used.bytes() + g_wl.bytes() + g_cost.bytes() + staging.bytes() + stats.bytes() +
-           ctl_dev.bytes();
+           bctl.bytes();
   }
 
   SearchParams Params() const {
@@ -186,10 +187,16 @@ struct kd_batch {
     p.g_log_nk = g_log_nk.p;
     p.g_log2_slots = g_log2_slots;
     p.batch = batch;
-    p.utt = reinterpret_cast<const UttCtl *>(ctl_dev.p);
-    p.order = reinterpret_cast<const int32_t *>(ctl_dev.p + off_order);
-    p.ctl = reinterpret_cast<BatchCtl *>(ctl_dev.p + off_bctl);
-    p.out = reinterpret_cast<UttOut *>(ctl_dev.p + off_out);
+    p.utt = h_ctl();     // (pinned host memory: the same address on the device)
+    p.order = h_order();
+    p.ctl = bctl.p;
+    p.out = h_out();
+    p.tops = h_tops();
+    p.work_base = work_raw;
+    p.done_base = done_raw;
+    p.tok_base = tok_base;
+    p.link_base = link_base;
+    p.out_base = out_base;
     p.lattice = lattice ? 1 : 0;
     p.simple = simple ? 1 : 0;
     p.g_log_ac = g_log_ac.p;
@@ -217,7 +224,7 @@ struct kd_batch {
     p.lat.finalized = lat_finalized.p;
     p.lat.frame_state_off = frame_state_off.p;
     p.lat.frame_arc_off = frame_arc_off.p;
-    p.lat.out = out_pool.p;
+    p.lat.out = out_pool;
     p.lat.out_cap = out_cap;
     return p;
   }
@@ -332,9 +339,11 @@ int GrowLinks(kd_batch *b) {
 int GrowOut(kd_batch *b) {
   const uint64_t cap = b->out_cap * 2;
   // (what the pool holds is exported again after growing: nothing to keep)
-  hipError_t e = GrowBuf(b->out_pool, cap, 0, b->stream);
-  if (e != hipSuccess)
+  unsigned long long *np = nullptr;
+  if (hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&np), cap * 8, hipHostMallocDefault); e != hipSuccess)
     return Fail(KD_E_CAPACITY, std::string("lattice output pool cannot grow: ") + hipGetErrorString(e));
+  (void)hipHostFree(b->out_pool);
+  b->out_pool = np;
   b->out_cap = cap;
   b->grow_events++;
   return KD_OK;
@@ -416,10 +425,9 @@ int GrowFrames(kd_batch *b, int32_t need) {
 
 // ---- launch -----------------------------------------------------------------------
 // The utterances' UttCtl entries (ll, num_rows, offset, target, flags) are in the pinned
-// mirror.  One H2D copy (control prefix), one kernel, one D2H copy (BatchCtl + results),
-// and -- when the launch exports lattices -- a speculative D2H of as much of the output
-// pool as the previous export filled, so that a steady stream of batches needs no
-// second round trip for the lattices.
+// control block.  A launch is ONE command on the stream -- the kernel: it reads its
+// inputs from, and leaves its results (per-utterance outcomes, exported lattices, the
+// pools' cursors) in, pinned host memory, so there is nothing to copy either way.
 int Enqueue(kd_batch *b) {
   // work queue order: most frames to decode first, so the launch does not end on a
   // long utterance started late
@@ -432,30 +440,16 @@ int Enqueue(kd_batch *b) {
     const int fy = uc[y].target - ((uc[y].flags & kUttInit) ? 0 : std::max(dec[y], 0));
     return fx > fy;
   });
-  BatchCtl *bc = b->h_bctl();
-  bc->work_ctr = 0;
-  bc->any_status = 0;
-  bc->tok_top = b->h_tok_top;
-  bc->link_top = b->h_link_top;
-  bc->out_top = b->h_out_top;
-  KD_HIP_TRY(hipMemcpyAsync(b->ctl_dev.p, b->ctl_host, b->off_out, hipMemcpyHostToDevice, b->stream));
   SearchParams p = b->Params();
   p.num_cols = b->l_num_cols;
   p.row_stride = b->l_row_stride;
+  const int wgs = std::min(b->batch, b->workgroups);
   KD_HIP_TRY(hipEventRecord(b->ev0, b->stream));
-  KD_HIP_TRY(LaunchSearch(p, std::min(b->batch, b->workgroups), b->stream));
+  KD_HIP_TRY(LaunchSearch(p, wgs, b->stream));
   KD_HIP_TRY(hipEventRecord(b->ev1, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(b->ctl_host + b->off_bctl, b->ctl_dev.p + b->off_bctl,
-                            sizeof(BatchCtl) + static_cast<size_t>(b->batch) * sizeof(UttOut),
-                            hipMemcpyDeviceToHost, b->stream));
-  b->out_spec_words = 0;
-  if (b->l_tail_flags & (kUttExport | kUttExportNoFinal)) {
-    size_t spec = std::min<size_t>(b->out_cap, b->out_last_words + b->out_last_words / 4);
-    if (spec && spec <= b->out_host_words) {
-      KD_HIP_TRY(hipMemcpyAsync(b->out_host, b->out_pool.p, spec * 8, hipMemcpyDeviceToHost, b->stream));
-      b->out_spec_words = spec;
-    }
-  }
+  // every utterance is handed out once and every workgroup makes one failed attempt
+  b->work_raw += static_cast<uint32_t>(b->batch + wgs);
+  b->done_raw += static_cast<uint32_t>(wgs);
   b->timed = true;
   b->pending = true;
   b->path_valid = false;
@@ -480,11 +474,14 @@ int ReadBack(kd_batch *b) {
   while (true) {
     KD_HIP_TRY(hipStreamSynchronize(b->stream));
     b->pending = false;
-    const BatchCtl bc = *b->h_bctl();
+    const HostTops tops = *b->h_tops();
     const UttOut *uo = b->h_out();
-    b->h_tok_top = bc.tok_top;
-    b->h_link_top = bc.link_top;
-    b->h_out_top = bc.out_top;
+    b->tok_raw = tops.tok_top;
+    b->link_raw = tops.link_top;
+    b->out_raw = tops.out_top;
+    b->h_tok_top = b->tok_raw - b->tok_base;
+    b->h_link_top = b->link_raw - b->link_base;
+    b->h_out_top = b->out_raw - b->out_base;
     uint32_t any = 0;
     int first_bad = -1;
     for (int i = 0; i < b->batch; ++i) {
@@ -503,8 +500,6 @@ int ReadBack(kd_batch *b) {
           b->h_lat_off[i] = uo[i].out_off;
         }
         b->exported_use_final = (b->l_tail_flags & kUttExport) ? 1 : 0;
-        b->out_fetched = b->h_out_top <= b->out_spec_words;
-        b->out_last_words = static_cast<size_t>(b->h_out_top);
       }
     }
     if (!any) return KD_OK;
@@ -517,7 +512,8 @@ int ReadBack(kd_batch *b) {
       if (int r = GrowTables(b)) return r;
     if (any & KD_UTT_OUT_FULL) {
       if (int r = GrowOut(b)) return r;
-      b->h_out_top = 0;  // every utterance exports again, into the larger pool
+      b->out_base = b->out_raw;  // every utterance exports again, into the larger pool
+      b->h_out_top = 0;
     }
     // resume: utterances that never got past InitDecoding start over, the others go on
     // from their last committed frame
@@ -582,7 +578,10 @@ void ResetForInit(kd_batch *b, int32_t batch) {
   b->finalized = false;
   b->lat_stats_valid = false;
   b->exported_use_final = -1;
-  b->out_fetched = false;
+  // the pools are empty again: index 0 is wherever their counters stand
+  b->tok_base = b->tok_raw;
+  b->link_base = b->link_raw;
+  b->out_base = b->out_raw;
   b->h_tok_top = 0;
   b->h_link_top = 0;
   b->h_out_top = 0;
@@ -729,12 +728,13 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   A(b->path_offset.Alloc(max_batch));
   A(b->final_weight.Alloc(2 * static_cast<size_t>(max_batch)));
   A(b->final_rel.Alloc(max_batch));
-  // launch control block and its pinned mirror
+  // launch control: the pinned block the GPU addresses directly, and the device counters
   b->off_order = static_cast<size_t>(max_batch) * sizeof(UttCtl);
-  b->off_bctl = (b->off_order + static_cast<size_t>(max_batch) * sizeof(int32_t) + 15) & ~size_t(15);
-  b->off_out = b->off_bctl + ((sizeof(BatchCtl) + 15) & ~size_t(15));
-  b->ctl_bytes = b->off_out + static_cast<size_t>(max_batch) * sizeof(UttOut);
-  A(b->ctl_dev.Alloc(b->ctl_bytes));
+  b->off_out = (b->off_order + static_cast<size_t>(max_batch) * sizeof(int32_t) + 15) & ~size_t(15);
+  b->off_tops = (b->off_out + static_cast<size_t>(max_batch) * sizeof(UttOut) + 15) & ~size_t(15);
+  b->ctl_bytes = b->off_tops + sizeof(HostTops);
+  A(b->bctl.Alloc(1));
+  if (e == hipSuccess) e = hipMemset(b->bctl.p, 0, sizeof(BatchCtl));
   if (e == hipSuccess)
     e = hipHostMalloc(reinterpret_cast<void **>(&b->ctl_host), b->ctl_bytes, hipHostMallocDefault);
   if (e == hipSuccess) std::memset(b->ctl_host, 0, b->ctl_bytes);
@@ -757,7 +757,7 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
     A(b->link_ac.Alloc(b->link_cap));
     A(b->link_graph.Alloc(b->link_cap));
     A(b->link_delta.Alloc(b->link_cap));
-    A(b->out_pool.Alloc(b->out_cap));
+    A(hipHostMalloc(reinterpret_cast<void **>(&b->out_pool), b->out_cap * 8, hipHostMallocDefault));
     A(b->link_emit_base.Alloc(nf));
     A(b->link_emit_count.Alloc(nf));
     A(b->link_eps_base.Alloc(nf));
@@ -1175,8 +1175,8 @@ int kd_batch_raw_lattice_prepare(kd_batch *b, int32_t use_final_probs, int32_t *
     if (!(b->h_decoded[i] > 0)) return Fail(KD_E_STATE, "Check failed: num_frames > 0");
   const int want = use_final_probs ? 1 : 0;
   if (b->exported_use_final != want) {
-    b->h_out_top = 0;  // the pool is rewritten from its start
-    b->out_fetched = false;
+    b->out_base = b->out_raw;  // the pool is rewritten from its start
+    b->h_out_top = 0;
     if (int r = LaunchTail(b, use_final_probs ? kUttExport : kUttExportNoFinal)) return r;
   }
   std::memcpy(sizes, b->h_lat_sizes.data(), 4 * b->batch * sizeof(int32_t));
@@ -1192,29 +1192,13 @@ int kd_batch_raw_lattice_copy(kd_batch *b, const int64_t *state_off, const int64
   if (!b->lattice || b->exported_use_final < 0 || b->pending)
     return Fail(KD_E_STATE, "call kd_batch_raw_lattice_prepare first");
   KD_HIP_TRY(hipSetDevice(b->g->device));
-  const size_t words = static_cast<size_t>(b->h_out_top);
-  if (words == 0) return KD_OK;
-  if (!b->out_fetched) {
-    if (b->out_host_words < words) {
-      if (b->out_host) (void)hipHostFree(b->out_host);
-      b->out_host = nullptr;
-      b->out_host_words = 0;
-      const size_t want = words + words / 2;
-      if (hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&b->out_host), want * 8, hipHostMallocDefault);
-          e != hipSuccess)
-        return Fail(KD_E_HIP, std::string("lattice output (host): ") + hipGetErrorString(e));
-      b->out_host_words = want;
-    }
-    KD_HIP_TRY(hipMemcpyAsync(b->out_host, b->out_pool.p, words * 8, hipMemcpyDeviceToHost, b->stream));
-    KD_HIP_TRY(hipStreamSynchronize(b->stream));
-    b->out_fetched = true;
-  }
+  if (b->h_out_top == 0) return KD_OK;
   // an utterance's region: states {frame, graph state} | finals {state, weight} |
   // arcs {src, dst, ilabel, olabel, graph, ac}
   for (int i = 0; i < b->batch; ++i) {
     const size_t ns = b->h_lat_sizes[4 * i], na = b->h_lat_sizes[4 * i + 1], nf = b->h_lat_sizes[4 * i + 2];
     if (ns == 0 || b->h_lat_off[i] < 0) continue;
-    const int32_t *w = reinterpret_cast<const int32_t *>(b->out_host + b->h_lat_off[i]);
+    const int32_t *w = reinterpret_cast<const int32_t *>(b->out_pool + b->h_lat_off[i]);
     for (size_t k = 0; k < ns; ++k) {
       if (state_frame) state_frame[state_off[i] + k] = w[2 * k];
       if (state_graph) state_graph[state_off[i] + k] = w[2 * k + 1];

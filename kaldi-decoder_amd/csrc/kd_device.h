@@ -43,10 +43,14 @@ constexpr int kProfSlots = 24;   // diagnostic cycle buckets (KD_PROFILE builds)
 constexpr int kStatStride = 40;  // KD_NUM_STATS counters + kProfSlots, padded
 
 // ---- launch control ------------------------------------------------------------
-// One device buffer per batch, laid out  UttCtl[B] | order[B] | BatchCtl | UttOut[B].
-// The host uploads the prefix up to and including BatchCtl before every launch (it
-// knows every value: cursors come back with the previous launch's results) and reads
-// BatchCtl | UttOut[B] back afterwards: one copy each way per launch.
+// No copy engine and no copy kernel takes part in a launch.  The per-utterance inputs
+// (UttCtl, the work-queue order) and outputs (UttOut, the pools' cursors) live in ONE block
+// of pinned host memory that the GPU addresses directly: workgroups read their UttCtl
+// from it and write their UttOut into it, and exported lattices go straight into a
+// pinned output pool.  The only device-resident control words are the atomically
+// updated counters of BatchCtl; they are never reset -- every launch is told the value
+// each one has when it starts (`*_base` in SearchParams: the host knows them, the last
+// workgroup of a launch publishes them) and works with differences.
 struct UttCtl {
   const float *ll;     // row 0 of this utterance's log-likelihood matrix
   int32_t num_rows;
@@ -61,11 +65,15 @@ constexpr uint32_t kUttExport = 8u;      // GetRawLattice into the output pool
 constexpr uint32_t kUttExportNoFinal = 16u;  // ... with use_final_probs == false
 
 struct BatchCtl {
-  int32_t work_ctr;              // next position of `order` to take (work queue)
-  uint32_t any_status;           // OR of every utterance's status bits
-  unsigned long long tok_top;    // token pool: next free record
-  unsigned long long link_top;   // link pool: next free link
-  unsigned long long out_top;    // output pool: next free 8-byte word
+  uint32_t work_ctr;             // work queue: positions of `order` handed out, ever
+  uint32_t n_done;               // workgroups that have left, ever
+  unsigned long long tok_top;    // token pool: records handed out since the pool's base
+  unsigned long long link_top;   // link pool
+  unsigned long long out_top;    // output pool: 8-byte words
+};
+// what the last workgroup of a launch leaves in pinned memory for the host
+struct HostTops {
+  unsigned long long tok_top, link_top, out_top, launches;
 };
 
 struct UttOut {
@@ -101,7 +109,7 @@ struct LatticeParams {
   int32_t *frame_arc_off;
   // output pool, 8-byte words: per utterance  states {frame, graph state} x ns |
   // finals {state id, weight} x nf | arcs {src, dst, ilabel, olabel, graph, ac} x na
-  unsigned long long *out;
+  unsigned long long *out;   // (pinned host memory)
   unsigned long long out_cap;
 };
 
@@ -143,12 +151,15 @@ struct SearchParams {
   uint32_t *g_log_src;
   unsigned long long *g_log_nk;
   int32_t g_log2_slots;
-  // launch control
+  // launch control (utt, order, out, tops: pinned host memory; ctl: device memory)
   int32_t batch;
   const UttCtl *utt;
   const int32_t *order;      // work queue: utterance ids, longest first
   BatchCtl *ctl;
   UttOut *out;
+  HostTops *tops;
+  uint32_t work_base, done_base;                   // BatchCtl's counters when this launch starts
+  unsigned long long tok_base, link_base, out_base;  // ... and where each pool's index 0 is
   int32_t num_cols;
   long long row_stride;
   // lattice mode (LatticeSimpleDecoder / LatticeFasterDecoder semantics)

@@ -454,7 +454,7 @@ __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &
   const int nf = s.n_finals;
   if (tid == 0) {
     const unsigned long long words = static_cast<unsigned long long>(ns) + nf + 3ull * na;
-    const unsigned long long b = atomicAdd(&p.ctl->out_top, words);
+    const unsigned long long b = atomicAdd(&p.ctl->out_top, words) - p.out_base;
     if (b + words > p.lat.out_cap) {
       atomicAdd(&p.ctl->out_top, 0ull - words);
       s.out_off = -1;
@@ -593,7 +593,7 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
   // the utterance's region of the output pool: states | finals | arcs, in 8-byte words
   if (tid == 0) {
     const unsigned long long words = static_cast<unsigned long long>(ns) + nf + 3ull * na;
-    const unsigned long long b = atomicAdd(&p.ctl->out_top, words);
+    const unsigned long long b = atomicAdd(&p.ctl->out_top, words) - p.out_base;
     if (b + words > p.lat.out_cap) {
       atomicAdd(&p.ctl->out_top, 0ull - words);
       s.out_off = -1;

@@ -177,6 +177,8 @@ struct Shared {
   int32_t best_abeg, best_deg;  // ... and its emitting arc range
   long long link_next;          // lattice: next free link of this utterance's link-pool chunk
   long long link_end;
+  unsigned long long ud_ll;     // the utterance's UttCtl::ll and ::offset (read once from
+  int32_t ud_offset, ud_pad;    // pinned host memory when the utterance is taken up)
   int32_t soft_bar;             // team barrier arrivals since the launch began
   int32_t alloc_ok;             // result of the last chunk allocation (0 ok, else a KD_UTT_* bit)
   // what a tier-1 frame leaves for the waves that sat it out, by frame parity:
@@ -452,7 +454,7 @@ __device__ __forceinline__ uint32_t TakeChunks(CParams &p, Shared &s, long long 
   if (s.arena_next + need_tokens > s.arena_end) {
     const unsigned long long want =
         static_cast<unsigned long long>(need_tokens > p.tok_chunk ? need_tokens : p.tok_chunk);
-    const unsigned long long b = atomicAdd(&p.ctl->tok_top, want);
+    const unsigned long long b = atomicAdd(&p.ctl->tok_top, want) - p.tok_base;
     if (b + want > p.tok_cap) {
       atomicAdd(&p.ctl->tok_top, 0ull - want);
       return KD_UTT_ARENA_FULL;
@@ -463,7 +465,7 @@ __device__ __forceinline__ uint32_t TakeChunks(CParams &p, Shared &s, long long 
   if (need_links > 0 && s.link_next + need_links > s.link_end) {
     const unsigned long long want =
         static_cast<unsigned long long>(need_links > p.link_chunk ? need_links : p.link_chunk);
-    const unsigned long long b = atomicAdd(&p.ctl->link_top, want);
+    const unsigned long long b = atomicAdd(&p.ctl->link_top, want) - p.link_base;
     if (b + want > p.link_cap) {
       atomicAdd(&p.ctl->link_top, 0ull - want);
       return KD_UTT_LINKS_FULL;
@@ -2319,8 +2321,8 @@ __device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long 
   cnt.tokens_expanded = n_expanded;
   cnt.arcs_scanned = n_arcs;
   if (frame >= 0)
-    c.ll_row = ToG(ToG(p.utt)[utt].ll) +
-               static_cast<long long>(frame - ToG(p.utt)[utt].offset) * p.row_stride;
+    c.ll_row = ToG(reinterpret_cast<const float *>(s.ud_ll)) +
+               static_cast<long long>(frame - s.ud_offset) * p.row_stride;
   __syncthreads();  // token records stored by a small team are visible to every wave
   if (upper_dirty) FullClear<true>(tl, s);
   if (filtered) {
@@ -2410,7 +2412,11 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
 
   if (tid < KD_NUM_STATS) s.stat[tid] = 0;
   if (tid < 4) s.frame_cnt[tid] = 0;
-  if (tid == 0) s.soft_bar = 0;
+  if (tid == 0) {
+    s.soft_bar = 0;
+    s.ud_ll = reinterpret_cast<unsigned long long>(ud.ll);
+    s.ud_offset = ud.offset;
+  }
 #ifdef KD_PROFILE
   if (tid < kProfSlots) s.cyc[tid] = 0;
   if (tid == 0) s.lap_last = static_cast<long long>(__builtin_amdgcn_s_memtime());
@@ -2591,7 +2597,6 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     m->arena_end = s.arena_end;
     m->link_next = s.link_next;
     m->link_end = s.link_end;
-    if (err) atomicOr(&p.ctl->any_status, err);
   }
   if (tid < KD_NUM_STATS) {
     KD_G long long *st = ToG(p.stats) + static_cast<long long>(utt) * kStatStride;
@@ -2619,10 +2624,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       __syncthreads();  // (every wave is done with the search's LDS)
       const uint32_t e = Uni(LatticeTail(&p, utt, frame, ud.flags));
       __syncthreads();
-      if (e && tid == 0) {
-        ToG(p.status)[utt] = e;
-        atomicOr(&p.ctl->any_status, e);
-      }
+      if (e && tid == 0) ToG(p.status)[utt] = e;
       const TailShared &ts = TailLds();
       o.status = e;
       o.sizes[0] = ts.r_sizes[0]; o.sizes[1] = ts.r_sizes[1];
@@ -2649,11 +2651,27 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
   // instead of idling until the launch's slowest utterance is done.
   while (true) {
     __syncthreads();  // the previous utterance is finished by every wave
-    if (threadIdx.x == 0) kd_work_item = atomicAdd(&p.ctl->work_ctr, 1);
+    if (threadIdx.x == 0)
+      kd_work_item = static_cast<int>(atomicAdd(&p.ctl->work_ctr, 1u) - p.work_base);
     __syncthreads();
     const int item = Uni(kd_work_item);
     if (item >= p.batch) break;
     RunUtterance<M>(p, s, Uni(ToG(p.order)[item]));
+  }
+  // The last workgroup to leave tells the host where the pools' cursors stand (every
+  // other workgroup's allocations are behind its n_done increment).
+  if (threadIdx.x == 0) {
+    __threadfence_system();
+    const uint32_t left = atomicAdd(&p.ctl->n_done, 1u) - p.done_base;
+    if (left == gridDim.x - 1) {
+      HostTops t;
+      t.tok_top = atomicAdd(&p.ctl->tok_top, 0ull);
+      t.link_top = atomicAdd(&p.ctl->link_top, 0ull);
+      t.out_top = atomicAdd(&p.ctl->out_top, 0ull);
+      t.launches = p.tops->launches + 1;
+      *p.tops = t;
+      __threadfence_system();
+    }
   }
 }
 

@@ -3,7 +3,7 @@
 # the rocprofv3 kernel trace of the same command, and the two PMC passes the HBM-traffic
 # figure needs (FETCH_SIZE and WRITE_SIZE do not fit one pass).  Then, back in the
 # container:  python tools/summarize_profile.py rNN
-R=${1:-r01}
+R=${1:-r02}
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$ROOT"
 mkdir -p gpurun_out

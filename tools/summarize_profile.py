@@ -32,25 +32,40 @@ def one(pattern):
     return max(hits, key=os.path.getmtime)  # a directory may hold several runs: newest
 
 
+def full_launch(row):
+    """A launch of a whole call (steps_per_call x B utterances: one workgroup per CU);
+    the bench also launches single batches of B utterances for its single-batch figure."""
+    g = row.get("Grid_Size_X") or row.get("Grid_Size")
+    w = row.get("Workgroup_Size_X") or row.get("Workgroup_Size")
+    try:
+        return int(g) // int(w) >= 256
+    except (TypeError, ValueError, ZeroDivisionError):
+        return True
+
+
 def counter(path, name):
     rows = [r for r in csv.DictReader(open(path))
-            if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name]
-    # the search kernel is launched once for InitDecoding (tiny) and once per step
-    vals = sorted(float(r["Counter_Value"]) for r in rows)
-    big = vals[len(vals) // 2:]
-    return sum(big) / len(big), len(big)
+            if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name and full_launch(r)]
+    vals = [float(r["Counter_Value"]) for r in rows]
+    return sum(vals) / len(vals), len(vals)
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     stats = one(f"prof_{rnd}_trace/*/*_kernel_stats.csv")
     trace = one(f"prof_{rnd}_trace/*/*_kernel_trace.csv")
     shutil.copy(stats, os.path.join(out, f"{rnd}_kernel_stats.csv"))
-    durs = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-                  for r in csv.DictReader(open(trace)) if KERNEL in r["Kernel_Name"])
-    adv = durs[len(durs) // 2:]  # every step launches the kernel twice: InitDecoding (short), then the frames
+    rows = [r for r in csv.DictReader(open(trace)) if KERNEL in r["Kernel_Name"]]
+    dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6  # noqa: E731
+    full = sorted(dur(r) for r in rows if full_launch(r))
+    single = sorted(dur(r) for r in rows if not full_launch(r))
+    # GPU time by kernel (everything the process launched)
+    by = {}
+    for r in csv.DictReader(open(trace)):
+        by[r["Kernel_Name"][:60]] = by.get(r["Kernel_Name"][:60], 0.0) + dur(r)
+    tot = sum(by.values())
     fetch_kb, nf = counter(one(f"prof_{rnd}_fetch/*/*_counter_collection.csv"), "FETCH_SIZE")
     write_kb, nw = counter(one(f"prof_{rnd}_write/*/*_counter_collection.csv"), "WRITE_SIZE")
     bench = {}
@@ -64,17 +79,23 @@ def main():
         "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu "
                    "(+ one run each with --pmc FETCH_SIZE / --pmc WRITE_SIZE)",
         "kernel": KERNEL,
-        "advance_launches": len(adv),
-        "avg_launch_ms": sum(adv) / len(adv),
-        "min_launch_ms": adv[0], "max_launch_ms": adv[-1],
+        "full_launches": len(full),
+        "avg_launch_ms": sum(full) / len(full),
+        "min_launch_ms": full[0], "max_launch_ms": full[-1],
+        "single_batch_launches": len(single),
+        "avg_single_batch_launch_ms": sum(single) / len(single) if single else None,
+        "gpu_time_share_by_kernel": {k: v / tot for k, v in sorted(by.items(), key=lambda kv: -kv[1])},
         "FETCH_SIZE_KiB_per_launch": fetch_kb,
         "WRITE_SIZE_KiB_per_launch": write_kb,
+        "pmc_launches_averaged": [nf, nw],
         "hbm_read_bytes_per_launch": 2 * fetch_kb * 1024,
         "hbm_write_bytes_per_launch": write_kb * 1024,
         "hbm_bytes_per_launch": 2 * fetch_kb * 1024 + write_kb * 1024,
-        "note": "reads use the guide's gfx950 x2 FETCH_SIZE correction, calibrated there on wide "
-                "coalesced 16 B/lane streams; this kernel's reads are 16 B/lane gathers, so the "
-                "absolute read figure is an upper estimate (raw counter is half of it)",
+        "note": "per launch of a whole call (the bench's steps_per_call x B utterances).  Reads use "
+                "the guide's gfx950 x2 FETCH_SIZE correction, calibrated there on wide coalesced 16 "
+                "B/lane streams; this kernel's reads are 16 B/lane gathers, so the absolute read "
+                "figure is an upper estimate (raw counter is half of it).  Counter passes serialise "
+                "the launches; the trace pass does not (launches of calls in flight overlap).",
         "bench_line_under_profiler": bench,
     }
     with open(os.path.join(out, f"{rnd}_summary.json"), "w") as f:
