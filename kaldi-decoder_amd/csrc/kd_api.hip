@@ -693,7 +693,7 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device) != hipSuccess || cus <= 0)
     cus = 256;
-  b->workgroups = std::min<int>(max_batch, cus);
+  b->workgroups = std::min<int>(max_batch, cus * SearchWorkgroupsPerCu());
   // pools: 2^17 token records per utterance to begin with (an HLG decode at beam 15 writes
   // about 10^5 per 10 s utterance), two links per token; both grow on demand
   uint64_t tok = b->o.arena_tokens > 0 ? static_cast<uint64_t>(b->o.arena_tokens)

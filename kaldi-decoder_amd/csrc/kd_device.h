@@ -216,6 +216,7 @@ struct PathParams {
 // `workgroups` persistent workgroups take the batch's utterances from the work queue.
 hipError_t LaunchSearch(const SearchParams &p, int workgroups, hipStream_t stream);
 size_t SearchLdsBytes();
+int SearchWorkgroupsPerCu();  // resident workgroups a CU holds (build geometry)
 hipError_t LaunchPathPrepare(const PathParams &p, int batch, hipStream_t stream);
 hipError_t LaunchPathFill(const PathParams &p, int batch, hipStream_t stream);
 

@@ -28,7 +28,9 @@
 #ifndef KD_LEPS_REGS
 #define KD_LEPS_REGS 4
 #endif
-constexpr int kLdsToks = 36864;  // extra-cost keys of one frame kept in LDS (144 KiB)
+// extra-cost keys of one frame kept in LDS: what the search's LDS block holds (144 KiB of
+// 160 with one workgroup per CU)
+constexpr int kLdsToks = ((static_cast<int>(sizeof(Shared)) - 512) / 4) / 2048 * 2048;
 constexpr uint32_t kFInfKey = 0xFF800000u;  // FloatKey(+inf)
 constexpr int kEpsRegs = KD_LEPS_REGS;  // epsilon links of a frame a lane keeps in registers
 

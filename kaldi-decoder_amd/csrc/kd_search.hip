@@ -2270,18 +2270,29 @@ __device__ __noinline__ uint32_t FrameBackSpill(CParams *pp, int utt, long long 
   cnt.tokens_expanded = n_expanded;
   cnt.arcs_scanned = n_arcs;
   const long long gslots = 1ll << p.g_log2_slots, wg = blockIdx.x;
-  Table<false> tg{s, ToG(p.g_key) + wg * gslots, ToG(p.g_cost) + wg * gslots,
-                  ToG(p.g_arc) + wg * gslots, reinterpret_cast<uint32_t *>(s.cost),
-                  p.g_log2_slots, static_cast<uint32_t>(gslots - 1)};
-  uint32_t r = FrameBack<false>(c, tg, frame, q_emit, cnt);
-  if (r != 0) {
+  // The table is as large as the frame needs, not as large as it could be: a frame of
+  // 8 k tokens hashes into 32 k slots (512 KiB of key / cost / arc words, which stay in
+  // the XCD's L2) instead of scattering its atomics over all 2^17..2^19 slots (2-8 MiB:
+  // every one of them a memory transaction), and the worklist bitmask that each epsilon
+  // round clears shrinks with it.  The emitting candidates bound the emitting tokens;
+  // the epsilon closure may add more: a frame that outgrows the guess runs again in the
+  // whole table.
+  int lg = 14;
+  while ((1 << lg) < 2 * q_emit && lg < p.g_log2_slots) ++lg;
+  uint32_t r;
+  while (true) {
+    Table<false> tg{s, ToG(p.g_key) + wg * gslots, ToG(p.g_cost) + wg * gslots,
+                    ToG(p.g_arc) + wg * gslots, reinterpret_cast<uint32_t *>(s.cost),
+                    lg, (1u << lg) - 1u};
+    r = FrameBack<false>(c, tg, frame, q_emit, cnt);
+    if (r == 0) break;
     // Leave the global table clean: this workgroup goes on with other utterances of the
     // work queue (and, after the host has grown what ran out, with this one).  A frame
     // that ran out of token or link records has a complete live list; one that overflowed
     // the table itself has claimed slots that are on no list, so all of it is wiped.
     __syncthreads();
     if (r == kRetry) {
-      for (long long h = threadIdx.x; h < gslots; h += kBlock) {
+      for (long long h = threadIdx.x; h < (1ll << lg); h += kBlock) {
         tg.StoreKey(static_cast<uint32_t>(h), kKeyEmpty);
         tg.StoreCost(static_cast<uint32_t>(h), kCostDead);
         tg.StoreArc(static_cast<uint32_t>(h), kArcNone);
@@ -2291,6 +2302,24 @@ __device__ __noinline__ uint32_t FrameBackSpill(CParams *pp, int utt, long long 
                                                                    : static_cast<int>(tg.FillLimit());
       ClearLive<false>(c, tg, used);
     }
+    if (r != kRetry || lg == p.g_log2_slots) break;
+    // once more, in the whole table (the queue's emitting part is intact; its
+    // destination words now hold slots of the table just wiped: replay from the arcs)
+    lg = p.g_log2_slots;
+    if (threadIdx.x == 0) {
+      s.q_n = q_emit;
+      s.n_live = 0;
+      s.overflow = 0;
+      s.wl_count[0] = 0;
+      s.wl_count[1] = 0;
+      s.n_emit_links = 0;
+      s.n_eps_links = 0;
+      s.n_emit_written = 0;
+    }
+    c.replay = true;
+    cnt.eps_exp = 0;
+    cnt.eps_arcs = 0;
+    __syncthreads();
   }
   __syncthreads();
   return r == kRetry ? static_cast<uint32_t>(KD_UTT_TABLE_FULL) : r;
@@ -2678,6 +2707,7 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
 }  // namespace
 
 size_t SearchLdsBytes() { return sizeof(Shared); }
+int SearchWorkgroupsPerCu() { return KD_WG_PER_CU; }
 
 namespace {
 template <int M>
