@@ -320,7 +320,8 @@ def main():
         once (kd_batch_decode_async)."""
         n = n_steps * B
         bts[slot].decode_device(ptrs_of[slot][:n], [T] * n, V, finalize=not args.search_only,
-                                lattice=not args.search_only, sync=False)
+                                lattice=not args.search_only, best_path=not args.search_only,
+                                sync=False)
 
     def collect(slot):
         """Waits for the slot's call and takes its results to the host."""

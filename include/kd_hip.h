@@ -147,13 +147,15 @@ int kd_batch_sync(kd_batch *b);
  * csrc/lattice-simple-decoder.cc:53-73) for utterances [0, batch) as ONE kernel launch:
  * InitDecoding, AdvanceDecoding over every row and -- lattice batches, as `want` asks --
  * FinalizeDecoding (the reference's Decode() always finalizes, :68) and GetRawLattice
- * (use_final_probs = true) into the batch's output pool, each by the workgroup that
- * decoded the utterance.  Device pointers only; enqueues and returns, pair with
+ * (use_final_probs = true) into the batch's output pool -- 1-best batches: ReachedFinal
+ * and GetBestPath(use_final_probs = true) -- each by the workgroup that decoded the
+ * utterance.  Device pointers only; enqueues and returns, pair with
  * kd_batch_sync.  Afterwards kd_batch_raw_lattice_prepare / _copy (or the best-path
  * calls) only move results; no further kernel runs.  The batch may hold any number of
  * utterances: one launch keeps one workgroup per CU busy from a work queue. */
-#define KD_DECODE_FINALIZE 1
-#define KD_DECODE_LATTICE 2
+#define KD_DECODE_FINALIZE 1   /* lattice batches: FinalizeDecoding                        */
+#define KD_DECODE_LATTICE 2    /* lattice batches: GetRawLattice(use_final_probs = true)  */
+#define KD_DECODE_BEST_PATH 4  /* 1-best batches: ReachedFinal + GetBestPath(true)         */
 int kd_batch_decode_async(kd_batch *b, int32_t batch, const float *const *loglikes_dev,
                           const int32_t *num_rows, const int32_t *offset, int32_t num_cols,
                           int64_t row_stride, int32_t want);

@@ -115,12 +115,6 @@ struct kd_batch {
   std::vector<int32_t> h_lat_sizes;
   std::vector<long long> h_lat_off;
   DevBuf<float> staging;
-  // path outputs
-  DevBuf<int32_t> reached_final, path_len;
-  DevBuf<long long> best_tok, path_offset;
-  DevBuf<float> final_weight, final_rel;
-  DevBuf<int32_t> o_ilabel, o_olabel, o_state;
-  DevBuf<float> o_graph, o_ac;
   // host mirrors
   std::vector<int32_t> h_decoded, h_path_len, h_reached;
   std::vector<uint32_t> h_status;
@@ -226,37 +220,6 @@ struct kd_batch {
     p.lat.frame_arc_off = frame_arc_off.p;
     p.lat.out = out_pool;
     p.lat.out_cap = out_cap;
-    return p;
-  }
-
-  PathParams PParams(int use_final) const {
-    PathParams p{};
-    p.states = g->states.p;
-    p.arcs = g->arcs.p;
-    p.tok_state = tok_state.p;
-    p.tok_cost = tok_cost.p;
-    p.tok_prev = tok_prev.p;
-    p.tok_arc = tok_arc.p;
-    p.frame_base = frame_base.p;
-    p.frame_count = frame_count.p;
-    p.max_frames = o.max_frames;
-    p.frames_decoded = frames_decoded.p;
-    p.use_final_probs = use_final;
-    p.batch = batch;
-    p.simple = simple ? 1 : 0;
-    p.no_backptr = lattice ? 1 : 0;
-    p.tok_ac = tok_extra.p;
-    p.final_rel = final_rel.p;
-    p.reached_final = reached_final.p;
-    p.best_tok = best_tok.p;
-    p.path_len = path_len.p;
-    p.final_weight = final_weight.p;
-    p.path_offset = path_offset.p;
-    p.o_ilabel = o_ilabel.p;
-    p.o_olabel = o_olabel.p;
-    p.o_state = o_state.p;
-    p.o_graph = o_graph.p;
-    p.o_ac = o_ac.p;
     return p;
   }
 };
@@ -502,6 +465,18 @@ int ReadBack(kd_batch *b) {
         b->exported_use_final = (b->l_tail_flags & kUttExport) ? 1 : 0;
       }
     }
+    if (!b->lattice && (b->l_tail_flags & kUttBestPath) && !any) {
+      for (int i = 0; i < b->batch; ++i) {
+        b->h_path_len[i] = uo[i].sizes[0];
+        b->h_reached[i] = uo[i].sizes[1];
+        std::memcpy(&b->h_final_weight[2 * i], &uo[i].sizes[2], 4);
+        b->h_final_weight[2 * i + 1] = 0.0f;
+        b->h_path_final_rel[i] = uo[i].final_rel;
+        b->h_lat_off[i] = uo[i].out_off;
+      }
+      b->path_valid = true;
+      b->path_use_final = (b->l_tail_flags & kUttPathNoFinal) ? 0 : 1;
+    }
     if (!any) return KD_OK;
     if (b->o.no_grow || (any & ~kRecoverable)) return Fail(KD_E_CAPACITY, StatusMessage(b, first_bad));
     if (any & KD_UTT_ARENA_FULL)
@@ -722,12 +697,6 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   A(b->mem.Alloc(max_batch));
   A(b->stats.Alloc(static_cast<size_t>(max_batch) * kStatStride));
   A(AllocTables(b, lg));
-  A(b->reached_final.Alloc(max_batch));
-  A(b->path_len.Alloc(max_batch));
-  A(b->best_tok.Alloc(max_batch));
-  A(b->path_offset.Alloc(max_batch));
-  A(b->final_weight.Alloc(2 * static_cast<size_t>(max_batch)));
-  A(b->final_rel.Alloc(max_batch));
   // launch control: the pinned block the GPU addresses directly, and the device counters
   b->off_order = static_cast<size_t>(max_batch) * sizeof(UttCtl);
   b->off_out = (b->off_order + static_cast<size_t>(max_batch) * sizeof(int32_t) + 15) & ~size_t(15);
@@ -742,13 +711,16 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   if (e == hipSuccess) e = hipMemset(b->status.p, 0, b->status.bytes());
   if (e == hipSuccess) e = hipMemset(b->stats.p, 0, b->stats.bytes());
   if (e == hipSuccess) e = hipMemset(b->mem.p, 0, b->mem.bytes());
+  // output pool (pinned): exported lattices, or best paths (three words an arc)
+  b->out_cap = std::max<uint64_t>(1ull << 16, static_cast<uint64_t>(max_batch) << (lopts ? 13 : 11));
+  A(hipHostMalloc(reinterpret_cast<void **>(&b->out_pool), b->out_cap * 8, hipHostMallocDefault));
+  b->h_lat_off.assign(max_batch, -1);
   if (e == hipSuccess) e = hipEventCreate(&b->ev0);
   if (e == hipSuccess) e = hipEventCreate(&b->ev1);
   if (e == hipSuccess && lopts) {
     uint64_t links = lopts->arena_links > 0 ? static_cast<uint64_t>(lopts->arena_links) : 2 * b->tok_cap;
     b->link_cap = std::min<uint64_t>(links, kIndexLimit);
     b->lo.arena_links = static_cast<int64_t>(b->link_cap);
-    b->out_cap = std::max<uint64_t>(1ull << 16, static_cast<uint64_t>(max_batch) << 13);
     A(b->tok_newid.Alloc(b->tok_cap));
     A(b->lat_scratch.Alloc(b->tok_cap));
     A(b->link_src.Alloc(b->link_cap));
@@ -757,7 +729,6 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
     A(b->link_ac.Alloc(b->link_cap));
     A(b->link_graph.Alloc(b->link_cap));
     A(b->link_delta.Alloc(b->link_cap));
-    A(hipHostMalloc(reinterpret_cast<void **>(&b->out_pool), b->out_cap * 8, hipHostMallocDefault));
     A(b->link_emit_base.Alloc(nf));
     A(b->link_emit_count.Alloc(nf));
     A(b->link_eps_base.Alloc(nf));
@@ -772,7 +743,6 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
     if (e == hipSuccess) e = hipMemset(b->link_eps_count.p, 0, b->link_eps_count.bytes());
     if (e == hipSuccess) e = hipMemset(b->lat_finalized.p, 0, b->lat_finalized.bytes());
     b->h_lat_sizes.assign(4 * static_cast<size_t>(max_batch), 0);
-    b->h_lat_off.assign(max_batch, -1);
   }
   if (e != hipSuccess) {
     delete b;
@@ -894,7 +864,7 @@ int kd_batch_init_decoding(kd_batch *b, int32_t batch) {
 
 static uint32_t TailFlags(const kd_batch *b, int32_t want) {
   uint32_t t = 0;
-  if (!b->lattice) return 0;
+  if (!b->lattice) return (want & KD_DECODE_BEST_PATH) ? kUttBestPath : 0u;
   if (want & KD_DECODE_FINALIZE) t |= kUttFinalize;
   if (want & KD_DECODE_LATTICE) t |= kUttExport;
   return t;
@@ -1027,19 +997,10 @@ static int PreparePath(kd_batch *b, int32_t use_final_probs) {
   if (b->pending)
     if (int r = ReadBack(b)) return r;
   if (b->path_valid && b->path_use_final == use_final_probs) return KD_OK;
-  KD_HIP_TRY(LaunchPathPrepare(b->PParams(use_final_probs), b->batch, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(b->h_path_len.data(), b->path_len.p, b->batch * sizeof(int32_t),
-                            hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(b->h_reached.data(), b->reached_final.p, b->batch * sizeof(int32_t),
-                            hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(b->h_final_weight.data(), b->final_weight.p,
-                            2 * b->batch * sizeof(float), hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(b->h_path_final_rel.data(), b->final_rel.p, b->batch * sizeof(float),
-                            hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipStreamSynchronize(b->stream));
-  b->path_valid = true;
-  b->path_use_final = use_final_probs;
-  return KD_OK;
+  // a launch in which every utterance only runs its tail: best token, traceback, arcs
+  b->out_base = b->out_raw;  // the pool is rewritten from its start
+  b->h_out_top = 0;
+  return LaunchTail(b, kUttBestPath | (use_final_probs ? 0u : kUttPathNoFinal));
 }
 
 int kd_batch_reached_final(kd_batch *b, int32_t *out) {
@@ -1064,43 +1025,23 @@ int kd_batch_best_path_copy(kd_batch *b, const int64_t *path_offset, int32_t *il
                             int32_t *olabel, int32_t *state, float *graph_cost, float *ac_cost,
                             float *final_weight) {
   if (!b || !path_offset) return Fail(KD_E_INVALID, "bad argument");
-  if (!b->path_valid) return Fail(KD_E_STATE, "call kd_batch_best_path_prepare first");
-  KD_HIP_TRY(hipSetDevice(b->g->device));
-  // device-side packing is dense in utterance order; scatter to the caller's offsets on the host
-  std::vector<long long> doff(b->batch);
-  size_t total = 0;
-  for (int i = 0; i < b->batch; ++i) {
-    doff[i] = static_cast<long long>(total);
-    total += b->h_path_len[i] > 0 ? b->h_path_len[i] : 0;
-  }
+  if (!b->path_valid || b->pending) return Fail(KD_E_STATE, "call kd_batch_best_path_prepare first");
   if (final_weight)
     std::memcpy(final_weight, b->h_final_weight.data(), 2 * b->batch * sizeof(float));
-  if (total == 0) return KD_OK;
-  KD_HIP_TRY(b->o_ilabel.Reserve(total));
-  KD_HIP_TRY(b->o_olabel.Reserve(total));
-  KD_HIP_TRY(b->o_state.Reserve(total));
-  KD_HIP_TRY(b->o_graph.Reserve(total));
-  KD_HIP_TRY(b->o_ac.Reserve(total));
-  KD_HIP_TRY(hipMemcpyAsync(b->path_offset.p, doff.data(), b->batch * sizeof(long long),
-                            hipMemcpyHostToDevice, b->stream));
-  KD_HIP_TRY(LaunchPathFill(b->PParams(b->path_use_final), b->batch, b->stream));
-  std::vector<int32_t> hi(total), ho(total), hs(total);
-  std::vector<float> hg(total), ha(total);
-  KD_HIP_TRY(hipMemcpyAsync(hi.data(), b->o_ilabel.p, total * 4, hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(ho.data(), b->o_olabel.p, total * 4, hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(hs.data(), b->o_state.p, total * 4, hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(hg.data(), b->o_graph.p, total * 4, hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipMemcpyAsync(ha.data(), b->o_ac.p, total * 4, hipMemcpyDeviceToHost, b->stream));
-  KD_HIP_TRY(hipStreamSynchronize(b->stream));
+  // an utterance's region of the (pinned) output pool: {ilabel, olabel} {state, graph} {ac, -}
   for (int i = 0; i < b->batch; ++i) {
     const int32_t n = b->h_path_len[i];
-    if (n <= 0) continue;
-    const size_t s = static_cast<size_t>(doff[i]), d = static_cast<size_t>(path_offset[i]);
-    if (ilabel) std::memcpy(ilabel + d, hi.data() + s, n * 4);
-    if (olabel) std::memcpy(olabel + d, ho.data() + s, n * 4);
-    if (state) std::memcpy(state + d, hs.data() + s, n * 4);
-    if (graph_cost) std::memcpy(graph_cost + d, hg.data() + s, n * 4);
-    if (ac_cost) std::memcpy(ac_cost + d, ha.data() + s, n * 4);
+    if (n <= 0 || b->h_lat_off[i] < 0) continue;
+    const int32_t *w = reinterpret_cast<const int32_t *>(b->out_pool + b->h_lat_off[i]);
+    const size_t d = static_cast<size_t>(path_offset[i]);
+    for (int32_t k = 0; k < n; ++k) {
+      const int32_t *a = w + 6 * k;
+      if (ilabel) ilabel[d + k] = a[0];
+      if (olabel) olabel[d + k] = a[1];
+      if (state) state[d + k] = a[2];
+      if (graph_cost) std::memcpy(graph_cost + d + k, a + 3, 4);
+      if (ac_cost) std::memcpy(ac_cost + d + k, a + 4, 4);
+    }
   }
   return KD_OK;
 }

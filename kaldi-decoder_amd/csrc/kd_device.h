@@ -63,6 +63,8 @@ constexpr uint32_t kUttFinalStats = 2u;  // ComputeFinalCosts / FinalRelativeCos
 constexpr uint32_t kUttFinalize = 4u;    // FinalizeDecoding when the target is reached
 constexpr uint32_t kUttExport = 8u;      // GetRawLattice into the output pool
 constexpr uint32_t kUttExportNoFinal = 16u;  // ... with use_final_probs == false
+constexpr uint32_t kUttBestPath = 32u;       // 1-best decoders: ReachedFinal + GetBestPath into the pool
+constexpr uint32_t kUttPathNoFinal = 64u;    // ... with use_final_probs == false
 
 struct BatchCtl {
   uint32_t work_ctr;             // work queue: positions of `order` handed out, ever
@@ -184,41 +186,11 @@ struct SearchParams {
   LatticeParams lat;
 };
 
-struct PathParams {
-  const StateRec *states;
-  const ArcRec *arcs;
-  const int32_t *tok_state;
-  const double *tok_cost;
-  const int32_t *tok_prev;
-  const int32_t *tok_arc;
-  const long long *frame_base;
-  const int32_t *frame_count;
-  int32_t max_frames;
-  const int32_t *frames_decoded;
-  int32_t use_final_probs;
-  int32_t batch;
-  int32_t simple;            // SimpleDecoder: per-arc costs are the stored ones
-  int32_t no_backptr;        // lattice batches keep forward links, not back-pointers: no walk
-  const float *tok_ac;       // [arena] acoustic cost of the arc that made each token (simple mode)
-  float *final_rel;          // [batch] FinalRelativeCost (simple-decoder.cc:78-100)
-  // outputs of the prepare step
-  int32_t *reached_final;  // [batch]
-  long long *best_tok;     // [batch] arena index or -1
-  int32_t *path_len;       // [batch]
-  float *final_weight;     // [batch][2]
-  // fill step
-  const long long *path_offset;
-  int32_t *o_ilabel, *o_olabel, *o_state;
-  float *o_graph, *o_ac;
-};
-
-// Launchers implemented in kd_search.hip / kd_path.hip
+// Launcher implemented in kd_search.hip
 // `workgroups` persistent workgroups take the batch's utterances from the work queue.
 hipError_t LaunchSearch(const SearchParams &p, int workgroups, hipStream_t stream);
 size_t SearchLdsBytes();
 int SearchWorkgroupsPerCu();  // resident workgroups a CU holds (build geometry)
-hipError_t LaunchPathPrepare(const PathParams &p, int batch, hipStream_t stream);
-hipError_t LaunchPathFill(const PathParams &p, int batch, hipStream_t stream);
 
 // Order-preserving map double -> uint64 (so integer atomicMin orders costs).
 __host__ __device__ inline unsigned long long CostKey(double d) {

@@ -2411,6 +2411,7 @@ __device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long 
 }
 
 #include "kd_lattice_tail.h"
+#include "kd_path_tail.h"
 
 // What one workgroup does for one utterance of the work queue: InitDecoding if asked,
 // the frames up to the utterance's target, then -- lattice decoders, when asked -- the
@@ -2662,6 +2663,20 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       o.final_rel = ts.r_final_rel;
     }
     if (Uni(ToG(p.lat.finalized)[utt]) != 0) o.phase = kPhaseFinalized;
+  } else {
+    // 1-best decoders: ReachedFinal and GetBestPath of what has been decoded so far
+    if (err == 0 && frame == target && frame >= 0 && (ud.flags & kUttBestPath)) {
+      __syncthreads();
+      const uint32_t e = Uni(PathTail(&p, utt, frame, ud.flags));
+      __syncthreads();
+      if (e && tid == 0) ToG(p.status)[utt] = e;
+      const TailShared &ts = TailLds();
+      o.status = e;
+      o.sizes[0] = ts.r_sizes[0]; o.sizes[1] = ts.r_sizes[1];
+      o.sizes[2] = ts.r_sizes[2]; o.sizes[3] = ts.r_sizes[3];
+      o.out_off = ts.r_out_off;
+      o.final_rel = ts.r_final_rel;
+    }
   }
   if (tid == 0) p.out[utt] = o;
 }

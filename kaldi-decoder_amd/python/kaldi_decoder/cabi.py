@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("KD_HIP_LIB", "libkd_hip.so
 
 INT_MAX = 2**31 - 1
 KD_MEM_HOST, KD_MEM_DEVICE = 0, 1
-KD_DECODE_FINALIZE, KD_DECODE_LATTICE = 1, 2
+KD_DECODE_FINALIZE, KD_DECODE_LATTICE, KD_DECODE_BEST_PATH = 1, 2, 4
 CAPACITY_NAMES = ("arena_tokens", "arena_links", "table_slots", "max_frames", "tokens_used",
                   "links_used", "grow_events", "workgroups")
 STAT_NAMES = ("frames", "tokens_in", "tokens_expanded", "arcs_scanned", "arcs_kept",
@@ -289,13 +289,15 @@ class Batch:
         _check(fn(*args))
 
     def decode_device(self, dev_ptrs, num_rows, num_cols, row_stride=None, offsets=None,
-                      finalize=True, lattice=True, sync=True):
+                      finalize=True, lattice=True, best_path=True, sync=True):
         """Decode() of every utterance in one launch (kd_batch_decode_async): InitDecoding,
-        every frame and, for lattice batches, FinalizeDecoding / GetRawLattice as asked."""
+        every frame and, as asked, FinalizeDecoding / GetRawLattice (lattice batches) or
+        ReachedFinal / GetBestPath (1-best batches)."""
         rows = np.ascontiguousarray(num_rows, np.int32)
         self.batch = len(rows)
         off = None if offsets is None else np.ascontiguousarray(offsets, np.int32)
-        want = (KD_DECODE_FINALIZE if finalize else 0) | (KD_DECODE_LATTICE if lattice else 0)
+        want = ((KD_DECODE_FINALIZE if finalize else 0) | (KD_DECODE_LATTICE if lattice else 0) |
+                (KD_DECODE_BEST_PATH if best_path else 0))
         _check(lib().kd_batch_decode_async(self.h, self.batch, self._ptrs(list(dev_ptrs)), rows,
                                            None if off is None else off.ctypes.data, num_cols,
                                            num_cols if row_stride is None else row_stride, want))
