@@ -255,6 +255,9 @@ def main():
                          "collects them in order")
     ap.add_argument("--min-seconds", type=float, default=2.5,
                     help="repeat the K timed steps until the timed region lasts this long")
+    ap.add_argument("--prune-interval", type=int, default=0,
+                    help="lattice workloads: PruneActiveTokens every this many frames (0: the "
+                         "workload's setting)")
     ap.add_argument("--search-only", action="store_true",
                     help="diagnostic: time InitDecoding + AdvanceDecoding only (not a bench line)")
     args = ap.parse_args()
@@ -311,7 +314,10 @@ def main():
     ptrs_of = [[d[i].data_ptr() for i in range(per_slot)] for d in devs]
     streams = [torch.cuda.Stream() for _ in range(n_fly)]
     cls = cabi.LatticeBatch if wl["lattice"] else cabi.Batch
-    bts = [cls(Gr, max_batch=per_slot, max_frames=T, stream=st.cuda_stream, **wl["opts"])
+    opts = dict(wl["opts"])
+    if wl["lattice"] and args.prune_interval:
+        opts["prune_interval"] = args.prune_interval
+    bts = [cls(Gr, max_batch=per_slot, max_frames=T, stream=st.cuda_stream, **opts)
            for st in streams]
     setup_s = time.time() - t0
 

@@ -67,6 +67,9 @@ struct kd_batch {
   int workgroups = 1;  // persistent workgroups of a launch == owners of the scratch regions
   // ---- pools (shared by the utterances; grown on demand, see GrowPools)
   uint64_t tok_cap = 0, link_cap = 0, out_cap = 0;
+  // records an utterance takes from a pool at a time (fixed when the batch is created:
+  // freed chunks are reused as chunks of exactly this size)
+  int32_t tok_chunk = 8192, link_chunk = 16384;
   DevBuf<int32_t> tok_state, tok_prev, tok_arc;
   DevBuf<double> tok_cost;
   DevBuf<float> tok_extra;
@@ -162,7 +165,7 @@ struct kd_batch {
     // a chunk is what an utterance takes from a pool at a time: large enough that the
     // atomic is rare, small enough that what is left over when the utterance ends is
     // nothing against the pool
-    p.tok_chunk = static_cast<int32_t>(std::min<uint64_t>(8192, std::max<uint64_t>(64, tok_cap / (8ull * workgroups))));
+    p.tok_chunk = tok_chunk;
     p.frame_base = frame_base.p;
     p.frame_count = frame_count.p;
     p.max_frames = o.max_frames;
@@ -203,12 +206,13 @@ struct kd_batch {
     p.link_graph = link_graph.p;
     p.link_delta = link_delta.p;
     p.link_cap = link_cap;
-    p.link_chunk = static_cast<int32_t>(std::min<uint64_t>(16384, std::max<uint64_t>(64, link_cap / (8ull * workgroups))));
+    p.link_chunk = link_chunk;
     p.link_emit_base = link_emit_base.p;
     p.link_emit_count = link_emit_count.p;
     p.link_eps_base = link_eps_base.p;
     p.link_eps_count = link_eps_count.p;
     p.lat.lattice_beam = lo.lattice_beam;
+    p.lat.prune_interval = lattice && lo.prune_interval > 0 ? lo.prune_interval : 0x7FFFFFFF;
     p.lat.tok_extra = tok_extra.p;
     p.lat.tok_newid = tok_newid.p;
     p.lat.scratch = lat_scratch.p;
@@ -675,6 +679,7 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
                                         : std::max<uint64_t>(1ull << 20, static_cast<uint64_t>(max_batch) << 17);
   b->tok_cap = std::min<uint64_t>(tok, kIndexLimit);
   b->o.arena_tokens = static_cast<int64_t>(b->tok_cap);
+  b->tok_chunk = static_cast<int32_t>(std::min<uint64_t>(8192, std::max<uint64_t>(64, b->tok_cap / (8ull * b->workgroups))));
   if (b->o.max_frames <= 0) b->o.max_frames = 2048;
   int slots = b->o.table_slots <= 0 ? (1 << 17) : b->o.table_slots;
   int lg = 14;
@@ -721,6 +726,7 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
     uint64_t links = lopts->arena_links > 0 ? static_cast<uint64_t>(lopts->arena_links) : 2 * b->tok_cap;
     b->link_cap = std::min<uint64_t>(links, kIndexLimit);
     b->lo.arena_links = static_cast<int64_t>(b->link_cap);
+    b->link_chunk = static_cast<int32_t>(std::min<uint64_t>(16384, std::max<uint64_t>(64, b->link_cap / (8ull * b->workgroups))));
     A(b->tok_newid.Alloc(b->tok_cap));
     A(b->lat_scratch.Alloc(b->tok_cap));
     A(b->link_src.Alloc(b->link_cap));

@@ -88,16 +88,35 @@ struct UttOut {
 };
 constexpr int32_t kPhaseDecoding = 0, kPhaseFinalized = 1;
 
-// Per-utterance allocation state, device resident: the chunk of each pool the
-// utterance is filling.  Frames take contiguous blocks from it; a block that does not
-// fit takes a new chunk from the pool with one atomic (BatchCtl::tok_top / link_top).
+// Per-utterance allocation state, device resident.  Frames take contiguous blocks from
+// the chunk of each pool the utterance is filling (its "nursery"); a block that does not
+// fit takes a new chunk -- one the utterance has freed itself, or else the next of the
+// pool (one atomic on BatchCtl::tok_top / link_top).  Lattice decoders with periodic
+// pruning also keep an "archive": what survives of frames older than prune_interval is
+// moved there (compacted), and nursery chunks that hold nothing but such frames go on
+// the utterance's own free list, so an utterance's footprint follows its pruned lattice
+// plus a window of recent frames, not its length.
+constexpr int kChunkRing = 48;
+struct ChunkRing {
+  int32_t n_retired, n_free;
+  int32_t retired_start[kChunkRing];  // full nursery chunks, oldest first ...
+  int32_t retired_last[kChunkRing];   // ... and the last frame (plus one) that has a block in each
+  int32_t free_start[kChunkRing];     // chunks ready to be used again
+};
 struct UttMem {
-  long long arena_next, arena_end;
-  long long link_next, link_end;
+  long long arena_next, arena_end;   // token nursery: the chunk being filled
+  long long link_next, link_end;     // link nursery
+  long long atok_next, atok_end;     // token archive
+  long long alink_next, alink_end;   // link archive
+  int32_t arena_chunk, link_chunk;   // start of the nursery chunks if they are of standard size, else -1
+  int32_t visited;    // frames <= this have been through a periodic sweep
+  int32_t gc_frame;   // frames < this are in the archive
+  ChunkRing tok, link;
 };
 
 struct LatticeParams {
   float lattice_beam;
+  int32_t prune_interval;    // PruneActiveTokens every this many frames (lattice-simple-decoder.cc:57-59)
   float *tok_extra;
   int32_t *tok_newid;        // [token pool] state id in the exported lattice, -1 if pruned
   uint32_t *scratch;         // [token pool] per-frame extra-cost keys beyond LDS

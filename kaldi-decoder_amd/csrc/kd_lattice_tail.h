@@ -38,7 +38,8 @@ struct TailShared {
   uint32_t ne[kLdsToks];
   int32_t red_i[kWaves];
   uint32_t best_key, bestwf_key;
-  int32_t any_final, changed, count, start_id, empty_frame;
+  int32_t any_final, changed, count, start_id, empty_frame, frame_changed;
+  uint32_t alloc_err;
   int32_t n_finals;
   int32_t n_tok_staged, n_arc_staged, stage_overflow;
   long long out_off;
@@ -87,7 +88,8 @@ static_assert(kWaves <= 16, "BlockExclScanI scans at most 16 wave totals");
 // (every lane issues every load -- a lane without a link reads a valid dummy --
 // because hipcc waits for a conditional load before it issues the next).
 __device__ __forceinline__ void ApplyLinks(CParams &p, TailShared &s, KD_G uint32_t *ne,
-                                           bool ne_in_lds, long long lb, int ln, long long base) {
+                                           bool ne_in_lds, long long lb, int ln, long long base,
+                                           bool note_change = false) {
   constexpr int U = 4;
   const float lattice_beam = p.lat.lattice_beam;
   for (int i0 = threadIdx.x; i0 < ln; i0 += U * kBlock) {
@@ -112,6 +114,7 @@ __device__ __forceinline__ void ApplyLinks(CParams &p, TailShared &s, KD_G uint3
       float link_extra_cost = next_extra[u] + delta[u];
       if (link_extra_cost > lattice_beam) {  // :264 excise
         ToG(p.link_dst)[lb + i0 + u * kBlock] = -1;
+        if (note_change) s.frame_changed = 1;
         continue;
       }
       if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
@@ -191,11 +194,25 @@ __device__ __forceinline__ void StageArc(TailShared &s, const Stage &st, long lo
   else s.stage_overflow = 1;
 }
 
-// FinalizeDecoding: the exact backward sweep over all frames.
-__device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt, int F,
-                                             float final_best_cost, bool any_final, const Stage &st) {
+// FinalizeDecoding: the exact backward sweep over all frames -- and, with `periodic`,
+// PruneActiveTokens (:198-223), the same sweep started one frame below the newest (whose
+// tokens keep extra_cost 0: every token still active is taken to be on a best path), with
+// no final costs, run until a frame that an earlier sweep has already visited
+// (f <= `visited`) comes out unchanged (the reference's must_prune_forward_links chain,
+// :208-216; its `delta` tolerance is 0 here: extras are compared exactly).  What a
+// periodic sweep excises the final one would excise too (extras only grow while the
+// utterance does), so the finalized lattice does not depend on it.  Returns the lowest
+// frame swept.
+__device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, int F,
+                                            float final_best_cost, bool any_final, const Stage &st,
+                                            bool periodic = false, int visited = -1) {
   const int tid = threadIdx.x;
   if (tid == 0) { s.n_tok_staged = 0; s.n_arc_staged = 0; s.stage_overflow = 0; s.empty_frame = 0; }
+  // (periodic: F is the newest frame; the sweep starts at F - 1, whose emitting links end
+  // in F's tokens -- extra_cost 0.0f as the search wrote them, read from global memory)
+  const int f_top = periodic ? F - 1 : F;
+  const int f_last = periodic ? -1 : F;  // the frame that takes the final-cost term
+  int f_low = f_top + 1;
   const long long fb = static_cast<long long>(utt) * (p.max_frames + 1);
   const float lattice_beam = p.lat.lattice_beam;
   const uint32_t *next_b = nullptr;  // the next frame's final extras, while they are in LDS
@@ -206,8 +223,8 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
     Desc d;
     d.base = ToG(p.frame_base)[fb + f];
     d.n = ToG(p.frame_count)[fb + f];
-    d.eb = f == F ? 0 : ToG(p.link_emit_base)[fb + f];
-    d.en = f == F ? 0 : ToG(p.link_emit_count)[fb + f];
+    d.eb = f == f_last ? 0 : ToG(p.link_emit_base)[fb + f];
+    d.en = f == f_last ? 0 : ToG(p.link_emit_count)[fb + f];
     d.pb = ToG(p.link_eps_base)[fb + f];
     d.pn = ToG(p.link_eps_count)[fb + f];
     return d;
@@ -242,17 +259,20 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
     r.m_src0 = ToG(p.link_src)[at0];
     r.m_delta0 = ToG(p.link_delta)[at0];
   };
-  Desc ahead = describe(F), ahead2 = F > 0 ? describe(F - 1) : ahead;
+  if (f_top < 0) return 0;
+  Desc ahead = describe(f_top), ahead2 = f_top > 0 ? describe(f_top - 1) : ahead;
   Pre pre;
   bool have_pre = false;
   if (fits_lds(ahead)) { fetch(ahead, pre); have_pre = true; }
-  for (int f = F; f >= 0; --f) {
+  for (int f = f_top; f >= 0; --f) {
+    f_low = f;
+    if (tid == 0) s.frame_changed = 0;  // (read behind the barriers at the frame's end)
     const Desc d = ahead;
     ahead = ahead2;
     if (f > 1) ahead2 = describe(f - 2);
     const long long base = d.base;
     const int n = d.n;
-    const bool last = f == F;
+    const bool last = f == f_last;
     const long long eb = d.eb;
     const int en = d.en;
     const long long pb = d.pb;
@@ -317,6 +337,7 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
         float link_extra_cost = next_extra + delta;  // :257-260
         if (link_extra_cost > lattice_beam) {  // :264 excise
           ToG(p.link_dst)[at] = -1;
+          if (periodic) s.frame_changed = 1;
           continue;
         }
         if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
@@ -335,6 +356,7 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
           if (link_extra_cost > lattice_beam) {  // :264 excise
             ToG(p.link_dst)[pb + tid + r * kBlock] = -1;
             e_src[r] = -1;
+            if (periodic) s.frame_changed = 1;
             continue;
           }
           if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
@@ -357,6 +379,7 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
       }
       for (int i = tid; i < n; i += kBlock) {
         const float ex = KeyFloat(B[i]);
+        if (periodic && ToG(p.tok_extra)[base + i] != ex) s.frame_changed = 1;
         ToG(p.tok_extra)[base + i] = ex;
         if (st.on && ex != FInf()) StageTok(s, st, base + i, f);
       }
@@ -371,6 +394,11 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
       // (a later frame that reads these extras from global memory -- the path below --
       // does so behind a full barrier of its own)
       LdsBarrier();
+      if (periodic) {
+        const bool stop = f <= visited && !s.frame_changed;
+        LdsBarrier();  // (everybody has read the flag before the next frame clears it)
+        if (stop) break;
+      }
       continue;
     }
     next_b = nullptr;  // this frame's extras go to global memory only
@@ -391,8 +419,8 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
       }
       if (tid == 0) s.changed = 0;
       __syncthreads();
-      ApplyLinks(p, s, gne, ne_in_lds, eb, en, base);
-      ApplyLinks(p, s, gne, ne_in_lds, pb, pn, base);
+      ApplyLinks(p, s, gne, ne_in_lds, eb, en, base, periodic);
+      ApplyLinks(p, s, gne, ne_in_lds, pb, pn, base, periodic);
       __syncthreads();
       int ch = 0;
       for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {  // (four tokens per lane in flight)
@@ -418,11 +446,17 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
         }
       }
       if (ch) s.changed = 1;
+      if (ch && periodic) s.frame_changed = 1;
       __syncthreads();
       const int changed = s.changed;
       __syncthreads();
       // without epsilon links nothing in this frame depends on this frame
       if (!changed || pn == 0) break;
+    }
+    if (periodic) {
+      const bool stop = f <= visited && !s.frame_changed;
+      __syncthreads();
+      if (stop) break;
     }
     if (st.on) {  // (a frame of thousands of tokens: read back what the loop above left)
       for (int i = tid; i < n; i += kBlock)
@@ -435,6 +469,7 @@ __device__ __forceinline__ void LatticePrune(CParams &p, TailShared &s, int utt,
     }
   }
   __syncthreads();
+  return f_low;
 }
 
 // GetRawLattice from the lists FinalizeDecoding left (Stage): states are numbered
@@ -524,7 +559,10 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
   KD_G int32_t *soff = ToG(p.lat.frame_state_off) + fb, *aoff = ToG(p.lat.frame_arc_off) + fb;
   if (tid == 0) { s.start_id = -1; s.empty_frame = 0; s.n_finals = 0; }
   __syncthreads();
-  auto alive = [&](long long g) { return !finalized || ToG(p.tok_extra)[g] != FInf(); };
+  // (a token without surviving forward links has extra_cost +inf: FinalizeDecoding's or a
+  // periodic sweep's doing -- the reference deletes it, :310-334; the search writes 0)
+  (void)finalized;
+  auto alive = [&](long long g) { return ToG(p.tok_extra)[g] != FInf(); };
   constexpr int kT = 4;
   // pass 1: live tokens and surviving links of every frame
   for (int f = wave; f <= F; f += kWaves) {
@@ -684,6 +722,210 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
     s.r_out_off = off;
   }
   return 0;
+}
+
+// ---- the collector ---------------------------------------------------------------
+// The reference frees what PruneActiveTokens finds dead (ForwardLinks at :264-275, tokens
+// in PruneTokensForFrame, :310-334).  Here records live in append-only pools, so what
+// SURVIVES of frames [lo, hi) is moved instead: live tokens and surviving links of each
+// frame are copied, compacted, into the utterance's archive; link endpoints follow their
+// tokens through a forwarding word per token (tok_newid); the frame index is pointed at
+// the copies; and the nursery chunks that only held such frames are freed for reuse by
+// this utterance (TakeChunks).  Frames are independent here: each wave takes frames of
+// its own and ranks with ballot + popcount, no workgroup barrier inside a pass.
+// Everything is counted first and the archive space taken in one piece, so a pool that
+// is exhausted is noticed before anything has moved.
+constexpr int kCollectFrames = 1024;  // frames per pass (six counters each in the LDS block)
+
+__device__ __forceinline__ long long ArchiveAlloc(CParams &p, KD_G UttMem *m, bool links, long long need) {
+  long long &next = *(links ? ToFlat(&m->alink_next) : ToFlat(&m->atok_next));
+  long long &end = *(links ? ToFlat(&m->alink_end) : ToFlat(&m->atok_end));
+  if (next + need > end) {
+    const long long standard = links ? p.link_chunk : p.tok_chunk;
+    const long long want = need > standard ? need : standard;
+    const long long b = PoolChunk(p, links ? &m->link : &m->tok, links, static_cast<unsigned long long>(want));
+    if (b < 0) return -1;
+    next = b;
+    end = b + want;
+  }
+  const long long r = next;
+  next += need;
+  return r;
+}
+
+// rank of this lane among the lanes of `m` below it
+__device__ __forceinline__ int RankIn(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
+}
+
+__device__ __forceinline__ uint32_t LatticeCollect(CParams &p, TailShared &s, int utt, int lo, int hi) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long fb = static_cast<long long>(utt) * (p.max_frames + 1);
+  KD_G UttMem *m = ToG(p.mem) + utt;
+  const int nfr = hi - lo;  // <= kCollectFrames
+  int32_t *cnt_t = reinterpret_cast<int32_t *>(s.ne), *cnt_e = cnt_t + kCollectFrames,
+          *cnt_m = cnt_e + kCollectFrames;
+  long long *off_t = reinterpret_cast<long long *>(cnt_m + kCollectFrames), *off_e = off_t + kCollectFrames,
+            *off_m = off_e + kCollectFrames;
+  // ---- pass A: what survives, per frame
+  for (int j = wave; j < nfr; j += kWaves) {
+    const int k = lo + j;
+    const long long base = ToG(p.frame_base)[fb + k];
+    const int n = ToG(p.frame_count)[fb + k];
+    int ct = 0;
+    for (int c0 = 0; c0 < n; c0 += 64)
+      ct += __popcll(__ballot(c0 + lane < n && ToG(p.tok_extra)[base + c0 + lane] != FInf()));
+    int cl[2];
+    for (int blk = 0; blk < 2; ++blk) {
+      const long long lb = blk ? ToG(p.link_emit_base)[fb + k] : ToG(p.link_eps_base)[fb + k];
+      const int ln = blk ? ToG(p.link_emit_count)[fb + k] : ToG(p.link_eps_count)[fb + k];
+      int c = 0;
+      for (int c0 = 0; c0 < ln; c0 += 64)
+        c += __popcll(__ballot(c0 + lane < ln && ToG(p.link_dst)[lb + c0 + lane] >= 0));
+      cl[blk] = c;
+    }
+    if (lane == 0) { cnt_t[j] = ct; cnt_e[j] = cl[0]; cnt_m[j] = cl[1]; }
+  }
+  __syncthreads();
+  // ---- the archive space, in one piece per pool
+  if (tid == 0) {
+    long long tt = 0, tl = 0;
+    for (int j = 0; j < nfr; ++j) { tt += cnt_t[j]; tl += cnt_e[j] + cnt_m[j]; }
+    const long long bt = ArchiveAlloc(p, m, false, tt);
+    const long long bl = bt < 0 ? -1 : ArchiveAlloc(p, m, true, tl);
+    s.alloc_err = bt < 0 ? KD_UTT_ARENA_FULL : bl < 0 ? KD_UTT_LINKS_FULL : 0u;
+    if (!s.alloc_err) {
+      long long at = bt, al = bl;
+      for (int j = 0; j < nfr; ++j) {
+        off_t[j] = at; at += cnt_t[j];
+        off_e[j] = al; al += cnt_e[j];
+        off_m[j] = al; al += cnt_m[j];
+      }
+    }
+  }
+  __syncthreads();
+  if (s.alloc_err) return s.alloc_err;
+  // ---- pass B: tokens; every token of these frames gets its forwarding word
+  for (int j = wave; j < nfr; j += kWaves) {
+    const int k = lo + j;
+    const long long base = ToG(p.frame_base)[fb + k];
+    const int n = ToG(p.frame_count)[fb + k];
+    long long at = off_t[j];
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const int i = c0 + lane;
+      const long long g = base + i;
+      const float ex = i < n ? ToG(p.tok_extra)[g] : FInf();
+      const bool a = i < n && ex != FInf();
+      const int32_t st = a ? ToG(p.tok_state)[g] : 0;
+      const double co = a ? ToG(p.tok_cost)[g] : 0.0;
+      const unsigned long long mk = __ballot(a);
+      const long long to = at + RankIn(mk);
+      if (a) {
+        ToG(p.tok_state)[to] = st;
+        ToG(p.tok_cost)[to] = co;
+        ToG(p.tok_extra)[to] = ex;
+      }
+      if (i < n) ToG(p.lat.tok_newid)[g] = a ? static_cast<int32_t>(to) : -1;
+      at += __popcll(mk);
+    }
+  }
+  __syncthreads();  // every forwarding word is in place
+  // ---- the emitting links of frame lo - 1 (archived earlier) end in frame lo's tokens
+  if (lo > 0) {
+    const long long lb = ToG(p.link_emit_base)[fb + lo - 1];
+    const int ln = ToG(p.link_emit_count)[fb + lo - 1];
+    for (int i = tid; i < ln; i += kBlock) {
+      const int32_t d = ToG(p.link_dst)[lb + i];
+      if (d >= 0) ToG(p.link_dst)[lb + i] = ToG(p.lat.tok_newid)[d];
+    }
+  }
+  // ---- pass C: links, endpoints forwarded (an emitting link of frame hi - 1 ends in
+  // frame hi, which stays where it is until the next collection)
+  for (int j = wave; j < nfr; j += kWaves) {
+    const int k = lo + j;
+    for (int blk = 0; blk < 2; ++blk) {
+      const long long lb = blk ? ToG(p.link_emit_base)[fb + k] : ToG(p.link_eps_base)[fb + k];
+      const int ln = blk ? ToG(p.link_emit_count)[fb + k] : ToG(p.link_eps_count)[fb + k];
+      const bool fwd_dst = (blk ? k + 1 : k) < hi;
+      long long at = blk ? off_m[j] : off_e[j];
+      for (int c0 = 0; c0 < ln; c0 += 64) {
+        const int i = c0 + lane;
+        const long long l = lb + i;
+        const int32_t d = i < ln ? ToG(p.link_dst)[l] : -1;
+        const bool a = d >= 0;
+        int32_t src = 0, arc = 0, dst = d;
+        float ac = 0.f, gr = 0.f, dl = 0.f;
+        if (a) {
+          src = ToG(p.lat.tok_newid)[ToG(p.link_src)[l]];
+          if (fwd_dst) dst = ToG(p.lat.tok_newid)[d];
+          arc = ToG(p.link_arc)[l];
+          ac = ToG(p.link_ac)[l];
+          gr = ToG(p.link_graph)[l];
+          dl = ToG(p.link_delta)[l];
+        }
+        const unsigned long long mk = __ballot(a);
+        const long long to = at + RankIn(mk);
+        if (a) {
+          ToG(p.link_src)[to] = src;
+          ToG(p.link_dst)[to] = dst;
+          ToG(p.link_arc)[to] = arc;
+          ToG(p.link_ac)[to] = ac;
+          ToG(p.link_graph)[to] = gr;
+          ToG(p.link_delta)[to] = dl;
+        }
+        at += __popcll(mk);
+      }
+    }
+  }
+  __syncthreads();  // (every old block has been read: the frame index can move)
+  for (int j = tid; j < nfr; j += kBlock) {
+    const int k = lo + j;
+    ToG(p.frame_base)[fb + k] = off_t[j];
+    ToG(p.frame_count)[fb + k] = cnt_t[j];
+    ToG(p.link_eps_base)[fb + k] = off_e[j];
+    ToG(p.link_eps_count)[fb + k] = cnt_e[j];
+    ToG(p.link_emit_base)[fb + k] = off_m[j];
+    ToG(p.link_emit_count)[fb + k] = cnt_m[j];
+  }
+  // ---- nursery chunks that held nothing younger than hi - 1 are free again
+  if (tid == 0) {
+    m->gc_frame = hi;
+    for (int w = 0; w < 2; ++w) {
+      KD_G ChunkRing *r = w ? &m->link : &m->tok;
+      int keep = 0;
+      for (int i = 0; i < r->n_retired; ++i) {
+        if (r->retired_last[i] < hi && r->n_free < kChunkRing) {
+          r->free_start[r->n_free++] = r->retired_start[i];
+        } else if (r->retired_last[i] >= hi) {
+          r->retired_start[keep] = r->retired_start[i];
+          r->retired_last[keep] = r->retired_last[i];
+          keep++;
+        }  // (a freed chunk the full free list cannot take is lost until InitDecoding)
+      }
+      r->n_retired = keep;
+    }
+  }
+  __syncthreads();
+  return 0;
+}
+
+// PruneActiveTokens between two frames of the search (frame F is the newest), then the
+// collection of the frames that are older than prune_interval.  Uses the search's LDS
+// block: the caller re-establishes what the search keeps there.  Returns 0 or the
+// KD_UTT_* bit of the pool the archive could not get space from (nothing has moved then).
+__device__ __noinline__ uint32_t PeriodicPrune(CParams *pp, int utt, int F, int visited) {
+  CParams &p = *pp;
+  TailShared &s = TailLds();
+  Stage st = TailStage(p, false);
+  (void)LatticePrune(p, s, utt, F, 0.0f, false, st, /*periodic=*/true, visited);
+  const int hi = F - p.lat.prune_interval;
+  uint32_t r = 0;
+  while (r == 0) {
+    const int lo = Uni(ToG(p.mem)[utt].gc_frame);
+    if (lo >= hi) break;
+    r = LatticeCollect(p, s, utt, lo, hi - lo > kCollectFrames ? lo + kCollectFrames : hi);
+  }
+  return r;
 }
 
 // The tail of an utterance that has reached its target frame F.

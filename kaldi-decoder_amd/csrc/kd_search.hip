@@ -449,29 +449,55 @@ __device__ __forceinline__ unsigned long long BlockMinU64(Shared &s, unsigned lo
 // the old chunk is abandoned: at most one frame's worth).  Returns 0 or the KD_UTT_* bit
 // of the pool that is exhausted -- the frame is then not committed, and the host grows
 // the pool and relaunches (kd_api.hip).  Call from one thread.
-__device__ __forceinline__ uint32_t TakeChunks(CParams &p, Shared &s, long long need_tokens,
-                                               long long need_links) {
+// A chunk of `want` records of pool `links ? link : token`: one of the utterance's own
+// freed chunks if the request is of standard size, else the next of the pool.  -1: the
+// pool is exhausted.
+__device__ __forceinline__ long long PoolChunk(CParams &p, KD_G ChunkRing *ring, bool links,
+                                               unsigned long long want) {
+  const unsigned long long standard = links ? p.link_chunk : p.tok_chunk;
+  if (want == standard && ring->n_free > 0) return ring->free_start[--ring->n_free];
+  unsigned long long *top = links ? &p.ctl->link_top : &p.ctl->tok_top;
+  const unsigned long long base = links ? p.link_base : p.tok_base, cap = links ? p.link_cap : p.tok_cap;
+  const unsigned long long b = atomicAdd(top, want) - base;
+  if (b + want > cap) {
+    atomicAdd(top, 0ull - want);
+    return -1;
+  }
+  return static_cast<long long>(b);
+}
+
+// Notes a nursery chunk that is full (standard size only; `last` = the last frame plus
+// one with a block in it) so that the collector can free it once that frame is archived.
+__device__ __forceinline__ void RetireChunk(KD_G ChunkRing *ring, int32_t start, int32_t last) {
+  if (start < 0 || ring->n_retired >= kChunkRing) return;  // (not recycled: lost until InitDecoding)
+  ring->retired_start[ring->n_retired] = start;
+  ring->retired_last[ring->n_retired] = last;
+  ring->n_retired++;
+}
+
+__device__ __forceinline__ uint32_t TakeChunks(CParams &p, Shared &s, int utt, int frame_plus_one,
+                                               long long need_tokens, long long need_links) {
+  KD_G UttMem *m = ToG(p.mem) + utt;
   if (s.arena_next + need_tokens > s.arena_end) {
     const unsigned long long want =
         static_cast<unsigned long long>(need_tokens > p.tok_chunk ? need_tokens : p.tok_chunk);
-    const unsigned long long b = atomicAdd(&p.ctl->tok_top, want) - p.tok_base;
-    if (b + want > p.tok_cap) {
-      atomicAdd(&p.ctl->tok_top, 0ull - want);
-      return KD_UTT_ARENA_FULL;
-    }
-    s.arena_next = static_cast<long long>(b);
-    s.arena_end = static_cast<long long>(b + want);
+    const long long b = PoolChunk(p, &m->tok, false, want);
+    if (b < 0) return KD_UTT_ARENA_FULL;
+    RetireChunk(&m->tok, m->arena_chunk, frame_plus_one - 1);
+    m->arena_chunk = want == static_cast<unsigned long long>(p.tok_chunk) ? static_cast<int32_t>(b) : -1;
+    s.arena_next = b;
+    s.arena_end = b + static_cast<long long>(want);
   }
   if (need_links > 0 && s.link_next + need_links > s.link_end) {
     const unsigned long long want =
         static_cast<unsigned long long>(need_links > p.link_chunk ? need_links : p.link_chunk);
-    const unsigned long long b = atomicAdd(&p.ctl->link_top, want) - p.link_base;
-    if (b + want > p.link_cap) {
-      atomicAdd(&p.ctl->link_top, 0ull - want);
-      return KD_UTT_LINKS_FULL;
-    }
-    s.link_next = static_cast<long long>(b);
-    s.link_end = static_cast<long long>(b + want);
+    const long long b = PoolChunk(p, &m->link, true, want);
+    if (b < 0) return KD_UTT_LINKS_FULL;
+    // (the links of frame_plus_one - 1's tokens are being written: the old chunk's last are older)
+    RetireChunk(&m->link, m->link_chunk, frame_plus_one - 1);
+    m->link_chunk = want == static_cast<unsigned long long>(p.link_chunk) ? static_cast<int32_t>(b) : -1;
+    s.link_next = b;
+    s.link_end = b + static_cast<long long>(want);
   }
   return 0;
 }
@@ -1314,7 +1340,8 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
   if (tid == 0) {
     // the frame's token block, and room for its forward links (at most one per queue
     // entry below the cutoff), from this utterance's chunks of the pools
-    const uint32_t e = TakeChunks(p, s, n_out, c.lattice ? s.n_emit_links + (n_q - q_emit) : 0);
+    const uint32_t e = TakeChunks(p, s, c.utt, frame + 1, n_out,
+                                  c.lattice ? s.n_emit_links + (n_q - q_emit) : 0);
     s.alloc_ok = static_cast<int32_t>(e);
     s.base_out = e ? -1 : s.arena_next;
     if (!e) s.arena_next += n_out;
@@ -2042,7 +2069,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   if (Uni(s.arena_next) + n_out > Uni(s.arena_end) ||
       (c.lattice && Uni(s.link_next) + link_room > Uni(s.link_end))) {
     tm.Sync(false);
-    if (tid == 0) s.alloc_ok = static_cast<int32_t>(TakeChunks(p, s, n_out, link_room));
+    if (tid == 0) s.alloc_ok = static_cast<int32_t>(TakeChunks(p, s, c.utt, frame + 1, n_out, link_room));
     tm.Sync(false);
     const uint32_t e = static_cast<uint32_t>(Uni(s.alloc_ok));
     if (e) return e;
@@ -2456,7 +2483,14 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   c.base_in = 0;
   c.n_in = 0;
   if (tid == 0) {
-    const KD_G UttMem *m = ToG(p.mem) + utt;
+    KD_G UttMem *m = ToG(p.mem) + utt;
+    if (do_init) {  // no chunk of any pool yet, nothing archived, nothing to recycle
+      m->atok_next = 0; m->atok_end = 0; m->alink_next = 0; m->alink_end = 0;
+      m->arena_chunk = -1; m->link_chunk = -1;
+      m->gc_frame = 0;
+      m->tok.n_retired = 0; m->tok.n_free = 0;
+      m->link.n_retired = 0; m->link.n_free = 0;
+    }
     s.arena_next = do_init ? 0 : m->arena_next;
     s.arena_end = do_init ? 0 : m->arena_end;
     s.link_next = do_init ? 0 : m->link_next;
@@ -2491,6 +2525,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   if (err == 0) row_to_lds(frame);
   __syncthreads();
   Counters tot;  // per-lane work counters of the small frames, folded when the launch ends
+  int visited = do_init ? -1 : Uni(ToG(p.mem)[utt].visited);
 
   while (err == 0 && frame < target) {
     KD_LAP(s, 13);
@@ -2604,6 +2639,29 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     }
     if (r != 0) { err |= r; break; }
     frame++;
+    if constexpr (M == 1) {
+      // PruneActiveTokens every prune_interval frames (lattice-simple-decoder.cc:57-59):
+      // bounds what FinalizeDecoding will have to look at and, with it, memory
+      if (frame < target && frame > 0 && frame % p.lat.prune_interval == 0 && frame - 1 > visited) {
+        __syncthreads();
+        if (tid == 0) {  // (the collector takes archive chunks through the same cursors' owner)
+          KD_G UttMem *m = ToG(p.mem) + utt;
+          m->arena_next = s.arena_next; m->arena_end = s.arena_end;
+          m->link_next = s.link_next; m->link_end = s.link_end;
+        }
+        __syncthreads();
+        const uint32_t pe = Uni(PeriodicPrune(&p, utt, frame, visited));
+        visited = frame - 1;
+        __syncthreads();
+        if (pe) { err |= pe; }
+        // the sweep used the LDS block: the table is cleared again, the frontier comes
+        // back from the arena (the next frame's log-likelihood row and the frame counters
+        // lie beyond what the sweep touches)
+        FullClear<true>(tl, s);
+        front_lds = false;
+        upper_dirty = false;
+      }
+    }
   }
 
   // fold the small frames' per-lane work counters into the launch totals
@@ -2627,6 +2685,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     m->arena_end = s.arena_end;
     m->link_next = s.link_next;
     m->link_end = s.link_end;
+    m->visited = visited;
   }
   if (tid < KD_NUM_STATS) {
     KD_G long long *st = ToG(p.stats) + static_cast<long long>(utt) * kStatStride;

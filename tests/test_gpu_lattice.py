@@ -280,3 +280,69 @@ def test_more_utterances_than_workgroups_and_table_growth_mid_launch(oracle):
         assert gl.num_states == cl.num_states and len(gl.src) == len(cl.src), i
         if i % 25 == 0:
             _assert_same_lattice(gl, cl, i)
+
+
+@pytest.mark.parametrize("prune_interval", [1, 2, 7])
+@pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
+def test_periodic_pruning_and_collection_leave_the_lattice_unchanged(oracle, case, prune_interval):
+    """PruneActiveTokens every prune_interval frames (lattice-simple-decoder.cc:57-59) and
+    the collector that moves the survivors of older frames into the archive: whatever the
+    interval, the finalized lattice is the canonical oracle's; so is the lattice exported
+    without FinalizeDecoding when it is compared after the same pruning on the oracle's
+    side -- i.e. as the set of arcs a later FinalizeDecoding keeps."""
+    import torch
+    name, g, lex, V, opts = case
+    B, T = 4, 60
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lps = [synth.make_logprobs(T - 5 * i, V, 20 + i, peak=5.0, lexicon=lex) for i in range(B)]
+    dev = [torch.from_numpy(lp).cuda() for lp in lps]
+    want = []
+    for lp in lps:
+        can = oracle.CanonLatticeDecoder(OG, **opts)
+        can.decode(lp)
+        want.append((can.get_raw_lattice(), can.final_relative_cost()))
+    # one launch
+    lb = cabi.LatticeBatch(G, max_batch=B, prune_interval=prune_interval, **opts)
+    lb.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V)
+    for i, lat in enumerate(lb.raw_lattices()):
+        _assert_same_lattice(lat, want[i][0], (name, prune_interval, i))
+    assert lb.final_relative_cost().tolist() == [w[1] for w in want]
+    # in chunks of 11 frames (sweeps and collections fall on and between launch boundaries),
+    # un-finalized export in the middle, then FinalizeDecoding as a call of its own
+    st = cabi.LatticeBatch(G, max_batch=B, prune_interval=prune_interval, **opts)
+    st.init_decoding(B)
+    for t0 in range(0, T, 11):
+        st.advance_host(lps, max_num_frames=11)
+        if t0 == 22:
+            mid = st.raw_lattices(use_final_probs=False)
+            assert all(m.ok for m in mid)
+    st.finalize_decoding()
+    for i, lat in enumerate(st.raw_lattices()):
+        _assert_same_lattice(lat, want[i][0], (name, prune_interval, i, "chunks"))
+
+
+def test_periodic_pruning_bounds_memory(oracle):
+    """A long utterance over a dense graph in pools that may not grow: with the reference's
+    default prune_interval the collector keeps the footprint at the pruned lattice plus a
+    window of recent frames and the decode finishes; with pruning off the same pools are
+    exhausted after a fraction of the frames."""
+    import torch
+    g = synth.ctc_topo(100)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    T, V = 1500, 100
+    lp = synth.make_logprobs(T, V, 77, peak=7.0)
+    dev = torch.from_numpy(lp).cuda()
+    opts = dict(beam=8.0, lattice_beam=4.0, min_active=0)
+    kw = dict(arena_tokens=1 << 16, arena_links=1 << 18, max_frames=T, no_grow=1)
+    off = cabi.LatticeBatch(G, max_batch=1, prune_interval=10**6, **kw, **opts)
+    with pytest.raises(RuntimeError, match="pool full"):
+        off.decode_device([dev.data_ptr()], [T], V)
+    on = cabi.LatticeBatch(G, max_batch=1, prune_interval=25, **kw, **opts)
+    on.decode_device([dev.data_ptr()], [T], V)
+    assert on.num_frames_decoded().tolist() == [T]
+    can = oracle.CanonLatticeDecoder(OG, **opts)
+    can.decode(lp)
+    _assert_same_lattice(on.raw_lattices()[0], can.get_raw_lattice(), "bounded")
+    created = can.links_created()
+    cap = on.capacity()
+    assert cap["links_used"] < created // 2, (cap, created)  # the pool never held them all
