@@ -34,7 +34,7 @@ SUBSAMPLING = 4
 HLG = dict(V=500, n_words=20000, n_hist=20000, avg_succ=50, seed=2)
 WORKLOADS = {
     "hlg-lattice": dict(kind="hlg", graph=HLG, lattice=True,
-                        opts=dict(beam=15.0, lattice_beam=8.0, min_active=0),
+                        opts=dict(beam=15.0, lattice_beam=8.0, min_active=0, prune_interval=1 << 20),
                         batch=128, frames=250, V=500,
                         desc="LatticeFasterDecoder over synthetic LibriSpeech-like HLG (bigram G, "
                              "20k words, V=500), beam=15, lattice_beam=8, B=128/GPU, T=250"),
@@ -42,7 +42,7 @@ WORKLOADS = {
     # 141 M arcs = 2.26 GB of 16-byte arc records (stresses HBM: the graph is nine times the
     # Infinity Cache), beam 17
     "hlg-large": dict(kind="hlg", graph=dict(V=500, n_words=200000, n_hist=200000, avg_succ=50, seed=2),
-                      lattice=True, opts=dict(beam=17.0, lattice_beam=8.0, min_active=0),
+                      lattice=True, opts=dict(beam=17.0, lattice_beam=8.0, min_active=0, prune_interval=1 << 20),
                       batch=128, frames=250, V=500,
                       desc="LatticeFasterDecoder over synthetic large-LM HLG (bigram G, 200k words, "
                            "141M arcs = 2.26 GB, V=500), beam=17, lattice_beam=8, B=128/GPU, T=250"),
@@ -406,6 +406,25 @@ def main():
     bt = bts[0]
     lps = all_lps[:per_slot]
     stats = bt.stats() if not args.search_only else None
+    # The same pipeline at the reference's default prune_interval (25): PruneActiveTokens
+    # every 25 frames plus the collector that keeps an utterance's footprint at its pruned
+    # lattice and a window of recent frames.  The lattices are the same either way (the
+    # knob trades time for memory); the headline runs with it off because a 10 s utterance
+    # needs 5 MB, and reports this figure next to it.
+    value_pi25 = None
+    if wl["lattice"] and not args.search_only and not args.prune_interval:
+        keep = bts
+        bts = [cls(Gr, max_batch=per_slot, max_frames=T, stream=st.cuda_stream,
+                   **{**wl["opts"], "prune_interval": 25}) for st in streams]
+        run_steps(2 * n_fly * G)
+        fence()
+        n25 = max(args.steps, 6 * n_fly * G)
+        t25 = time.perf_counter()
+        run_steps(n25)
+        fence()
+        value_pi25 = world * B * T * n25 * SUBSAMPLING / (time.perf_counter() - t25)
+        del bts
+        bts = keep
     # a full call alone on the GPU (no other launch sharing the CUs): what the launch's
     # own duration is when nothing stretches it
     alone_ms = []
@@ -452,6 +471,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / steps_timed * 1e3,
             "timed_seconds": elapsed,
+            "value_prune_interval_25": value_pi25,
             "single_batch_ms": single_batch_ms,
             "single_batch_value": B * T * SUBSAMPLING / (single_batch_ms * 1e-3),
             "single_batch_kernel_ms": single_kernel_ms,
@@ -462,6 +482,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["desc"], "graph_states": info["states"],
                        "graph_arcs": info["arcs"], "batch_per_gpu": B, "frames": T,
+                       "prune_interval": (args.prune_interval or wl["opts"].get("prune_interval")),
                        "steps_per_call": G, "utterances_per_launch": n_last * B,
                        "calls_in_flight": n_fly, "workgroups_per_launch": cap["workgroups"],
                        "device_mb_per_call": bt.device_bytes / 2**20,

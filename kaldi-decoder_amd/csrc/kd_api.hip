@@ -213,6 +213,7 @@ struct kd_batch {
     p.link_eps_count = link_eps_count.p;
     p.lat.lattice_beam = lo.lattice_beam;
     p.lat.prune_interval = lattice && lo.prune_interval > 0 ? lo.prune_interval : 0x7FFFFFFF;
+    p.lat.prune_scale = lo.prune_scale;
     p.lat.tok_extra = tok_extra.p;
     p.lat.tok_newid = tok_newid.p;
     p.lat.scratch = lat_scratch.p;

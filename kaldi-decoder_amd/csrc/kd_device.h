@@ -108,7 +108,8 @@ struct UttMem {
   long long link_next, link_end;     // link nursery
   long long atok_next, atok_end;     // token archive
   long long alink_next, alink_end;   // link archive
-  int32_t arena_chunk, link_chunk;   // start of the nursery chunks if they are of standard size, else -1
+  int32_t arena_chunk, link_chunk;   // start of the nursery chunks (-1: none yet) ...
+  int32_t arena_chunk_len, link_chunk_len;  // ... and their sizes
   int32_t visited;    // frames <= this have been through a periodic sweep
   int32_t gc_frame;   // frames < this are in the archive
   ChunkRing tok, link;
@@ -117,6 +118,7 @@ struct UttMem {
 struct LatticeParams {
   float lattice_beam;
   int32_t prune_interval;    // PruneActiveTokens every this many frames (lattice-simple-decoder.cc:57-59)
+  float prune_scale;         // ... with delta = lattice_beam * prune_scale
   float *tok_extra;
   int32_t *tok_newid;        // [token pool] state id in the exported lattice, -1 if pruned
   uint32_t *scratch;         // [token pool] per-frame extra-cost keys beyond LDS

@@ -88,8 +88,7 @@ static_assert(kWaves <= 16, "BlockExclScanI scans at most 16 wave totals");
 // (every lane issues every load -- a lane without a link reads a valid dummy --
 // because hipcc waits for a conditional load before it issues the next).
 __device__ __forceinline__ void ApplyLinks(CParams &p, TailShared &s, KD_G uint32_t *ne,
-                                           bool ne_in_lds, long long lb, int ln, long long base,
-                                           bool note_change = false) {
+                                           bool ne_in_lds, long long lb, int ln, long long base) {
   constexpr int U = 4;
   const float lattice_beam = p.lat.lattice_beam;
   for (int i0 = threadIdx.x; i0 < ln; i0 += U * kBlock) {
@@ -114,7 +113,6 @@ __device__ __forceinline__ void ApplyLinks(CParams &p, TailShared &s, KD_G uint3
       float link_extra_cost = next_extra[u] + delta[u];
       if (link_extra_cost > lattice_beam) {  // :264 excise
         ToG(p.link_dst)[lb + i0 + u * kBlock] = -1;
-        if (note_change) s.frame_changed = 1;
         continue;
       }
       if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
@@ -194,18 +192,27 @@ __device__ __forceinline__ void StageArc(TailShared &s, const Stage &st, long lo
   else s.stage_overflow = 1;
 }
 
+// |a - b| > delta for extra costs (+inf == +inf: not moved; a token that died, or came
+// back, has moved)
+__device__ __forceinline__ bool Moved(float a, float b, float delta) {
+  if (a == b) return false;
+  return !(fabsf(a - b) <= delta);
+}
+
 // FinalizeDecoding: the exact backward sweep over all frames -- and, with `periodic`,
 // PruneActiveTokens (:198-223), the same sweep started one frame below the newest (whose
 // tokens keep extra_cost 0: every token still active is taken to be on a best path), with
 // no final costs, run until a frame that an earlier sweep has already visited
-// (f <= `visited`) comes out unchanged (the reference's must_prune_forward_links chain,
-// :208-216; its `delta` tolerance is 0 here: extras are compared exactly).  What a
-// periodic sweep excises the final one would excise too (extras only grow while the
-// utterance does), so the finalized lattice does not depend on it.  Returns the lowest
-// frame swept.
+// (f <= `visited`) comes out with no extra cost moved by more than `delta` = lattice_beam
+// x prune_scale (the reference's must_prune_forward_links chain, :208-216, and its
+// tolerance, :286-288).  What a periodic sweep excises the final one would excise too:
+// extras only grow while the utterance does, so a stale extra under-estimates a link's
+// cost and the final, exact sweep recomputes every frame from below -- the finalized
+// lattice does not depend on how often or how far the periodic sweeps went.  Returns
+// the lowest frame swept.
 __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, int F,
                                             float final_best_cost, bool any_final, const Stage &st,
-                                            bool periodic = false, int visited = -1) {
+                                            bool periodic = false, int visited = -1, float delta = 0.0f) {
   const int tid = threadIdx.x;
   if (tid == 0) { s.n_tok_staged = 0; s.n_arc_staged = 0; s.stage_overflow = 0; s.empty_frame = 0; }
   // (periodic: F is the newest frame; the sweep starts at F - 1, whose emitting links end
@@ -337,7 +344,6 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
         float link_extra_cost = next_extra + delta;  // :257-260
         if (link_extra_cost > lattice_beam) {  // :264 excise
           ToG(p.link_dst)[at] = -1;
-          if (periodic) s.frame_changed = 1;
           continue;
         }
         if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
@@ -356,7 +362,6 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
           if (link_extra_cost > lattice_beam) {  // :264 excise
             ToG(p.link_dst)[pb + tid + r * kBlock] = -1;
             e_src[r] = -1;
-            if (periodic) s.frame_changed = 1;
             continue;
           }
           if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
@@ -379,7 +384,7 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
       }
       for (int i = tid; i < n; i += kBlock) {
         const float ex = KeyFloat(B[i]);
-        if (periodic && ToG(p.tok_extra)[base + i] != ex) s.frame_changed = 1;
+        if (periodic && Moved(ToG(p.tok_extra)[base + i], ex, delta)) s.frame_changed = 1;
         ToG(p.tok_extra)[base + i] = ex;
         if (st.on && ex != FInf()) StageTok(s, st, base + i, f);
       }
@@ -404,6 +409,9 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
     next_b = nullptr;  // this frame's extras go to global memory only
     have_pre = false;  // (a prefetch made for this frame is dropped: it takes the path below)
     const bool ne_in_lds = n <= kLdsToks;
+    // (periodic: has any extra moved by more than delta?  The first round's `was` is what
+    // the previous sweep left; later rounds only move further from it)
+    bool first_round = true;
     KD_G uint32_t *gne = ToG(p.lat.scratch) + base;  // (the frame's own slice of the pool-wide scratch)
     while (true) {
       // start value: +inf, or for the last frame the token's own final term (:467)
@@ -419,8 +427,8 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
       }
       if (tid == 0) s.changed = 0;
       __syncthreads();
-      ApplyLinks(p, s, gne, ne_in_lds, eb, en, base, periodic);
-      ApplyLinks(p, s, gne, ne_in_lds, pb, pn, base, periodic);
+      ApplyLinks(p, s, gne, ne_in_lds, eb, en, base);
+      ApplyLinks(p, s, gne, ne_in_lds, pb, pn, base);
       __syncthreads();
       int ch = 0;
       for (int i0 = tid; i0 < n; i0 += 4 * kBlock) {  // (four tokens per lane in flight)
@@ -442,14 +450,15 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
           if (v != was[u]) {
             ToG(p.tok_extra)[base + i0 + u * kBlock] = v;
             ch = 1;
+            if (periodic && first_round && Moved(was[u], v, delta)) s.frame_changed = 1;
           }
         }
       }
       if (ch) s.changed = 1;
-      if (ch && periodic) s.frame_changed = 1;
       __syncthreads();
       const int changed = s.changed;
       __syncthreads();
+      first_round = false;
       // without epsilon links nothing in this frame depends on this frame
       if (!changed || pn == 0) break;
     }
@@ -917,7 +926,8 @@ __device__ __noinline__ uint32_t PeriodicPrune(CParams *pp, int utt, int F, int 
   CParams &p = *pp;
   TailShared &s = TailLds();
   Stage st = TailStage(p, false);
-  (void)LatticePrune(p, s, utt, F, 0.0f, false, st, /*periodic=*/true, visited);
+  (void)LatticePrune(p, s, utt, F, 0.0f, false, st, /*periodic=*/true, visited,
+                     p.lat.lattice_beam * p.lat.prune_scale);
   const int hi = F - p.lat.prune_interval;
   uint32_t r = 0;
   while (r == 0) {

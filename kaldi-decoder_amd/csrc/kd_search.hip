@@ -466,13 +466,17 @@ __device__ __forceinline__ long long PoolChunk(CParams &p, KD_G ChunkRing *ring,
   return static_cast<long long>(b);
 }
 
-// Notes a nursery chunk that is full (standard size only; `last` = the last frame plus
-// one with a block in it) so that the collector can free it once that frame is archived.
-__device__ __forceinline__ void RetireChunk(KD_G ChunkRing *ring, int32_t start, int32_t last) {
-  if (start < 0 || ring->n_retired >= kChunkRing) return;  // (not recycled: lost until InitDecoding)
-  ring->retired_start[ring->n_retired] = start;
-  ring->retired_last[ring->n_retired] = last;
-  ring->n_retired++;
+// Notes a nursery chunk that is full (`last` = the last frame plus one with a block in
+// it) so that the collector can free it once that frame is archived.  A chunk taken for
+// one oversized frame is noted as the standard-size pieces it can be cut into.
+__device__ __forceinline__ void RetireChunk(KD_G ChunkRing *ring, int32_t start, int32_t len,
+                                            int32_t standard, int32_t last) {
+  if (start < 0) return;
+  for (int32_t off = 0; off + standard <= len && ring->n_retired < kChunkRing; off += standard) {
+    ring->retired_start[ring->n_retired] = start + off;
+    ring->retired_last[ring->n_retired] = last;
+    ring->n_retired++;
+  }  // (what does not fit the ring is not recycled: lost until InitDecoding)
 }
 
 __device__ __forceinline__ uint32_t TakeChunks(CParams &p, Shared &s, int utt, int frame_plus_one,
@@ -483,8 +487,9 @@ __device__ __forceinline__ uint32_t TakeChunks(CParams &p, Shared &s, int utt, i
         static_cast<unsigned long long>(need_tokens > p.tok_chunk ? need_tokens : p.tok_chunk);
     const long long b = PoolChunk(p, &m->tok, false, want);
     if (b < 0) return KD_UTT_ARENA_FULL;
-    RetireChunk(&m->tok, m->arena_chunk, frame_plus_one - 1);
-    m->arena_chunk = want == static_cast<unsigned long long>(p.tok_chunk) ? static_cast<int32_t>(b) : -1;
+    RetireChunk(&m->tok, m->arena_chunk, m->arena_chunk_len, p.tok_chunk, frame_plus_one - 1);
+    m->arena_chunk = static_cast<int32_t>(b);
+    m->arena_chunk_len = static_cast<int32_t>(want);
     s.arena_next = b;
     s.arena_end = b + static_cast<long long>(want);
   }
@@ -494,8 +499,9 @@ __device__ __forceinline__ uint32_t TakeChunks(CParams &p, Shared &s, int utt, i
     const long long b = PoolChunk(p, &m->link, true, want);
     if (b < 0) return KD_UTT_LINKS_FULL;
     // (the links of frame_plus_one - 1's tokens are being written: the old chunk's last are older)
-    RetireChunk(&m->link, m->link_chunk, frame_plus_one - 1);
-    m->link_chunk = want == static_cast<unsigned long long>(p.link_chunk) ? static_cast<int32_t>(b) : -1;
+    RetireChunk(&m->link, m->link_chunk, m->link_chunk_len, p.link_chunk, frame_plus_one - 1);
+    m->link_chunk = static_cast<int32_t>(b);
+    m->link_chunk_len = static_cast<int32_t>(want);
     s.link_next = b;
     s.link_end = b + static_cast<long long>(want);
   }
@@ -2486,7 +2492,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     KD_G UttMem *m = ToG(p.mem) + utt;
     if (do_init) {  // no chunk of any pool yet, nothing archived, nothing to recycle
       m->atok_next = 0; m->atok_end = 0; m->alink_next = 0; m->alink_end = 0;
-      m->arena_chunk = -1; m->link_chunk = -1;
+      m->arena_chunk = -1; m->link_chunk = -1; m->arena_chunk_len = 0; m->link_chunk_len = 0;
       m->gc_frame = 0;
       m->tok.n_retired = 0; m->tok.n_free = 0;
       m->link.n_retired = 0; m->link.n_free = 0;

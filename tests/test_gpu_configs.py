@@ -66,13 +66,14 @@ def test_cfg5_large_lm_hlg_beam17_default_capacities(oracle):
     B, T, V = 4, wl["frames"], wl["V"]
     lps = [synth.make_logprobs(T, V, 70 + i, peak=12.0, lexicon=g["lexicon"]) for i in range(B)]
     dev = [torch.from_numpy(lp).cuda() for lp in lps]
-    lb = cabi.LatticeBatch(G, max_batch=B, **wl["opts"])
+    oopts = {k: v for k, v in wl["opts"].items() if k != "prune_interval"}
+    lb = cabi.LatticeBatch(G, max_batch=B, **oopts)  # (prune_interval at the reference's default)
     lb.decode_device([d.data_ptr() for d in dev], [T] * B, V)
     assert lb.num_frames_decoded().tolist() == [T] * B
     lats, frc, st = lb.raw_lattices(), lb.final_relative_cost(), lb.stats()
     assert st[:, 9].sum() > 0  # frames beyond the LDS table (the global-table tier) occur
     for i in range(B):
-        can = oracle.CanonLatticeDecoder(OG, **wl["opts"])
+        can = oracle.CanonLatticeDecoder(OG, **oopts)
         can.decode(lps[i])
         cl, gl = can.get_raw_lattice(), lats[i]
         assert gl.state_set() == cl.state_set(), i

@@ -131,7 +131,10 @@ def test_bench_size_workload_matches_canonical_oracle(oracle):
     G, OG = cabi.Graph(g), oracle.Graph(g)
     B, T, V = 4, wl["frames"], wl["V"]
     lps = [synth.make_logprobs(T, V, i, peak=12.0, lexicon=g["lexicon"]) for i in range(B)]
-    lb = cabi.LatticeBatch(G, max_batch=B, max_frames=T, **wl["opts"])
+    # (the bench turns periodic pruning off; here the reference's default interval, so that
+    # the sweeps and the collector run at full size too)
+    oopts = {k: v for k, v in wl["opts"].items() if k != "prune_interval"}
+    lb = cabi.LatticeBatch(G, max_batch=B, max_frames=T, **{**oopts, "prune_interval": 25})
     lb.init_decoding()
     lb.advance_host(lps)
     st = lb.stats()
@@ -141,7 +144,7 @@ def test_bench_size_workload_matches_canonical_oracle(oracle):
     lats = lb.raw_lattices()
     frc = lb.final_relative_cost()
     for i in range(B):
-        can = oracle.CanonLatticeDecoder(OG, **wl["opts"])
+        can = oracle.CanonLatticeDecoder(OG, **oopts)
         can.decode(lps[i])
         cl = can.get_raw_lattice()
         gl = lats[i]
