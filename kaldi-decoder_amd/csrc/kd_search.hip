@@ -2650,6 +2650,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       // bounds what FinalizeDecoding will have to look at and, with it, memory
       if (frame < target && frame > 0 && frame % p.lat.prune_interval == 0 && frame - 1 > visited) {
         __syncthreads();
+        KD_LAP(s, 13);
         if (tid == 0) {  // (the collector takes archive chunks through the same cursors' owner)
           KD_G UttMem *m = ToG(p.mem) + utt;
           m->arena_next = s.arena_next; m->arena_end = s.arena_end;
@@ -2666,6 +2667,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
         FullClear<true>(tl, s);
         front_lds = false;
         upper_dirty = false;
+        KD_LAP(s, 23);
       }
     }
   }

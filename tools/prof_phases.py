@@ -24,7 +24,7 @@ NAMES = ['0 frame start/ll row', '1 GetCutoff', '2 prepass', '3 emit filter: ite
          '12 stats fold + barrier', '13 clear/loop', '14 spill-mode frames', '15 aborted LDS attempts',
          '16 R2 back-pointers', '17 link records', '18 best token + frame index',
          '19 small (LDS-resident) frames', '20 tail: final costs', '21 tail: FinalizeDecoding',
-         '22 tail: GetRawLattice', '23 -']
+         '22 tail: GetRawLattice', '23 periodic sweep + collector']
 
 
 def run(kind, B=None):
@@ -36,7 +36,10 @@ def run(kind, B=None):
     G = cabi.Graph(g)
     dev = torch.from_numpy(np.stack(lps)).cuda()
     cls = cabi.LatticeBatch if wl["lattice"] else cabi.Batch
-    bt = cls(G, max_batch=B, max_frames=T, **wl["opts"])
+    opts = dict(wl["opts"])
+    if os.environ.get("KD_PRUNE_INTERVAL"):
+        opts["prune_interval"] = int(os.environ["KD_PRUNE_INTERVAL"])
+    bt = cls(G, max_batch=B, max_frames=T, **opts)
     for _ in range(2):
         bt.decode_device([dev[i].data_ptr() for i in range(B)], [T] * B, V)
     cyc, st = bt.phase_cycles(), bt.stats()
