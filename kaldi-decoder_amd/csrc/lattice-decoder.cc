@@ -226,7 +226,16 @@ bool ShortestPath(const Lattice &in, Lattice *out) {
     for (size_t k = 0; k < arcs.size(); ++k) {
       const LatticeArc &a = arcs[k];
       const float n1 = d1[s] + a.weight.graph, n2 = d2[s] + a.weight.acoustic;
-      if (better(n1, n2, d1[a.nextstate], d2[a.nextstate])) {
+      // Exact (graph, acoustic) ties: the device exports a frame's states and arcs in
+      // arena order, which varies from run to run, so "first found" would too.  The arc
+      // with the smaller (olabel, ilabel) wins -- tied arcs that carry the same labels
+      // give the same symbol sequences whichever is taken.
+      bool tie_wins = false;
+      if (n1 == d1[a.nextstate] && n2 == d2[a.nextstate] && back_state[a.nextstate] >= 0) {
+        const LatticeArc &cur = in.Arcs(back_state[a.nextstate])[back_arc[a.nextstate]];
+        tie_wins = a.olabel < cur.olabel || (a.olabel == cur.olabel && a.ilabel < cur.ilabel);
+      }
+      if (tie_wins || better(n1, n2, d1[a.nextstate], d2[a.nextstate])) {
         d1[a.nextstate] = n1;
         d2[a.nextstate] = n2;
         back_state[a.nextstate] = s;
