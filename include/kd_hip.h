@@ -159,6 +159,10 @@ int kd_batch_sync(kd_batch *b);
 int kd_batch_decode_async(kd_batch *b, int32_t batch, const float *const *loglikes_dev,
                           const int32_t *num_rows, const int32_t *offset, int32_t num_cols,
                           int64_t row_stride, int32_t want);
+/* The same, waiting for the result; host matrices (KD_MEM_HOST) are staged first. */
+int kd_batch_decode(kd_batch *b, int32_t batch, const float *const *loglikes,
+                    const int32_t *num_rows, const int32_t *offset, int32_t num_cols,
+                    int64_t row_stride, int mem_kind, int32_t want);
 
 /* FasterDecoder::NumFramesDecoded per utterance (ref: csrc/faster-decoder.h:104). */
 int kd_batch_num_frames_decoded(kd_batch *b, int32_t *out);

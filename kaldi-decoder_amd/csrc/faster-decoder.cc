@@ -124,8 +124,44 @@ void BatchFasterDecoder::AdvanceDecoding(const std::vector<DecodableInterface *>
   KdCheck(kd_batch_advance(b_, ptr.data(), rows.data(), off.data(), cols, cols, KD_MEM_HOST, -1));
 }
 
+// Matrix-backed decodables of one layout (all DecodableCtc, all on the host or all on the
+// device, one row stride): their pointers, rows and offsets for the one-launch Decode.
+static bool AllCtc(const std::vector<DecodableInterface *> &decodables, std::vector<const float *> *ptr,
+                   std::vector<int32_t> *rows, std::vector<int32_t> *off, int32_t *cols,
+                   int64_t *stride, bool *on_device) {
+  const size_t n = decodables.size();
+  if (n == 0) return false;
+  ptr->resize(n); rows->resize(n); off->resize(n);
+  *cols = decodables[0]->NumIndices();
+  *stride = -1;
+  for (size_t i = 0; i < n; ++i) {
+    auto *d = dynamic_cast<DecodableCtc *>(decodables[i]);
+    if (!d || d->NumCols() != *cols) return false;
+    if (i == 0) { *stride = d->RowStride(); *on_device = d->OnDevice(); }
+    if (d->RowStride() != *stride || d->OnDevice() != *on_device) return false;
+    (*ptr)[i] = d->Data();
+    (*rows)[i] = d->NumRows();
+    (*off)[i] = d->Offset();
+  }
+  return true;
+}
+
 void BatchFasterDecoder::Decode(const std::vector<DecodableInterface *> &decodables) {
-  InitDecoding(static_cast<int32_t>(decodables.size()));  // faster-decoder.cc:121-124
+  // faster-decoder.cc:121-124.  Matrix-backed decodables: InitDecoding, every frame,
+  // ReachedFinal and GetBestPath in ONE kernel launch; others go call by call.
+  std::vector<const float *> ptr;
+  std::vector<int32_t> rows, off;
+  int32_t cols = 0;
+  int64_t stride = 0;
+  bool dev = false;
+  if (AllCtc(decodables, &ptr, &rows, &off, &cols, &stride, &dev)) {
+    KdCheck(kd_batch_decode(b_, static_cast<int32_t>(decodables.size()), ptr.data(), rows.data(),
+                            off.data(), cols, stride, dev ? KD_MEM_DEVICE : KD_MEM_HOST,
+                            KD_DECODE_BEST_PATH));
+    batch_ = static_cast<int32_t>(decodables.size());
+    return;
+  }
+  InitDecoding(static_cast<int32_t>(decodables.size()));
   AdvanceDecoding(decodables);
 }
 

@@ -877,6 +877,38 @@ static uint32_t TailFlags(const kd_batch *b, int32_t want) {
   return t;
 }
 
+// Host matrices: only the rows this call will read are staged (packed to num_cols), and
+// the utterances' ll pointers are set so that row (frame - offset) of the caller's matrix
+// is row (frame - first decoded frame) of the staged block.  `done` = frames decoded so far.
+static int StageHost(kd_batch *b, const float *const *loglikes, int32_t num_cols, int64_t row_stride,
+                     const int32_t *done) {
+  UttCtl *uc = b->h_ctl();
+  size_t total = 0;
+  std::vector<size_t> first(b->batch), count(b->batch);
+  for (int i = 0; i < b->batch; ++i) {
+    const int32_t f0 = done ? std::max(done[i], 0) : 0, f1 = uc[i].target;
+    first[i] = f1 > f0 ? static_cast<size_t>(f0 - uc[i].offset) : 0;
+    count[i] = f1 > f0 ? static_cast<size_t>(f1 - f0) : 0;
+    total += count[i] * num_cols;
+  }
+  if (total > 0 && num_cols < b->g->max_ilabel)
+    return Fail(KD_E_INVALID, "log-likelihood matrix has " + std::to_string(num_cols) +
+                              " columns but the graph's largest ilabel is " + std::to_string(b->g->max_ilabel));
+  KD_HIP_TRY(b->staging.Reserve(total));
+  size_t pos = 0;
+  for (int i = 0; i < b->batch; ++i) {
+    if (count[i]) {
+      KD_HIP_TRY(hipMemcpy2DAsync(b->staging.p + pos, num_cols * sizeof(float),
+                                  loglikes[i] + first[i] * row_stride, row_stride * sizeof(float),
+                                  num_cols * sizeof(float), count[i], hipMemcpyHostToDevice,
+                                  b->stream));
+    }
+    uc[i].ll = b->staging.p + pos - first[i] * static_cast<size_t>(num_cols);
+    pos += count[i] * num_cols;
+  }
+  return KD_OK;
+}
+
 int kd_batch_decode_async(kd_batch *b, int32_t batch, const float *const *loglikes_dev,
                           const int32_t *num_rows, const int32_t *offset, int32_t num_cols,
                           int64_t row_stride, int32_t want) {
@@ -901,6 +933,34 @@ int kd_batch_decode_async(kd_batch *b, int32_t batch, const float *const *loglik
   b->l_tail_flags = tail;
   b->initialized = true;
   return Enqueue(b);
+}
+
+int kd_batch_decode(kd_batch *b, int32_t batch, const float *const *loglikes, const int32_t *num_rows,
+                    const int32_t *offset, int32_t num_cols, int64_t row_stride, int mem_kind,
+                    int32_t want) {
+  if (mem_kind == KD_MEM_DEVICE) {
+    if (int r = kd_batch_decode_async(b, batch, loglikes, num_rows, offset, num_cols, row_stride, want))
+      return r;
+    return ReadBack(b);
+  }
+  if (mem_kind != KD_MEM_HOST) return Fail(KD_E_INVALID, "bad mem_kind");
+  if (!b || !loglikes || !num_rows || num_cols <= 0) return Fail(KD_E_INVALID, "bad argument");
+  if (batch <= 0 || batch > b->max_batch) return Fail(KD_E_INVALID, "bad batch size");
+  if (row_stride < num_cols) return Fail(KD_E_INVALID, "row_stride < num_cols");
+  KD_HIP_TRY(hipSetDevice(b->g->device));
+  if (b->pending) (void)ReadBack(b);
+  ResetForInit(b, batch);
+  if (int r = PlanAdvance(b, num_rows, offset, -1, true)) return r;
+  if (int r = StageHost(b, loglikes, num_cols, row_stride, nullptr)) return r;
+  const uint32_t tail = TailFlags(b, want);
+  UttCtl *uc = b->h_ctl();
+  for (int i = 0; i < batch; ++i) uc[i].flags |= tail;
+  b->l_num_cols = num_cols;
+  b->l_row_stride = num_cols;
+  b->l_tail_flags = tail;
+  b->initialized = true;
+  if (int r = Enqueue(b)) return r;
+  return ReadBack(b);
 }
 
 int kd_batch_advance_async(kd_batch *b, const float *const *loglikes_dev, const int32_t *num_rows,
@@ -949,31 +1009,7 @@ int kd_batch_advance(kd_batch *b, const float *const *loglikes, const int32_t *n
     if (int r = ReadBack(b)) return r;
   if (int r = PlanAdvance(b, num_rows, offset, max_num_frames, false)) return r;
   UttCtl *uc = b->h_ctl();
-  // stage only the rows this call will read, packed to num_cols
-  size_t total = 0;
-  std::vector<size_t> first(b->batch), count(b->batch);
-  for (int i = 0; i < b->batch; ++i) {
-    const int32_t f0 = b->h_decoded[i], f1 = uc[i].target;
-    first[i] = f1 > f0 ? static_cast<size_t>(f0 - uc[i].offset) : 0;
-    count[i] = f1 > f0 ? static_cast<size_t>(f1 - f0) : 0;
-    total += count[i] * num_cols;
-  }
-  if (total > 0 && num_cols < b->g->max_ilabel)
-    return Fail(KD_E_INVALID, "log-likelihood matrix has " + std::to_string(num_cols) +
-                              " columns but the graph's largest ilabel is " + std::to_string(b->g->max_ilabel));
-  KD_HIP_TRY(b->staging.Reserve(total));
-  size_t pos = 0;
-  for (int i = 0; i < b->batch; ++i) {
-    if (count[i]) {
-      KD_HIP_TRY(hipMemcpy2DAsync(b->staging.p + pos, num_cols * sizeof(float),
-                                  loglikes[i] + first[i] * row_stride, row_stride * sizeof(float),
-                                  num_cols * sizeof(float), count[i], hipMemcpyHostToDevice,
-                                  b->stream));
-    }
-    // row (frame - offset) of the caller's matrix == row (frame - f0) of the staged block
-    uc[i].ll = b->staging.p + pos - first[i] * static_cast<size_t>(num_cols);
-    pos += count[i] * num_cols;
-  }
+  if (int r = StageHost(b, loglikes, num_cols, row_stride, b->h_decoded.data())) return r;
   b->l_num_cols = num_cols;
   b->l_row_stride = num_cols;
   b->l_tail_flags = 0;

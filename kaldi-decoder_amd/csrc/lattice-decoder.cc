@@ -108,9 +108,34 @@ void BatchLatticeDecoder::AdvanceDecoding(const std::vector<DecodableInterface *
 void BatchLatticeDecoder::FinalizeDecoding() { KdCheck(kd_batch_finalize_decoding(b_)); }
 
 std::vector<bool> BatchLatticeDecoder::Decode(const std::vector<DecodableInterface *> &decodables) {
-  InitDecoding(static_cast<int32_t>(decodables.size()));  // lattice-simple-decoder.cc:53-73
-  AdvanceDecoding(decodables);
-  FinalizeDecoding();
+  // lattice-simple-decoder.cc:53-73.  Matrix-backed decodables of one layout: InitDecoding,
+  // every frame, FinalizeDecoding and GetRawLattice(use_final_probs = true) in ONE kernel
+  // launch; others go call by call.
+  bool one_launch = !decodables.empty();
+  std::vector<const float *> ptr(decodables.size());
+  std::vector<int32_t> rows(decodables.size()), off(decodables.size());
+  int32_t cols = decodables.empty() ? 0 : decodables[0]->NumIndices();
+  int64_t stride = -1;
+  bool dev = false;
+  for (size_t i = 0; i < decodables.size() && one_launch; ++i) {
+    auto *d = dynamic_cast<DecodableCtc *>(decodables[i]);
+    if (!d || d->NumCols() != cols) { one_launch = false; break; }
+    if (i == 0) { stride = d->RowStride(); dev = d->OnDevice(); }
+    if (d->RowStride() != stride || d->OnDevice() != dev) { one_launch = false; break; }
+    ptr[i] = d->Data();
+    rows[i] = d->NumRows();
+    off[i] = d->Offset();
+  }
+  if (one_launch) {
+    KdCheck(kd_batch_decode(b_, static_cast<int32_t>(decodables.size()), ptr.data(), rows.data(),
+                            off.data(), cols, stride, dev ? KD_MEM_DEVICE : KD_MEM_HOST,
+                            KD_DECODE_FINALIZE | KD_DECODE_LATTICE));
+    batch_ = static_cast<int32_t>(decodables.size());
+  } else {
+    InitDecoding(static_cast<int32_t>(decodables.size()));
+    AdvanceDecoding(decodables);
+    FinalizeDecoding();
+  }
   // the reference returns !final_costs_.empty(): some token of the last frame is in a final state
   std::vector<float> frc = FinalRelativeCost();
   std::vector<bool> r(batch_);

@@ -36,7 +36,7 @@ SYMBOLS = (
     "kd_batch_last_kernel_ms", "kd_batch_device_bytes", "kd_batch_phase_cycles",
     "kd_lattice_options_default", "kd_batch_create_lattice", "kd_batch_finalize_decoding",
     "kd_batch_final_relative_cost", "kd_batch_raw_lattice_prepare", "kd_batch_raw_lattice_copy",
-    "kd_batch_create_simple", "kd_batch_decode_async", "kd_batch_capacity",
+    "kd_batch_create_simple", "kd_batch_decode_async", "kd_batch_decode", "kd_batch_capacity",
 )
 
 
@@ -101,6 +101,8 @@ def lib():
     L.kd_batch_sync.argtypes = [C.c_void_p]
     L.kd_batch_decode_async.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), _i32p,
                                         C.c_void_p, C.c_int32, C.c_int64, C.c_int32]
+    L.kd_batch_decode.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), _i32p, C.c_void_p,
+                                  C.c_int32, C.c_int64, C.c_int, C.c_int32]
     L.kd_batch_capacity.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int64)]
     L.kd_batch_num_frames_decoded.argtypes = [C.c_void_p, _i32p]
     L.kd_batch_status.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.uint32)]
@@ -303,6 +305,19 @@ class Batch:
                                            num_cols if row_stride is None else row_stride, want))
         if sync:
             self.sync()
+
+    def decode_host(self, mats, offsets=None, finalize=True, lattice=True, best_path=True):
+        """Decode() over host matrices (staged to the device first), one launch."""
+        mats = [np.ascontiguousarray(m, np.float32) for m in mats]
+        self.batch = len(mats)
+        V = mats[0].shape[1]
+        rows = np.asarray([m.shape[0] for m in mats], np.int32)
+        off = None if offsets is None else np.ascontiguousarray(offsets, np.int32)
+        want = ((KD_DECODE_FINALIZE if finalize else 0) | (KD_DECODE_LATTICE if lattice else 0) |
+                (KD_DECODE_BEST_PATH if best_path else 0))
+        _check(lib().kd_batch_decode(self.h, self.batch, self._ptrs([m.ctypes.data for m in mats]),
+                                     rows, None if off is None else off.ctypes.data, V, V,
+                                     KD_MEM_HOST, want))
 
     def sync(self):
         _check(lib().kd_batch_sync(self.h))

@@ -349,3 +349,26 @@ def test_periodic_pruning_bounds_memory(oracle):
     created = can.links_created()
     cap = on.capacity()
     assert cap["links_used"] < created // 2, (cap, created)  # the pool never held them all
+
+
+def test_decode_from_host_matrices_in_one_launch(oracle):
+    """kd_batch_decode with KD_MEM_HOST: the matrices are staged, then the same one-launch
+    Decode (ragged lengths); lattice and 1-best batches."""
+    g = synth.hlg_graph(V=30, n_words=100, n_hist=100, avg_succ=6, seed=6)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    opts = dict(beam=9.0, lattice_beam=5.0, min_active=0)
+    lps = [synth.make_logprobs(55 - 6 * i, 30, 60 + i, peak=5.0, lexicon=g["lexicon"]) for i in range(4)]
+    lb = cabi.LatticeBatch(G, max_batch=4, **opts)
+    lb.decode_host(lps)
+    for i, lat in enumerate(lb.raw_lattices()):
+        can = oracle.CanonLatticeDecoder(OG, **opts)
+        can.decode(lps[i])
+        _assert_same_lattice(lat, can.get_raw_lattice(), i)
+    bt = cabi.Batch(G, max_batch=4, beam=9.0)
+    bt.decode_host(lps)
+    paths = bt.best_paths()
+    for i in range(4):
+        d = oracle.FasterDecoder(OG, beam=9.0, policy=1)
+        d.decode(lps[i])
+        p = d.get_best_path()
+        assert paths[i].ilabel.tolist() == p.ilabel.tolist() and paths[i].ac_cost.tolist() == p.ac_cost.tolist()
