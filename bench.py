@@ -348,7 +348,8 @@ def main():
         # every rank runs its collectives alike
         if world > 1 and out is not None:
             if wl["lattice"]:
-                sharded.gather_lattices(out, dst=0)
+                # (left in rank 0's HBM: the gather is the exchange, not a host copy)
+                sharded.gather_lattices(out, dst=0, keep_on_device=True)
             else:
                 sharded.gather_paths([(p.ilabel, p.olabel) for p in out], dst=0)
 
@@ -432,6 +433,22 @@ def main():
         fence()
         alone_ms.append(call(0, G)[1])
     alone_ms = float(np.median(alone_ms))
+    # The PCIe-inclusive rate: the same call fed host matrices (numpy, pageable), which the
+    # library stages to the device first -- never the headline (the boundary hands over
+    # device pointers when the acoustic model runs on the GPU), reported for comparison.
+    host_input = None
+    if not args.search_only and world == 1:
+        ts = []
+        for _ in range(3):
+            fence()
+            t1 = time.perf_counter()
+            bts[0].decode_host(all_lps[:per_slot])
+            (bts[0].raw_lattices() if wl["lattice"] else bts[0].best_paths())
+            ts.append(time.perf_counter() - t1)
+        host_input = dict(value=per_slot * T * SUBSAMPLING / float(np.median(ts)), unit="audio_frames/s",
+                          ms_per_call=float(np.median(ts)) * 1e3,
+                          note=f"one call of {per_slot} utterances at a time, log-probs in pageable "
+                               f"host memory ({per_slot * T * V * 4 / 2**20:.0f} MB per call)")
     # one batch of B utterances alone on the GPU, nothing else in flight: what a caller
     # who submits a single batch gets
     single = []
@@ -472,6 +489,7 @@ def main():
             "ms_per_step": elapsed / steps_timed * 1e3,
             "timed_seconds": elapsed,
             "value_prune_interval_25": value_pi25,
+            "host_input": host_input,
             "single_batch_ms": single_batch_ms,
             "single_batch_value": B * T * SUBSAMPLING / (single_batch_ms * 1e-3),
             "single_batch_kernel_ms": single_kernel_ms,

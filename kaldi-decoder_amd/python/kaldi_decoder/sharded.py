@@ -86,10 +86,52 @@ def lattice_from_blob(blob):
                       sf, sg, fs, fg.view(np.float32))
 
 
-def gather_lattices(lats, dst=0, group=None, as_lattices=False):
-    """Gathers every rank's pruned raw lattices to `dst` in rank order: a list of int32
-    blobs (see lattice_blob), or of RawLattice objects with `as_lattices`; None on the
-    other ranks."""
+def pack_lattice_batch(lats):
+    """cabi.RawLattices (the lattices of one decode call: batch-wide arrays plus offsets) ->
+    one int32 blob, a dozen array operations whatever the number of utterances:
+    [n, states, arcs, finals | sizes (4 per utterance) | the ten arrays back to back]."""
+    n = len(lats)
+    ns, na, nf = int(lats.state_off[-1]), int(lats.arc_off[-1]), int(lats.final_off[-1])
+    head = np.asarray([n, ns, na, nf], np.int32)
+    parts = [head, np.ascontiguousarray(lats.sizes, np.int32).reshape(-1)]
+    parts += [np.ascontiguousarray(a[:na]).view(np.int32) for a in lats.arc_arrays]
+    parts += [np.ascontiguousarray(a[:ns]).view(np.int32) for a in lats.state_arrays]
+    parts += [np.ascontiguousarray(a[:nf]).view(np.int32) for a in lats.final_arrays]
+    return np.concatenate(parts)
+
+
+def unpack_lattice_batch(blob):
+    """Inverse of pack_lattice_batch: a cabi.RawLattices of views into `blob`."""
+    from .cabi import RawLattices
+    blob = np.asarray(blob, np.int32)
+    n, ns, na, nf = (int(x) for x in blob[:4])
+    sizes = blob[4:4 + 4 * n].reshape(n, 4).astype(np.int64)
+    pos = 4 + 4 * n
+    arrs = []
+    for k, m in enumerate((na,) * 6 + (ns,) * 2 + (nf,) * 2):
+        a = blob[pos:pos + m]
+        pos += m
+        arrs.append(a.view(np.float32) if k in (4, 5, 9) else a)
+    so, ao, fo = (np.zeros(n + 1, np.int64) for _ in range(3))
+    so[1:], ao[1:], fo[1:] = np.cumsum(sizes[:, 0]), np.cumsum(sizes[:, 1]), np.cumsum(sizes[:, 2])
+    return RawLattices(sizes, so, ao, fo, tuple(arrs[:6]), tuple(arrs[6:8]), tuple(arrs[8:]))
+
+
+def gather_lattices(lats, dst=0, group=None, as_lattices=False, keep_on_device=False):
+    """Gathers every rank's pruned raw lattices to `dst` in rank order -- the one exchange of
+    a sharded decode.  `lats` is what LatticeBatch.raw_lattices() returned (packed as one
+    blob per rank: pack_lattice_batch) or a list of RawLattice (one blob each).  On `dst`:
+    a list of int32 blobs, or of RawLattice objects with `as_lattices`; with
+    `keep_on_device` (RCCL) the gathered int32 tensors, one per rank, left in the
+    destination GPU's memory (unpack_lattice_batch(t.cpu().numpy()) reads one).  None on
+    the other ranks."""
+    from .cabi import RawLattices
+    if isinstance(lats, RawLattices):
+        got = gather_paths([(pack_lattice_batch(lats), None)], dst=dst, group=group, _single=True,
+                           _keep_on_device=keep_on_device)
+        if got is None or keep_on_device or not as_lattices:
+            return got
+        return [lat for blob in got for lat in unpack_lattice_batch(blob)]
     got = gather_paths([(lattice_blob(lat), None) for lat in lats], dst=dst, group=group,
                        _single=True)
     if got is None or not as_lattices:
@@ -97,7 +139,7 @@ def gather_lattices(lats, dst=0, group=None, as_lattices=False):
     return [lattice_from_blob(b) for b in got]
 
 
-def gather_paths(paths, dst=0, group=None, _single=False):
+def gather_paths(paths, dst=0, group=None, _single=False, _keep_on_device=False):
     """Gathers every rank's best paths to `dst` in rank order; returns the
     concatenated list there and None elsewhere."""
     import torch
@@ -120,6 +162,8 @@ def gather_paths(paths, dst=0, group=None, _single=False):
     if rank == dst:
         bufs = [torch.zeros(mx, dtype=torch.int32, device=dev) for _ in range(world)]
         dist.gather(padded, bufs, dst=dst, group=group)
+        if _keep_on_device:  # (each rank's payload: [1, length, blob]: strip the framing)
+            return [bufs[r][2:sizes[r]] for r in range(world)]
         out = []
         for r in range(world):
             buf = bufs[r][:sizes[r]].cpu().numpy()

@@ -165,3 +165,60 @@ def test_gather_lattices_world2_gloo(spans):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _fake_batch(lo, hi):
+    """A cabi.RawLattices holding _fake_lattice(lo..hi-1), as LatticeBatch.raw_lattices() builds it."""
+    from kaldi_decoder.cabi import RawLattices
+    ls = [_fake_lattice(u) for u in range(lo, hi)]
+    sizes = np.array([[l.num_states, len(l.src), len(l.final_state), l.start] for l in ls],
+                     np.int64).reshape(len(ls), 4)
+    so, ao, fo = (np.zeros(len(ls) + 1, np.int64) for _ in range(3))
+    if len(ls):
+        so[1:], ao[1:], fo[1:] = np.cumsum(sizes[:, 0]), np.cumsum(sizes[:, 1]), np.cumsum(sizes[:, 2])
+    cat = lambda k, dt: (np.concatenate([getattr(l, k) for l in ls]) if ls else np.zeros(0, dt))  # noqa: E731
+    arcs = tuple(cat(k, np.float32 if k.endswith("cost") else np.int32) for k in _LAT_FIELDS[:6])
+    states = tuple(cat(k, np.int32) for k in _LAT_FIELDS[6:8])
+    finals = (cat("final_state", np.int32), cat("final_graph", np.float32))
+    return RawLattices(sizes, so, ao, fo, arcs, states, finals)
+
+
+def test_lattice_batch_pack_roundtrip():
+    for lo, hi in ((0, 9), (3, 4), (5, 5)):
+        got = sharded.unpack_lattice_batch(sharded.pack_lattice_batch(_fake_batch(lo, hi)))
+        assert len(got) == hi - lo
+        for k, u in enumerate(range(lo, hi)):
+            assert _same_lattice(got[k], _fake_lattice(u))
+
+
+def _batch_worker(rank, world, port, spans, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = spans[rank]
+    got = sharded.gather_lattices(_fake_batch(lo, hi), dst=0, as_lattices=True)
+    if rank == 0:
+        total = spans[-1][1]
+        q.put(len(got) == total and all(_same_lattice(got[u], _fake_lattice(u)) for u in range(total)))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("spans", [((0, 6), (6, 11)), ((0, 4), (4, 4))])
+def test_gather_of_whole_call_results_world2_gloo(spans):
+    """What bench.py --gpus N sends: one packed blob per rank and call (the batch-wide arrays of
+    LatticeBatch.raw_lattices()), reassembled on rank 0 into every utterance's RawLattice."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, spans, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
