@@ -28,9 +28,12 @@
 #ifndef KD_LEPS_REGS
 #define KD_LEPS_REGS 4
 #endif
-// extra-cost keys of one frame kept in LDS: what the search's LDS block holds (144 KiB of
-// 160 with one workgroup per CU)
-constexpr int kLdsToks = ((static_cast<int>(sizeof(Shared)) - 512) / 4) / 2048 * 2048;
+// Extra-cost keys of one frame kept in LDS (144 KiB of 160 with one workgroup per CU): the
+// part of the search's LDS block below the frontier's state array.  The periodic sweep
+// runs BETWEEN two frames of the search, when the block already holds the next frame's
+// log-likelihood row, the frame counters and the launch's statistics: the keys end where
+// `it_src` begins, and the few words behind them stay below `ll` (asserted).
+constexpr int kLdsToks = static_cast<int>(offsetof(Shared, it_src) / 4) / 2048 * 2048;
 constexpr uint32_t kFInfKey = 0xFF800000u;  // FloatKey(+inf)
 constexpr int kEpsRegs = KD_LEPS_REGS;  // epsilon links of a frame a lane keeps in registers
 
@@ -48,7 +51,8 @@ struct TailShared {
   long long r_out_off;
   float r_final_rel;
 };
-static_assert(sizeof(TailShared) <= sizeof(Shared), "the tail reuses the search's LDS block");
+static_assert(sizeof(TailShared) <= offsetof(Shared, ll),
+              "the tail reuses the search's LDS block, below what a periodic sweep must leave alone");
 __device__ __forceinline__ TailShared &TailLds() { return *reinterpret_cast<TailShared *>(kd_smem); }
 
 __device__ __forceinline__ float FInf() { return __int_as_float(0x7F800000); }
@@ -500,13 +504,7 @@ __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &
   const int nf = s.n_finals;
   if (tid == 0) {
     const unsigned long long words = static_cast<unsigned long long>(ns) + nf + 3ull * na;
-    const unsigned long long b = atomicAdd(&p.ctl->out_top, words) - p.out_base;
-    if (b + words > p.lat.out_cap) {
-      atomicAdd(&p.ctl->out_top, 0ull - words);
-      s.out_off = -1;
-    } else {
-      s.out_off = static_cast<long long>(b);
-    }
+    s.out_off = PoolTake(&p.ctl->out_top, p.out_base, p.lat.out_cap, words);
     s.count = 0;  // (finals written so far)
   }
   __syncthreads();
@@ -642,13 +640,7 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
   // the utterance's region of the output pool: states | finals | arcs, in 8-byte words
   if (tid == 0) {
     const unsigned long long words = static_cast<unsigned long long>(ns) + nf + 3ull * na;
-    const unsigned long long b = atomicAdd(&p.ctl->out_top, words) - p.out_base;
-    if (b + words > p.lat.out_cap) {
-      atomicAdd(&p.ctl->out_top, 0ull - words);
-      s.out_off = -1;
-    } else {
-      s.out_off = static_cast<long long>(b);
-    }
+    s.out_off = PoolTake(&p.ctl->out_top, p.out_base, p.lat.out_cap, words);
   }
   __syncthreads();
   const long long off = s.out_off;

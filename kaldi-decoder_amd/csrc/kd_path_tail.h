@@ -143,13 +143,7 @@ __device__ __noinline__ uint32_t PathTail(CParams *pp, int utt, int F, uint32_t 
   if (len >= st.cap) { __syncthreads(); return KD_UTT_OUT_FULL; }  // (a path of > 32 k arcs)
   if (tid == 0) {
     const unsigned long long words = 3ull * len;
-    const unsigned long long b = atomicAdd(&p.ctl->out_top, words) - p.out_base;
-    if (b + words > p.lat.out_cap) {
-      atomicAdd(&p.ctl->out_top, 0ull - words);
-      s.out_off = -1;
-    } else {
-      s.out_off = static_cast<long long>(b);
-    }
+    s.out_off = PoolTake(&p.ctl->out_top, p.out_base, p.lat.out_cap, words);
   }
   __syncthreads();
   const long long off = s.out_off;

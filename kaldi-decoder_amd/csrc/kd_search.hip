@@ -449,6 +449,22 @@ __device__ __forceinline__ unsigned long long BlockMinU64(Shared &s, unsigned lo
 // the old chunk is abandoned: at most one frame's worth).  Returns 0 or the KD_UTT_* bit
 // of the pool that is exhausted -- the frame is then not committed, and the host grows
 // the pool and relaunches (kd_api.hip).  Call from one thread.
+// `want` units from a pool cursor, or -1 when they do not fit below `cap`.  Compare-and-
+// swap, not add-then-take-back: an allocator that adds first and subtracts on failure
+// moves, for a moment, the base of every allocation that succeeds in between, and its
+// subtraction then pulls the cursor back UNDER them (two utterances end up with the same
+// records -- seen as rare wrong lattices when a pool ran out mid-launch).
+__device__ __forceinline__ long long PoolTake(unsigned long long *top, unsigned long long base,
+                                              unsigned long long cap, unsigned long long want) {
+  unsigned long long old = atomicAdd(top, 0ull);
+  while (true) {
+    if (old - base + want > cap) return -1;
+    const unsigned long long seen = atomicCAS(top, old, old + want);
+    if (seen == old) return static_cast<long long>(old - base);
+    old = seen;
+  }
+}
+
 // A chunk of `want` records of pool `links ? link : token`: one of the utterance's own
 // freed chunks if the request is of standard size, else the next of the pool.  -1: the
 // pool is exhausted.
@@ -458,12 +474,7 @@ __device__ __forceinline__ long long PoolChunk(CParams &p, KD_G ChunkRing *ring,
   if (want == standard && ring->n_free > 0) return ring->free_start[--ring->n_free];
   unsigned long long *top = links ? &p.ctl->link_top : &p.ctl->tok_top;
   const unsigned long long base = links ? p.link_base : p.tok_base, cap = links ? p.link_cap : p.tok_cap;
-  const unsigned long long b = atomicAdd(top, want) - base;
-  if (b + want > cap) {
-    atomicAdd(top, 0ull - want);
-    return -1;
-  }
-  return static_cast<long long>(b);
+  return PoolTake(top, base, cap, want);
 }
 
 // Notes a nursery chunk that is full (`last` = the last frame plus one with a block in

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Randomised parity runs of the GPU decoders against the oracle's canonical decoders:
+random graphs, options (beams, max/min_active, prune_interval), batch sizes, pool sizes
+(small ones grow), one-launch Decode or chunked AdvanceDecoding.
+
+    python tools/fuzz_gpu.py [seconds] [seed]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "kaldi-decoder_amd", "python")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from kaldi_decoder import cabi, synth  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+INT_MAX = 2**31 - 1
+
+
+def graph(rng):
+    k = rng.integers(0, 5)
+    if k == 0:
+        V = int(rng.integers(4, 40))
+        return synth.ctc_topo(V), None, V
+    if k == 1:
+        V = int(rng.integers(8, 24))
+        return synth.random_graph(int(rng.integers(50, 3000)), float(rng.uniform(2, 5)), V,
+                                  float(rng.uniform(0, 0.35)), int(rng.integers(0, 10**6))), None, V
+    V = int(rng.integers(20, 60))
+    if k == 2:
+        g = synth.hl_graph(V=V, n_words=int(rng.integers(30, 600)), seed=int(rng.integers(0, 10**6)))
+    else:
+        n = int(rng.integers(30, 400))
+        g = synth.hlg_graph(V=V, n_words=n, n_hist=n, avg_succ=int(rng.integers(3, 12)),
+                            seed=int(rng.integers(0, 10**6)))
+    return g, g["lexicon"], V
+
+
+def same_lattice(gl, cl):
+    return (gl.ok == cl.ok and gl.num_states == cl.num_states and gl.state_set() == cl.state_set() and
+            gl.arc_set() == cl.arc_set() and len(gl.src) == len(cl.src) and gl.final_set() == cl.final_set())
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    t_end = time.time() + budget
+    n_cases = n_lat = n_1b = 0
+    while time.time() < t_end:
+        g, lex, V = graph(rng)
+        G, OG = cabi.Graph(g), oracle.Graph(g)
+        B = int(rng.integers(1, 9))
+        T = int(rng.integers(1, 90))
+        peak = float(rng.uniform(0.5, 9))
+        lps = [synth.make_logprobs(max(1, T - int(rng.integers(0, 10))), V, int(rng.integers(0, 10**6)),
+                                   peak=peak, lexicon=lex) for _ in range(B)]
+        dev = [torch.from_numpy(lp).cuda() for lp in lps]
+        beam = float(rng.uniform(2, 14))
+        ma = INT_MAX if rng.random() < 0.6 else int(rng.integers(5, 400))
+        mi = 0 if rng.random() < 0.5 else int(rng.integers(1, min(ma, 40)))
+        small = rng.random() < 0.4
+        cap = dict(arena_tokens=int(rng.integers(256, 4096)), max_frames=int(rng.integers(1, 16)),
+                   table_slots=1 << 14) if small else {}
+        one_launch = rng.random() < 0.5
+        chunk = int(rng.integers(1, 25))
+        tag = dict(B=B, T=T, V=V, beam=beam, ma=ma, mi=mi, small=small, one=one_launch, chunk=chunk,
+                   states=g["num_states"])
+        if rng.random() < 0.6:
+            lbeam = float(rng.uniform(1, 8))
+            pi = int(rng.integers(1, 30)) if rng.random() < 0.7 else 10**6
+            opts = dict(beam=beam, lattice_beam=lbeam, max_active=ma, min_active=mi)
+            if small:
+                cap["arena_links"] = int(rng.integers(256, 4096))
+            lb = cabi.LatticeBatch(G, max_batch=B, prune_interval=pi, **opts, **cap)
+            if one_launch:
+                lb.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V)
+            else:
+                lb.init_decoding(B)
+                for _ in range(0, T, chunk):
+                    lb.advance_host(lps, max_num_frames=chunk)
+                lb.finalize_decoding()
+            lats, frc = lb.raw_lattices(), lb.final_relative_cost()
+            for i, lp in enumerate(lps):
+                can = oracle.CanonLatticeDecoder(OG, **opts)
+                can.decode(lp)
+                if not same_lattice(lats[i], can.get_raw_lattice()) or not (
+                        frc[i] == can.final_relative_cost() or
+                        (np.isinf(frc[i]) and np.isinf(can.final_relative_cost()))):
+                    print("LATTICE MISMATCH", tag, dict(lbeam=lbeam, pi=pi, utt=i), flush=True)
+                    sys.exit(1)
+            n_lat += 1
+        else:
+            opts = dict(beam=beam, max_active=ma, min_active=mi)
+            bt = cabi.Batch(G, max_batch=B, **opts, **cap)
+            if one_launch:
+                bt.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V)
+            else:
+                bt.init_decoding(B)
+                for _ in range(0, T, chunk):
+                    bt.advance_host(lps, max_num_frames=chunk)
+            uf = bool(rng.integers(0, 2))
+            paths, rf = bt.best_paths(uf), bt.reached_final()
+            for i, lp in enumerate(lps):
+                d = oracle.FasterDecoder(OG, policy=1, **opts)
+                d.decode(lp)
+                p = d.get_best_path(uf)
+                q = paths[i]
+                if (q.ok != p.ok or q.ilabel.tolist() != p.ilabel.tolist() or q.state.tolist() != p.state.tolist()
+                        or q.ac_cost.tolist() != p.ac_cost.tolist() or q.graph_cost.tolist() != p.graph_cost.tolist()
+                        or tuple(q.final_weight) != tuple(p.final_weight) or bool(rf[i]) != d.reached_final()):
+                    print("PATH MISMATCH", tag, dict(uf=uf, utt=i), flush=True)
+                    sys.exit(1)
+            n_1b += 1
+        n_cases += 1
+    print(f"fuzz ok: {n_cases} cases ({n_lat} lattice, {n_1b} 1-best) in {budget:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
