@@ -21,6 +21,12 @@ INT_MAX = 2**31 - 1
 
 
 def graph(rng):
+    if rng.random() < 0.04:
+        # heavy: tens of thousands of states under flat posteriors -- frontiers far beyond
+        # the LDS tiers (the global-table tier, table growth, oversized pool blocks)
+        V = int(rng.integers(8, 24))
+        return synth.random_graph(int(rng.integers(8000, 50000)), float(rng.uniform(3, 5)), V,
+                                  float(rng.uniform(0, 0.2)), int(rng.integers(0, 10**6))), None, V
     k = rng.integers(0, 5)
     if k == 0:
         V = int(rng.integers(4, 40))
@@ -52,13 +58,14 @@ def main():
     while time.time() < t_end:
         g, lex, V = graph(rng)
         G, OG = cabi.Graph(g), oracle.Graph(g)
-        B = int(rng.integers(1, 9))
-        T = int(rng.integers(1, 90))
-        peak = float(rng.uniform(0.5, 9))
+        heavy = g["num_states"] >= 8000
+        B = int(rng.integers(1, 4 if heavy else 9))
+        T = int(rng.integers(1, 30 if heavy else 90))
+        peak = float(rng.uniform(0.3, 3) if heavy else rng.uniform(0.5, 9))
         lps = [synth.make_logprobs(max(1, T - int(rng.integers(0, 10))), V, int(rng.integers(0, 10**6)),
                                    peak=peak, lexicon=lex) for _ in range(B)]
         dev = [torch.from_numpy(lp).cuda() for lp in lps]
-        beam = float(rng.uniform(2, 14))
+        beam = float(rng.uniform(8, 25) if heavy else rng.uniform(2, 14))
         ma = INT_MAX if rng.random() < 0.6 else int(rng.integers(5, 400))
         mi = 0 if rng.random() < 0.5 else int(rng.integers(1, min(ma, 40)))
         small = rng.random() < 0.4
