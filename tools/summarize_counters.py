@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""gpurun_out/pmc_<round>_*/ (tools/pmc_counters.sh) -> profiles/<round>_search_counters.json:
+per-launch averages over the full-size launches of SearchKernel."""
+import csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+out = {}
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{rnd}_*", "*counter_collection.csv"))):
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if "SearchKernel" not in r["Kernel_Name"]:
+            continue
+        g = r.get("Grid_Size_X") or r.get("Grid_Size")
+        w = r.get("Workgroup_Size_X") or r.get("Workgroup_Size")
+        if int(g) // int(w) < 256:
+            continue
+        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        out[k] = sum(v) / len(v)
+d = {"note": "rocprofv3 --pmc passes (tools/pmc_counters.sh) over tools/call_timing.py 4: calls of 512 "
+             "utterances x 250 frames (one launch each, one in flight, prune_interval off), averages per "
+             "launch of SearchKernel<1> (search + FinalizeDecoding + GetRawLattice)",
+     "counters": out}
+if "SQ_INSTS_VALU" in out:
+    arcs = 8200.04 * 512 * 250  # arcs scanned per launch (bench line: arcs_scanned_per_frame x utterance-frames)
+    d["wave_instructions_per_arc_scanned"] = {k: out[k] / arcs for k in
+                                              ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
+                                               "SQ_INSTS_VMEM_WR") if k in out}
+if "TCC_HIT_sum" in out and "TCC_REQ_sum" in out:
+    d["l2_hit_rate"] = out["TCC_HIT_sum"] / out["TCC_REQ_sum"]
+json.dump(d, open(os.path.join(ROOT, "profiles", f"{rnd}_search_counters.json"), "w"), indent=1)
+print(json.dumps(d, indent=1))
