@@ -112,6 +112,19 @@ OPTS_C = dict(beam=1.0, min_active=2, max_active=INT_MAX, beam_delta=0.5)
 FRONTIERS_C = [{0: 0.0}, {1: 1.0, 2: 1.5, 3: 4.0, 4: 6.0}, {1: 1.0, 2: 2.5, 5: 4.0}]
 PATH_C = dict(ilabel=[1, 2], olabel=[1, 5], state=[1, 5], graph=[1.0, 2.0], ac=[0.0, 1.0])
 
+# ---------------------------------------------------------------------------------------
+# Graph C again, max_active binding: beam 10, max_active 2, min_active 0, beam_delta 0.5.
+#  frame 0: one token: not more than max_active (:289), more than min_active = 0 ->
+#    min_active_cutoff = best_cost = 0 (:312-313), not above beam_cutoff 10: adaptive_beam =
+#    beam = 10, weight_cutoff 10 (:331-334).  new weights 1.0, 1.5, 4.0, 6.0; the running
+#    cutoff ends at 1.0 + 10 = 11: all kept.          frontier {1: 1.0, 2: 1.5, 3: 4.0, 4: 6.0}
+#  frame 1: 4 tokens > max_active: nth_element at 2 of [1, 1.5, 4, 6] -> max_active_cutoff =
+#    4.0 (:291-295) < beam_cutoff 11: adaptive_beam = 4.0 - 1.0 + 0.5 = 3.5, weight_cutoff 4.0
+#    (:297-303).  Expanded: cost < 4.0 = states 1 and 2 -- max_active tokens.  From here on
+#    exactly as in the min_active case above (same weight_cutoff 4.0, same adaptive_beam 3.5):
+#                                                     frontier {1: 1.0, 2: 2.5, 5: 4.0}
+OPTS_C_MAX = dict(beam=10.0, min_active=0, max_active=2, beam_delta=0.5)
+
 FASTER_CASES = [
     ("eps-improves", graph_a, LP_A, dict(beam=16.0, min_active=0, max_active=INT_MAX), FRONTIERS_A,
      True, PATH_A, (0.5, 0.0)),
@@ -120,6 +133,7 @@ FASTER_CASES = [
     ("tie", graph_b, LP_B, dict(beam=16.0, min_active=0, max_active=INT_MAX), FRONTIERS_B, True,
      PATH_B, (0.0, 0.0)),
     ("min-active", graph_c, LP_C, OPTS_C, FRONTIERS_C, True, PATH_C, (0.25, 0.0)),
+    ("max-active", graph_c, LP_C, OPTS_C_MAX, FRONTIERS_C, True, PATH_C, (0.25, 0.0)),
 ]
 
 # ---------------------------------------------------------------------------------------
