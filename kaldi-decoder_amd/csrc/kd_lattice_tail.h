@@ -37,8 +37,28 @@ constexpr int kLdsToks = static_cast<int>(offsetof(Shared, it_src) / 4) / 2048 *
 constexpr uint32_t kFInfKey = 0xFF800000u;  // FloatKey(+inf)
 constexpr int kEpsRegs = KD_LEPS_REGS;  // epsilon links of a frame a lane keeps in registers
 
+// A WINDOW of the backward sweep: consecutive frames whose links fit the lanes' registers
+// (kWinRegs each) and whose tokens fit half the key array, swept together (SweepWindow).
+#ifndef KD_WIN_REGS
+#define KD_WIN_REGS 8
+#endif
+constexpr int kWinMax = 32;  // frames per window, at most
+constexpr int kWinRegs = KD_WIN_REGS;
+constexpr int kWinLinks = kWinRegs * kBlock;
+constexpr int kWinToks = kLdsToks / 2;
+struct WinShared {
+  // frame f - j of the window that starts at frame f (all kWinMax read, the first W used)
+  long long base[kWinMax], eb[kWinMax], pb[kWinMax];
+  int32_t n[kWinMax], en[kWinMax], pn[kWinMax];
+  int32_t tok_off[kWinMax + 1];      // where the frame's tokens start in the window's key array
+  int32_t seg_off[2 * kWinMax + 1];  // ... and its emitting (2j) and epsilon (2j + 1) links in link order
+  int32_t fchanged[kWinMax];         // periodic: an extra cost of the frame moved by more than delta
+  int32_t W, flag[3];
+};
+
 struct TailShared {
   uint32_t ne[kLdsToks];
+  WinShared win;
   int32_t red_i[kWaves];
   uint32_t best_key, bestwf_key;
   int32_t any_final, changed, count, start_id, empty_frame, frame_changed;
@@ -203,6 +223,208 @@ __device__ __forceinline__ bool Moved(float a, float b, float delta) {
   return !(fabsf(a - b) <= delta);
 }
 
+// The sweep over a window of small frames.  A frame of the median size (68 links) costs
+// what its chain of dependent memory round trips and barriers costs, whatever it holds;
+// frame by frame that is 7-10 k cycles each.  Here the link records of up to kWinMax
+// consecutive frames are fetched at once into registers (source and destination as
+// positions in the window's key array) and the whole window is relaxed in LDS:
+//   B[token] = min over its surviving links of max(B[destination] + delta, 0)
+// starting from +inf (from ABOVE), in place, every link of the window applied each
+// round until a round lowers nothing.  Links whose destination lies above the window
+// (the emitting links of its top frame) are applied once, from final values.  The
+// links form a DAG -- emitting links lead one frame up, epsilon links follow the graph's
+// acyclic epsilon arcs -- so the fixpoint is unique and equals what the frame-by-frame
+// sweep computes: a key only ever holds a candidate that a real chain of links
+// produces, never less than the true value, and when a round changes nothing every key
+// is the minimum over the links at their destinations' final values.  A link is applied
+// only while its cost is within lattice_beam (its cost only falls from round to round),
+// and excised (:264) after the last round if it still is not.  Lanes walk the links in
+// frame order (top frame first), so most windows settle in a few rounds.
+// Returns the number of frames swept (>= 1: the caller has checked that frame f fits).
+__device__ __forceinline__ bool WinFits(int n, int en, int pn) {
+  return n <= kWinToks && en + pn <= kWinLinks;
+}
+
+__device__ __forceinline__ int SweepWindow(CParams &p, TailShared &s, const Stage &st, long long fb,
+                                           int f, bool periodic, int visited, float delta,
+                                           const uint32_t *&next_b, long long &next_base, int &flip,
+                                           bool &stop) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const float lattice_beam = p.lat.lattice_beam;
+  WinShared &w = s.win;
+  if (tid < 64) {  // the descriptors of frames f, f - 1, ...; how many fit
+    const int k = f - lane;
+    const bool in = lane < kWinMax && k >= 0;
+    const long long at = fb + (in ? k : f);
+    const long long base = ToG(p.frame_base)[at], eb = ToG(p.link_emit_base)[at], pb = ToG(p.link_eps_base)[at];
+    int n = ToG(p.frame_count)[at], en = ToG(p.link_emit_count)[at], pn = ToG(p.link_eps_count)[at];
+    if (!in) { n = 0; en = 0; pn = 0; }
+    int ct = n, cl = en + pn;
+#pragma unroll
+    for (int d = 1; d < kWinMax; d <<= 1) {
+      const int yt = __shfl_up(ct, d, 64), yl = __shfl_up(cl, d, 64);
+      if (lane >= d) { ct += yt; cl += yl; }
+    }
+    const unsigned long long m = __ballot(in && ct <= kWinToks && cl <= kWinLinks);
+    const int W = __builtin_ctzll(~m);
+    if (lane < kWinMax) {
+      w.base[lane] = base; w.eb[lane] = eb; w.pb[lane] = pb;
+      w.n[lane] = n; w.en[lane] = en; w.pn[lane] = pn;
+      w.tok_off[lane] = ct - n;
+      w.seg_off[2 * lane] = cl - en - pn;
+      w.seg_off[2 * lane + 1] = cl - pn;
+      w.fchanged[lane] = 0;
+    }
+    if (lane == kWinMax - 1) { w.tok_off[kWinMax] = ct; w.seg_off[2 * kWinMax] = cl; }
+    if (lane == 0) { w.W = W; w.flag[0] = 0; w.flag[1] = 0; w.flag[2] = 0; }
+  }
+  __syncthreads();
+  const int W = w.W, NT = w.tok_off[W], NL = w.seg_off[2 * W];
+  uint32_t *B = s.ne + flip * (kLdsToks / 2);
+  flip ^= 1;
+  for (int i = tid; i < NT; i += kBlock) B[i] = kFInfKey;
+  // this lane's links: link g = tid + r * kBlock of the window's link order
+  constexpr int kDead = -1, kSrcBits = 16, kEmitBit = 1 << 24, kDoneBit = 1 << 25;
+  static_assert(kWinToks < (1 << kSrcBits) && kWinMax <= 256, "link slot packing");
+  uint32_t at[kWinRegs];
+  int meta[kWinRegs];  // source position | frame index << 16 | emitting | applied for good
+  int32_t dst[kWinRegs], src[kWinRegs];
+  float dl[kWinRegs];
+#pragma unroll
+  for (int r = 0; r < kWinRegs; ++r) {
+    const int g = tid + r * kBlock;
+    if (g < NL) {
+      int lo = 0, hi = 2 * W;  // seg_off[lo] <= g < seg_off[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (w.seg_off[mid] <= g) lo = mid; else hi = mid;
+      }
+      const int j = lo >> 1;
+      at[r] = static_cast<uint32_t>(((lo & 1) ? w.pb[j] : w.eb[j]) + (g - w.seg_off[lo]));
+      meta[r] = j << kSrcBits | ((lo & 1) ? 0 : kEmitBit);
+    } else {
+      at[r] = 0;  // (every lane issues every load: a lane without a link reads the pool's first record)
+      meta[r] = kDead;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kWinRegs; ++r) {
+    dst[r] = ToG(p.link_dst)[at[r]];
+    src[r] = ToG(p.link_src)[at[r]];
+    dl[r] = ToG(p.link_delta)[at[r]];
+  }
+  // the extras above the window, when they are not in LDS: a second gather
+  const bool above_global = next_b == nullptr;
+  float above[kWinRegs];
+  if (above_global) {
+    const long long safe = w.base[0];
+#pragma unroll
+    for (int r = 0; r < kWinRegs; ++r) {
+      const bool top = meta[r] != kDead && (meta[r] >> kSrcBits) == (kEmitBit >> kSrcBits) && dst[r] >= 0;
+      above[r] = ToG(p.tok_extra)[top ? dst[r] : safe];
+    }
+  }
+  LdsBarrier();  // B is +inf everywhere
+#pragma unroll
+  for (int r = 0; r < kWinRegs; ++r) {
+    if (meta[r] == kDead) continue;
+    if (dst[r] < 0) { meta[r] = kDead; continue; }  // excised by an earlier sweep
+    const int j = (meta[r] >> kSrcBits) & 0xFF;
+    const bool emitting = meta[r] & kEmitBit;
+    const int srcl = w.tok_off[j] + static_cast<int>(src[r] - w.base[j]);
+    meta[r] |= srcl;
+    if (!emitting) {
+      dst[r] = w.tok_off[j] + static_cast<int>(dst[r] - w.base[j]);
+    } else if (j > 0) {
+      dst[r] = w.tok_off[j - 1] + static_cast<int>(dst[r] - w.base[j - 1]);
+    } else {  // the destination's extra is final: this link is decided here
+      const float next_extra = above_global ? above[r] : KeyFloat(next_b[dst[r] - next_base]);
+      float link_extra_cost = next_extra + dl[r];  // :257-260
+      if (link_extra_cost > lattice_beam) {  // :264 excise
+        ToG(p.link_dst)[at[r]] = -1;
+        meta[r] = kDead;
+        continue;
+      }
+      if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
+      atomicMin(&B[srcl], FloatKey(link_extra_cost));
+      meta[r] |= kDoneBit;
+    }
+  }
+  LdsBarrier();
+  for (int round = 0;; ++round) {
+    int ch = 0;
+#pragma unroll
+    for (int r = 0; r < kWinRegs; ++r) {
+      if (meta[r] == kDead || (meta[r] & kDoneBit)) continue;
+      float link_extra_cost = KeyFloat(B[dst[r]]) + dl[r];  // :257-260
+      if (!(link_extra_cost <= lattice_beam)) continue;  // (not yet, or never: decided below)
+      if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
+      const uint32_t k = FloatKey(link_extra_cost);
+      if (atomicMin(&B[meta[r] & ((1 << kSrcBits) - 1)], k) > k) ch = 1;
+    }
+    if (ch) w.flag[round % 3] = 1;
+    if (tid == 0) w.flag[(round + 1) % 3] = 0;
+    LdsBarrier();
+    if (!w.flag[round % 3]) break;
+  }
+  // every key is final: the links that stay above the beam go (:264)
+#pragma unroll
+  for (int r = 0; r < kWinRegs; ++r) {
+    if (meta[r] == kDead || (meta[r] & kDoneBit)) continue;
+    const float link_extra_cost = KeyFloat(B[dst[r]]) + dl[r];
+    if (!(link_extra_cost <= lattice_beam)) {
+      ToG(p.link_dst)[at[r]] = -1;
+      meta[r] = kDead;
+    }
+  }
+  // the tokens' extras go to the pool (a token without a surviving link: +inf, which is
+  // how PruneTokensForFrame's verdict is recorded here)
+  for (int g0 = tid; g0 < NT; g0 += 4 * kBlock) {
+    int j[4];
+    long long gi[4];
+    float was[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = g0 + u * kBlock < NT ? g0 + u * kBlock : g0;
+      int lo = 0, hi = W;  // tok_off[lo] <= g < tok_off[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (w.tok_off[mid] <= g) lo = mid; else hi = mid;
+      }
+      j[u] = lo;
+      gi[u] = w.base[lo] + (g - w.tok_off[lo]);
+      was[u] = periodic ? ToG(p.tok_extra)[gi[u]] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = g0 + u * kBlock;
+      if (g >= NT) continue;
+      const float ex = KeyFloat(B[g]);
+      if (periodic && Moved(was[u], ex, delta)) w.fchanged[j[u]] = 1;
+      ToG(p.tok_extra)[gi[u]] = ex;
+      if (st.on && ex != FInf()) StageTok(s, st, gi[u], f - j[u]);
+    }
+  }
+  if (st.on) {
+#pragma unroll
+    for (int r = 0; r < kWinRegs; ++r)
+      if (meta[r] != kDead) StageArc(s, st, at[r], f - ((meta[r] >> kSrcBits) & 0xFF), (meta[r] & kEmitBit) ? 1 : 0);
+    if (tid < W && w.n[tid] == 0) s.empty_frame = 1;
+  }
+  next_b = B + w.tok_off[W - 1];
+  next_base = w.base[W - 1];
+  stop = false;
+  if (periodic) {
+    LdsBarrier();  // the frames' flags are complete
+    const bool quiet = lane < W && f - lane <= visited && !w.fchanged[lane];
+    stop = __ballot(quiet) != 0ull;  // (the same answer in every wave)
+  }
+  // (the next window's builder, or a frame that reads these extras from global memory,
+  // starts with a full barrier of its own, after which w and B's other half are reused)
+  LdsBarrier();
+  return W;
+}
+
 // FinalizeDecoding: the exact backward sweep over all frames -- and, with `periodic`,
 // PruneActiveTokens (:198-223), the same sweep started one frame below the newest (whose
 // tokens keep extra_cost 0: every token still active is taken to be on a best path), with
@@ -271,11 +493,37 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
     r.m_delta0 = ToG(p.link_delta)[at0];
   };
   if (f_top < 0) return 0;
+  // small frames are swept a window at a time (SweepWindow); the last frame (its tokens
+  // carry the final-cost term) and frames with more links than the lanes' registers
+  // hold go one by one, below
+  auto win_ok = [&](const Desc &d, int f) { return f != f_last && WinFits(d.n, d.en, d.pn); };
+  auto from_window = [&](int j) {
+    Desc d;
+    d.base = s.win.base[j]; d.n = s.win.n[j];
+    d.eb = s.win.eb[j]; d.en = s.win.en[j];
+    d.pb = s.win.pb[j]; d.pn = s.win.pn[j];
+    return d;
+  };
+  int flip = 0;  // which half of the key array the next LDS-resident frame or window takes
   Desc ahead = describe(f_top), ahead2 = f_top > 0 ? describe(f_top - 1) : ahead;
   Pre pre;
   bool have_pre = false;
-  if (fits_lds(ahead)) { fetch(ahead, pre); have_pre = true; }
+  if (!win_ok(ahead, f_top) && fits_lds(ahead)) { fetch(ahead, pre); have_pre = true; }
   for (int f = f_top; f >= 0; --f) {
+    if (win_ok(ahead, f)) {
+      bool stop;
+      const int W = SweepWindow(p, s, st, fb, f, periodic, visited, delta, next_b, next_base, flip, stop);
+      f_low = f - W + 1;
+      if (stop) break;
+      f = f_low;  // (the loop steps to the frame below the window)
+      if (f > 0) {  // the builder read the descriptors of kWinMax frames
+        ahead = W < kWinMax ? from_window(W) : describe(f - 1);
+        ahead2 = f > 1 ? (W + 1 < kWinMax ? from_window(W + 1) : describe(f - 2)) : ahead;
+        have_pre = !win_ok(ahead, f - 1) && fits_lds(ahead);
+        if (have_pre) fetch(ahead, pre);
+      }
+      continue;
+    }
     f_low = f;
     if (tid == 0) s.frame_changed = 0;  // (read behind the barriers at the frame's end)
     const Desc d = ahead;
@@ -294,8 +542,9 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
       // Epsilon links are fetched once into registers; each round recomputes
       // C = min(A, epsilon links over the current estimate B) and B := C, as the
       // loop below does through global memory.  Frames alternate between the two
-      // halves of the key array, so the next frame's extras are still there.
-      uint32_t *half = s.ne + (f & 1) * (kLdsToks / 2);
+      // halves of the key array (`flip`), so the next frame's extras are still there.
+      uint32_t *half = s.ne + flip * (kLdsToks / 2);
+      flip ^= 1;
       uint32_t *A = half, *B = half + n, *C = half + 2 * n;
       for (int i = tid; i < n; i += kBlock) {
         uint32_t k = kFInfKey;
@@ -321,7 +570,7 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
       const int32_t m_dst0 = pre.m_dst0, m_src0 = pre.m_src0;
       const float m_delta0 = pre.m_delta0;
       // ... and the request for the next frame's (f - 1)
-      have_pre = f > 0 && fits_lds(ahead);
+      have_pre = f > 0 && fits_lds(ahead) && !win_ok(ahead, f - 1);
       if (have_pre) fetch(ahead, pre);
 #pragma unroll
       for (int r = 0; r < kEpsRegs; ++r) {
@@ -336,23 +585,39 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
         }
       }
       LdsBarrier();
-      // emitting links, into A
-      for (int i = tid; i < en; i += kBlock) {
-        const long long at = eb + i;
-        const bool first = i == tid;  // (the first round was requested above)
-        const int32_t dst = first ? m_dst0 : ToG(p.link_dst)[at];
-        const int32_t src = first ? m_src0 : ToG(p.link_src)[at];
-        const float delta = first ? m_delta0 : ToG(p.link_delta)[at];
-        if (dst < 0) continue;  // already excised
-        const float next_extra = next_b ? KeyFloat(next_b[dst - next_base]) : ToG(p.tok_extra)[dst];
-        float link_extra_cost = next_extra + delta;  // :257-260
-        if (link_extra_cost > lattice_beam) {  // :264 excise
-          ToG(p.link_dst)[at] = -1;
-          continue;
+      // emitting links, into A: four per lane at a time, their records requested
+      // together (the very first one came with the prefetch above)
+      constexpr int kEmitU = 4;
+      for (int i0 = tid; i0 < en; i0 += kEmitU * kBlock) {
+        int32_t dst[kEmitU], src[kEmitU];
+        float dl[kEmitU];
+#pragma unroll
+        for (int u = 0; u < kEmitU; ++u) {
+          const int i = i0 + u * kBlock;
+          const long long at = eb + (i < en ? i : i0);
+          if (u == 0 && i0 == tid) {
+            dst[u] = m_dst0; src[u] = m_src0; dl[u] = m_delta0;
+          } else {
+            dst[u] = ToG(p.link_dst)[at];
+            src[u] = ToG(p.link_src)[at];
+            dl[u] = ToG(p.link_delta)[at];
+          }
+          if (i >= en) dst[u] = -1;
         }
-        if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
-        atomicMin(&A[src - base], FloatKey(link_extra_cost));
-        if (st.on) StageArc(s, st, at, f, 1);
+#pragma unroll
+        for (int u = 0; u < kEmitU; ++u) {
+          if (dst[u] < 0) continue;  // already excised (or no link)
+          const long long at = eb + i0 + u * kBlock;
+          const float next_extra = next_b ? KeyFloat(next_b[dst[u] - next_base]) : ToG(p.tok_extra)[dst[u]];
+          float link_extra_cost = next_extra + dl[u];  // :257-260
+          if (link_extra_cost > lattice_beam) {  // :264 excise
+            ToG(p.link_dst)[at] = -1;
+            continue;
+          }
+          if (link_extra_cost < 0.0f) link_extra_cost = 0.0f;  // :276-281
+          atomicMin(&A[src[u] - base], FloatKey(link_extra_cost));
+          if (st.on) StageArc(s, st, at, f, 1);
+        }
       }
       LdsBarrier();
       while (true) {
@@ -485,20 +750,40 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
   return f_low;
 }
 
-// GetRawLattice from the lists FinalizeDecoding left (Stage): states are numbered
-// frame-major (the sweep ran backwards, so list position j becomes id ns - 1 - j).
+// GetRawLattice from the lists FinalizeDecoding left (Stage).  States are numbered
+// frame-major like the reference's (:623-640 walks the frames in order): the lists come
+// in whatever order the sweep's windows and waves produced them, so a token's id is its
+// frame's offset (a prefix sum over per-frame counts) plus its rank inside the frame (an
+// atomic counter per frame) -- a counting sort over a thousand entries, once per utterance.
 __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &s, int utt, int F,
                                                         bool any_final, const Stage &st) {
   const int tid = threadIdx.x;
   const int ns = s.n_tok_staged, na = s.n_arc_staged;
   if (s.empty_frame || ns == 0) return 0;  // GetRawLattice returns false (:615-619)
+  const long long fb = static_cast<long long>(utt) * (p.max_frames + 1);
+  KD_G int32_t *soff = ToG(p.lat.frame_state_off) + fb;
   if (tid == 0) { s.n_finals = 0; s.start_id = -1; }
+  for (int k = tid; k <= F; k += kBlock) soff[k] = 0;
   __syncthreads();
-  // the last frame's tokens were listed first: count the final ones (:645-652)
+  // ranks inside the frames; the final states among the last frame's tokens (:645-652)
   for (int j = tid; j < ns; j += kBlock) {
-    if (static_cast<int>(st.tok_f[j]) != F) break;  // (positions are frame-descending per lane)
-    const float fc = ToG(p.states)[ToG(p.tok_state)[st.tok_g[j]]].final_cost;
-    if (!any_final || fc != FInf()) AggAdd1(&s.n_finals);
+    const uint32_t g = st.tok_g[j];
+    const int f = static_cast<int>(st.tok_f[j]);
+    ToG(p.lat.tok_newid)[g] = atomicAdd(ToFlat(&soff[f]), 1);
+    if (f == F) {
+      const float fc = ToG(p.states)[ToG(p.tok_state)[g]].final_cost;
+      if (!any_final || fc != FInf()) atomicAdd(&s.n_finals, 1);
+    }
+  }
+  __syncthreads();
+  int carry = 0;
+  for (int k0 = 0; k0 <= F; k0 += kBlock) {  // counts -> offsets
+    const int k = k0 + tid;
+    const int v = k <= F ? soff[k] : 0;
+    int total;
+    const int before = BlockExclScanI(s, v, total);
+    if (k <= F) soff[k] = carry + before;
+    carry += total;
   }
   __syncthreads();
   const int nf = s.n_finals;
@@ -516,7 +801,7 @@ __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &
   for (int j = tid; j < ns; j += kBlock) {
     const uint32_t g = st.tok_g[j];
     const int f = static_cast<int>(st.tok_f[j]);
-    const int id = ns - 1 - j;
+    const int id = soff[f] + ToG(p.lat.tok_newid)[g];
     const int32_t state = ToG(p.tok_state)[g];
     ToG(p.lat.tok_newid)[g] = id;
     o_state[id] = pack(static_cast<uint32_t>(f), static_cast<uint32_t>(state));
@@ -918,8 +1203,20 @@ __device__ __noinline__ uint32_t PeriodicPrune(CParams *pp, int utt, int F, int 
   CParams &p = *pp;
   TailShared &s = TailLds();
   Stage st = TailStage(p, false);
-  (void)LatticePrune(p, s, utt, F, 0.0f, false, st, /*periodic=*/true, visited,
-                     p.lat.lattice_beam * p.lat.prune_scale);
+#ifdef KD_PROFILE
+  long long lap = static_cast<long long>(__builtin_amdgcn_s_memtime());
+#endif
+  const int f_low = LatticePrune(p, s, utt, F, 0.0f, false, st, /*periodic=*/true, visited,
+                                 p.lat.lattice_beam * p.lat.prune_scale);
+#ifdef KD_PROFILE
+  if (threadIdx.x == 0) {  // (diagnostic build: bucket 18 = the sweep, 16 = frames it visited)
+    const long long now = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    Lds().cyc[18] += now - lap;  // (the search's diagnostic buckets lie beyond the tail's LDS use)
+    Lds().cyc[16] += F - f_low;
+  }
+#else
+  (void)f_low;
+#endif
   const int hi = F - p.lat.prune_interval;
   uint32_t r = 0;
   while (r == 0) {
