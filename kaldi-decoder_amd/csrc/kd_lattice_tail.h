@@ -42,7 +42,7 @@ constexpr int kEpsRegs = KD_LEPS_REGS;  // epsilon links of a frame a lane keeps
 #ifndef KD_WIN_REGS
 #define KD_WIN_REGS 8
 #endif
-constexpr int kWinMax = 32;  // frames per window, at most
+constexpr int kWinMax = 64;  // frames per window, at most (one lane of a wave reads a frame's descriptor)
 constexpr int kWinRegs = KD_WIN_REGS;
 constexpr int kWinLinks = kWinRegs * kBlock;
 constexpr int kWinToks = kLdsToks / 2;
@@ -266,7 +266,7 @@ __device__ __forceinline__ int SweepWindow(CParams &p, TailShared &s, const Stag
       if (lane >= d) { ct += yt; cl += yl; }
     }
     const unsigned long long m = __ballot(in && ct <= kWinToks && cl <= kWinLinks);
-    const int W = __builtin_ctzll(~m);
+    const int W = m == ~0ull ? 64 : __builtin_ctzll(~m);
     if (lane < kWinMax) {
       w.base[lane] = base; w.eb[lane] = eb; w.pb[lane] = pb;
       w.n[lane] = n; w.en[lane] = en; w.pn[lane] = pn;
@@ -353,6 +353,9 @@ __device__ __forceinline__ int SweepWindow(CParams &p, TailShared &s, const Stag
   LdsBarrier();
   for (int round = 0;; ++round) {
     int ch = 0;
+    // (a slot whose destination is still +inf, or dead, falls through in a few
+    // instructions -- a wave all of whose lanes do skips the slot -- so a round costs
+    // what the frames around the front of the propagation cost, not the whole window)
 #pragma unroll
     for (int r = 0; r < kWinRegs; ++r) {
       if (meta[r] == kDead || (meta[r] & kDoneBit)) continue;
@@ -379,6 +382,9 @@ __device__ __forceinline__ int SweepWindow(CParams &p, TailShared &s, const Stag
   }
   // the tokens' extras go to the pool (a token without a surviving link: +inf, which is
   // how PruneTokensForFrame's verdict is recorded here)
+  // (frames above `visited` are swept whatever they hold: a window of such frames does
+  // not look at the old extras)
+  const bool need_was = periodic && f - (W - 1) <= visited;
   for (int g0 = tid; g0 < NT; g0 += 4 * kBlock) {
     int j[4];
     long long gi[4];
@@ -393,14 +399,14 @@ __device__ __forceinline__ int SweepWindow(CParams &p, TailShared &s, const Stag
       }
       j[u] = lo;
       gi[u] = w.base[lo] + (g - w.tok_off[lo]);
-      was[u] = periodic ? ToG(p.tok_extra)[gi[u]] : 0.0f;
+      was[u] = need_was ? ToG(p.tok_extra)[gi[u]] : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int g = g0 + u * kBlock;
       if (g >= NT) continue;
       const float ex = KeyFloat(B[g]);
-      if (periodic && Moved(was[u], ex, delta)) w.fchanged[j[u]] = 1;
+      if (periodic && f - j[u] <= visited && Moved(was[u], ex, delta)) w.fchanged[j[u]] = 1;
       ToG(p.tok_extra)[gi[u]] = ex;
       if (st.on && ex != FInf()) StageTok(s, st, gi[u], f - j[u]);
     }
@@ -505,6 +511,28 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
     return d;
   };
   int flip = 0;  // which half of the key array the next LDS-resident frame or window takes
+#ifdef KD_PROFILE
+  // diagnostic build: cycles in windows (bucket 16) and in frames swept one by one (18)
+  long long prof_lap = static_cast<long long>(__builtin_amdgcn_s_memtime()), prof_cyc[2] = {0, 0};
+  auto prof = [&](int which) {
+    const long long now = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    prof_cyc[which] += now - prof_lap;
+    prof_lap = now;
+  };
+  auto prof_flush = [&]() {
+    if (tid != 0) return;
+    if (periodic) {  // (flushed with the search's own buckets when the utterance ends)
+      Lds().cyc[16] += prof_cyc[0];
+      Lds().cyc[18] += prof_cyc[1];
+    } else {
+      ToG(p.stats)[static_cast<long long>(utt) * kStatStride + KD_NUM_STATS + 16] += prof_cyc[0];
+      ToG(p.stats)[static_cast<long long>(utt) * kStatStride + KD_NUM_STATS + 18] += prof_cyc[1];
+    }
+  };
+#else
+  auto prof = [](int) {};
+  auto prof_flush = []() {};
+#endif
   Desc ahead = describe(f_top), ahead2 = f_top > 0 ? describe(f_top - 1) : ahead;
   Pre pre;
   bool have_pre = false;
@@ -514,6 +542,7 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
       bool stop;
       const int W = SweepWindow(p, s, st, fb, f, periodic, visited, delta, next_b, next_base, flip, stop);
       f_low = f - W + 1;
+      prof(0);
       if (stop) break;
       f = f_low;  // (the loop steps to the frame below the window)
       if (f > 0) {  // the builder read the descriptors of kWinMax frames
@@ -668,6 +697,7 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
       // (a later frame that reads these extras from global memory -- the path below --
       // does so behind a full barrier of its own)
       LdsBarrier();
+      prof(1);
       if (periodic) {
         const bool stop = f <= visited && !s.frame_changed;
         LdsBarrier();  // (everybody has read the flag before the next frame clears it)
@@ -745,7 +775,9 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
         if (ToG(p.link_dst)[pb + i] >= 0) StageArc(s, st, pb + i, f, 0);
       if (n == 0 && tid == 0) s.empty_frame = 1;
     }
+    prof(1);
   }
+  prof_flush();
   __syncthreads();
   return f_low;
 }
@@ -1017,11 +1049,21 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
 // frame are copied, compacted, into the utterance's archive; link endpoints follow their
 // tokens through a forwarding word per token (tok_newid); the frame index is pointed at
 // the copies; and the nursery chunks that only held such frames are freed for reuse by
-// this utterance (TakeChunks).  Frames are independent here: each wave takes frames of
-// its own and ranks with ballot + popcount, no workgroup barrier inside a pass.
-// Everything is counted first and the archive space taken in one piece, so a pool that
-// is exhausted is noticed before anything has moved.
-constexpr int kCollectFrames = 1024;  // frames per pass (six counters each in the LDS block)
+// this utterance (TakeChunks).
+// Work is dealt out in PIECES of a frame's tokens / epsilon links / emitting links
+// (256 records, more when a pass would otherwise have more than kMaxPieces): frame sizes
+// are heavy-tailed -- a median of 68 links, some of 20 000 -- and a wave per frame left
+// eleven waves waiting for the one with the large frame.  Pass A counts each piece's
+// survivors (ballot + popcount, no workgroup barrier inside a pass), a prefix sum over
+// the pieces gives every piece its place, the archive space is taken in one piece per
+// pool -- so a pool that is exhausted is noticed before anything has moved -- and passes
+// B (tokens) and C (links) copy.
+constexpr int kCollectFrames = 256;  // frames per call
+constexpr int kMaxPieces = 8192;     // pieces per call and record kind
+constexpr int kPiece = 256;          // records per piece (x 2^k)
+constexpr int kCU = 4;               // 64-wide steps of a piece a wave has in flight
+static_assert(kPiece == 64 * kCU, "a piece is one unrolled step (or 2^k of them)");
+static_assert(kChunkRing <= 64, "one lane per retired chunk");
 
 __device__ __forceinline__ long long ArchiveAlloc(CParams &p, KD_G UttMem *m, bool links, long long need) {
   long long &next = *(links ? ToFlat(&m->alink_next) : ToFlat(&m->atok_next));
@@ -1049,70 +1091,158 @@ __device__ __forceinline__ uint32_t LatticeCollect(CParams &p, TailShared &s, in
   const long long fb = static_cast<long long>(utt) * (p.max_frames + 1);
   KD_G UttMem *m = ToG(p.mem) + utt;
   const int nfr = hi - lo;  // <= kCollectFrames
-  int32_t *cnt_t = reinterpret_cast<int32_t *>(s.ne), *cnt_e = cnt_t + kCollectFrames,
-          *cnt_m = cnt_e + kCollectFrames;
-  long long *off_t = reinterpret_cast<long long *>(cnt_m + kCollectFrames), *off_e = off_t + kCollectFrames,
-            *off_m = off_e + kCollectFrames;
-  // ---- pass A: what survives, per frame
-  for (int j = wave; j < nfr; j += kWaves) {
-    const int k = lo + j;
-    const long long base = ToG(p.frame_base)[fb + k];
-    const int n = ToG(p.frame_count)[fb + k];
-    int ct = 0;
-    for (int c0 = 0; c0 < n; c0 += 64)
-      ct += __popcll(__ballot(c0 + lane < n && ToG(p.tok_extra)[base + c0 + lane] != FInf()));
-    int cl[2];
-    for (int blk = 0; blk < 2; ++blk) {
-      const long long lb = blk ? ToG(p.link_emit_base)[fb + k] : ToG(p.link_eps_base)[fb + k];
-      const int ln = blk ? ToG(p.link_emit_count)[fb + k] : ToG(p.link_eps_count)[fb + k];
-      int c = 0;
-      for (int c0 = 0; c0 < ln; c0 += 64)
-        c += __popcll(__ballot(c0 + lane < ln && ToG(p.link_dst)[lb + c0 + lane] >= 0));
-      cl[blk] = c;
+  // tables in the key array: the frames' descriptors; where each frame's / link block's
+  // pieces begin; which frame / block a piece belongs to; the pieces' survivor counts
+  // (then their places)
+  long long *d_base = reinterpret_cast<long long *>(s.ne), *d_eb = d_base + kCollectFrames,
+            *d_pb = d_eb + kCollectFrames, *arch = d_pb + kCollectFrames;  // arch[2]: the archive space taken
+  int32_t *d_n = reinterpret_cast<int32_t *>(arch + 2), *d_en = d_n + kCollectFrames, *d_pn = d_en + kCollectFrames;
+  int32_t *tp_pref = d_pn + kCollectFrames;        // [nfr + 1]
+  int32_t *lp_pref = tp_pref + kCollectFrames + 1;  // [2 nfr + 1]: block 2j = epsilon, 2j + 1 = emitting links of frame lo + j
+  int32_t *tpc = lp_pref + 2 * kCollectFrames + 1;  // [PT + 1]
+  int32_t *lpc = tpc + kMaxPieces + 1;              // [PL + 1]
+  uint16_t *tp_frame = reinterpret_cast<uint16_t *>(lpc + kMaxPieces + 1), *lp_block = tp_frame + kMaxPieces;
+  static_assert((3 * 8 + 3 * 4) * kCollectFrames + 16 + 4 * (3 * kCollectFrames + 2) + 8 * (kMaxPieces + 1) +
+                        4 * kMaxPieces <= 4 * kLdsToks, "the collector's tables fit the key array");
+  static_assert(2 * kCollectFrames <= 65536, "piece owners are 16-bit");
+  for (int j = tid; j < nfr; j += kBlock) {
+    const long long at = fb + lo + j;
+    d_base[j] = ToG(p.frame_base)[at];
+    d_n[j] = ToG(p.frame_count)[at];
+    d_eb[j] = ToG(p.link_emit_base)[at];
+    d_en[j] = ToG(p.link_emit_count)[at];
+    d_pb[j] = ToG(p.link_eps_base)[at];
+    d_pn[j] = ToG(p.link_eps_count)[at];
+  }
+  __syncthreads();
+  // ---- the pieces (kCollectFrames <= kBlock: a thread per frame)
+  static_assert(kCollectFrames <= kBlock, "a thread per collected frame");
+  int shift = 0, PT = 0, PL = 0;
+  while (true) {
+    const int S = kPiece << shift;
+    const int n = tid < nfr ? d_n[tid] : 0, pn = tid < nfr ? d_pn[tid] : 0, en = tid < nfr ? d_en[tid] : 0;
+    const int tq = (n + S - 1) / S, pq = (pn + S - 1) / S, eq = (en + S - 1) / S;
+    const int tb = BlockExclScanI(s, tq, PT);
+    const int lb = BlockExclScanI(s, pq + eq, PL);
+    if (PT <= kMaxPieces && PL <= kMaxPieces) {  // (the same totals in every thread)
+      if (tid < nfr) {
+        tp_pref[tid] = tb;
+        lp_pref[2 * tid] = lb;
+        lp_pref[2 * tid + 1] = lb + pq;
+        for (int q = 0; q < tq; ++q) tp_frame[tb + q] = static_cast<uint16_t>(tid);
+        for (int q = 0; q < pq; ++q) lp_block[lb + q] = static_cast<uint16_t>(2 * tid);
+        for (int q = 0; q < eq; ++q) lp_block[lb + pq + q] = static_cast<uint16_t>(2 * tid + 1);
+      }
+      if (tid == 0) { tp_pref[nfr] = PT; lp_pref[2 * nfr] = PL; }
+      break;
     }
-    if (lane == 0) { cnt_t[j] = ct; cnt_e[j] = cl[0]; cnt_m[j] = cl[1]; }
+    ++shift;
+  }
+  const int S = kPiece << shift;
+  __syncthreads();
+  // ---- pass A: what survives of each piece (kCU 64-wide steps in flight together)
+  for (int q = wave; q < PT + PL; q += kWaves) {
+    int c = 0;
+    if (q < PT) {
+      const int j = tp_frame[q];
+      const long long base = d_base[j];
+      const int n = d_n[j], c_begin = (q - tp_pref[j]) * S, c_end = c_begin + S < n ? c_begin + S : n;
+      for (int c0 = c_begin; c0 < c_end; c0 += 64 * kCU) {
+        float ex[kCU];
+#pragma unroll
+        for (int u = 0; u < kCU; ++u) {
+          const int i = c0 + u * 64 + lane;
+          ex[u] = ToG(p.tok_extra)[base + (i < c_end ? i : c0)];
+        }
+#pragma unroll
+        for (int u = 0; u < kCU; ++u)
+          c += __popcll(__ballot(c0 + u * 64 + lane < c_end && ex[u] != FInf()));
+      }
+      if (lane == 0) tpc[q] = c;
+    } else {
+      const int ql = q - PT, blk = lp_block[ql], j = blk >> 1;
+      const long long lb = (blk & 1) ? d_eb[j] : d_pb[j];
+      const int ln = (blk & 1) ? d_en[j] : d_pn[j];
+      const int c_begin = (ql - lp_pref[blk]) * S, c_end = c_begin + S < ln ? c_begin + S : ln;
+      for (int c0 = c_begin; c0 < c_end; c0 += 64 * kCU) {
+        int32_t d[kCU];
+#pragma unroll
+        for (int u = 0; u < kCU; ++u) {
+          const int i = c0 + u * 64 + lane;
+          d[u] = ToG(p.link_dst)[lb + (i < c_end ? i : c0)];
+        }
+#pragma unroll
+        for (int u = 0; u < kCU; ++u)
+          c += __popcll(__ballot(c0 + u * 64 + lane < c_end && d[u] >= 0));
+      }
+      if (lane == 0) lpc[ql] = c;
+    }
+  }
+  __syncthreads();
+  // ---- counts -> places (exclusive prefix sums over the pieces; totals behind them)
+  for (int which = 0; which < 2; ++which) {
+    int32_t *pc = which ? lpc : tpc;
+    const int P = which ? PL : PT;
+    int carry = 0;
+    for (int q0 = 0; q0 < P; q0 += kBlock) {
+      const int q = q0 + tid;
+      const int v = q < P ? pc[q] : 0;
+      int total;
+      const int before = BlockExclScanI(s, v, total);
+      if (q < P) pc[q] = carry + before;
+      carry += total;
+    }
+    if (tid == 0) pc[P] = carry;
   }
   __syncthreads();
   // ---- the archive space, in one piece per pool
   if (tid == 0) {
-    long long tt = 0, tl = 0;
-    for (int j = 0; j < nfr; ++j) { tt += cnt_t[j]; tl += cnt_e[j] + cnt_m[j]; }
-    const long long bt = ArchiveAlloc(p, m, false, tt);
-    const long long bl = bt < 0 ? -1 : ArchiveAlloc(p, m, true, tl);
+    const long long bt = ArchiveAlloc(p, m, false, tpc[PT]);
+    const long long bl = bt < 0 ? -1 : ArchiveAlloc(p, m, true, lpc[PL]);
     s.alloc_err = bt < 0 ? KD_UTT_ARENA_FULL : bl < 0 ? KD_UTT_LINKS_FULL : 0u;
-    if (!s.alloc_err) {
-      long long at = bt, al = bl;
-      for (int j = 0; j < nfr; ++j) {
-        off_t[j] = at; at += cnt_t[j];
-        off_e[j] = al; al += cnt_e[j];
-        off_m[j] = al; al += cnt_m[j];
-      }
-    }
+    arch[0] = bt;
+    arch[1] = bl;
   }
   __syncthreads();
   if (s.alloc_err) return s.alloc_err;
+  const long long bt = arch[0], bl = arch[1];
   // ---- pass B: tokens; every token of these frames gets its forwarding word
-  for (int j = wave; j < nfr; j += kWaves) {
-    const int k = lo + j;
-    const long long base = ToG(p.frame_base)[fb + k];
-    const int n = ToG(p.frame_count)[fb + k];
-    long long at = off_t[j];
-    for (int c0 = 0; c0 < n; c0 += 64) {
-      const int i = c0 + lane;
-      const long long g = base + i;
-      const float ex = i < n ? ToG(p.tok_extra)[g] : FInf();
-      const bool a = i < n && ex != FInf();
-      const int32_t st = a ? ToG(p.tok_state)[g] : 0;
-      const double co = a ? ToG(p.tok_cost)[g] : 0.0;
-      const unsigned long long mk = __ballot(a);
-      const long long to = at + RankIn(mk);
-      if (a) {
-        ToG(p.tok_state)[to] = st;
-        ToG(p.tok_cost)[to] = co;
-        ToG(p.tok_extra)[to] = ex;
+  for (int q = wave; q < PT; q += kWaves) {
+    const int j = tp_frame[q];
+    const long long base = d_base[j];
+    const int n = d_n[j], c_begin = (q - tp_pref[j]) * S, c_end = c_begin + S < n ? c_begin + S : n;
+    long long at = bt + tpc[q];
+    for (int c0 = c_begin; c0 < c_end; c0 += 64 * kCU) {
+      float ex[kCU];
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const int i = c0 + u * 64 + lane;
+        ex[u] = i < c_end ? ToG(p.tok_extra)[base + i] : FInf();
       }
-      if (i < n) ToG(p.lat.tok_newid)[g] = a ? static_cast<int32_t>(to) : -1;
-      at += __popcll(mk);
+      // (a dead token's state and cost are not needed: its lane reads the step's first
+      // record instead, so that every lane's loads are issued together)
+      int32_t st[kCU];
+      double co[kCU];
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const long long g = base + (ex[u] != FInf() ? c0 + u * 64 + lane : c0);
+        st[u] = ToG(p.tok_state)[g];
+        co[u] = ToG(p.tok_cost)[g];
+      }
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const int i = c0 + u * 64 + lane;
+        const bool a = ex[u] != FInf();
+        const unsigned long long mk = __ballot(a);
+        const long long to = at + RankIn(mk);
+        if (a) {
+          ToG(p.tok_state)[to] = st[u];
+          ToG(p.tok_cost)[to] = co[u];
+          ToG(p.tok_extra)[to] = ex[u];
+        }
+        if (i < c_end) ToG(p.lat.tok_newid)[base + i] = a ? static_cast<int32_t>(to) : -1;
+        at += __popcll(mk);
+      }
     }
   }
   __syncthreads();  // every forwarding word is in place
@@ -1127,37 +1257,48 @@ __device__ __forceinline__ uint32_t LatticeCollect(CParams &p, TailShared &s, in
   }
   // ---- pass C: links, endpoints forwarded (an emitting link of frame hi - 1 ends in
   // frame hi, which stays where it is until the next collection)
-  for (int j = wave; j < nfr; j += kWaves) {
-    const int k = lo + j;
-    for (int blk = 0; blk < 2; ++blk) {
-      const long long lb = blk ? ToG(p.link_emit_base)[fb + k] : ToG(p.link_eps_base)[fb + k];
-      const int ln = blk ? ToG(p.link_emit_count)[fb + k] : ToG(p.link_eps_count)[fb + k];
-      const bool fwd_dst = (blk ? k + 1 : k) < hi;
-      long long at = blk ? off_m[j] : off_e[j];
-      for (int c0 = 0; c0 < ln; c0 += 64) {
-        const int i = c0 + lane;
-        const long long l = lb + i;
-        const int32_t d = i < ln ? ToG(p.link_dst)[l] : -1;
-        const bool a = d >= 0;
-        int32_t src = 0, arc = 0, dst = d;
-        float ac = 0.f, gr = 0.f, dl = 0.f;
-        if (a) {
-          src = ToG(p.lat.tok_newid)[ToG(p.link_src)[l]];
-          if (fwd_dst) dst = ToG(p.lat.tok_newid)[d];
-          arc = ToG(p.link_arc)[l];
-          ac = ToG(p.link_ac)[l];
-          gr = ToG(p.link_graph)[l];
-          dl = ToG(p.link_delta)[l];
-        }
+  for (int ql = wave; ql < PL; ql += kWaves) {
+    const int blk = lp_block[ql], j = blk >> 1;
+    const long long lb = (blk & 1) ? d_eb[j] : d_pb[j];
+    const int ln = (blk & 1) ? d_en[j] : d_pn[j];
+    const int c_begin = (ql - lp_pref[blk]) * S, c_end = c_begin + S < ln ? c_begin + S : ln;
+    const bool fwd_dst = lo + j + (blk & 1) < hi;
+    long long at = bl + lpc[ql];
+    for (int c0 = c_begin; c0 < c_end; c0 += 64 * kCU) {
+      int32_t d[kCU];
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const int i = c0 + u * 64 + lane;
+        d[u] = i < c_end ? ToG(p.link_dst)[lb + i] : -1;
+      }
+      int32_t src[kCU], arc[kCU], dst[kCU];
+      float ac[kCU], gr[kCU], dl[kCU];
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {  // (an excised link's lane reads the step's first record)
+        const long long l = lb + (d[u] >= 0 ? c0 + u * 64 + lane : c0);
+        src[u] = ToG(p.link_src)[l];
+        arc[u] = ToG(p.link_arc)[l];
+        ac[u] = ToG(p.link_ac)[l];
+        gr[u] = ToG(p.link_graph)[l];
+        dl[u] = ToG(p.link_delta)[l];
+      }
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        src[u] = ToG(p.lat.tok_newid)[src[u]];
+        dst[u] = fwd_dst ? ToG(p.lat.tok_newid)[d[u] >= 0 ? d[u] : 0] : d[u];
+      }
+#pragma unroll
+      for (int u = 0; u < kCU; ++u) {
+        const bool a = d[u] >= 0;
         const unsigned long long mk = __ballot(a);
         const long long to = at + RankIn(mk);
         if (a) {
-          ToG(p.link_src)[to] = src;
-          ToG(p.link_dst)[to] = dst;
-          ToG(p.link_arc)[to] = arc;
-          ToG(p.link_ac)[to] = ac;
-          ToG(p.link_graph)[to] = gr;
-          ToG(p.link_delta)[to] = dl;
+          ToG(p.link_src)[to] = src[u];
+          ToG(p.link_dst)[to] = dst[u];
+          ToG(p.link_arc)[to] = arc[u];
+          ToG(p.link_ac)[to] = ac[u];
+          ToG(p.link_graph)[to] = gr[u];
+          ToG(p.link_delta)[to] = dl[u];
         }
         at += __popcll(mk);
       }
@@ -1166,29 +1307,38 @@ __device__ __forceinline__ uint32_t LatticeCollect(CParams &p, TailShared &s, in
   __syncthreads();  // (every old block has been read: the frame index can move)
   for (int j = tid; j < nfr; j += kBlock) {
     const int k = lo + j;
-    ToG(p.frame_base)[fb + k] = off_t[j];
-    ToG(p.frame_count)[fb + k] = cnt_t[j];
-    ToG(p.link_eps_base)[fb + k] = off_e[j];
-    ToG(p.link_eps_count)[fb + k] = cnt_e[j];
-    ToG(p.link_emit_base)[fb + k] = off_m[j];
-    ToG(p.link_emit_count)[fb + k] = cnt_m[j];
+    const int t0 = tpc[tp_pref[j]], t1 = tpc[tp_pref[j + 1]];
+    const int e0 = lpc[lp_pref[2 * j]], e1 = lpc[lp_pref[2 * j + 1]], e2 = lpc[lp_pref[2 * j + 2]];
+    ToG(p.frame_base)[fb + k] = bt + t0;
+    ToG(p.frame_count)[fb + k] = t1 - t0;
+    ToG(p.link_eps_base)[fb + k] = bl + e0;
+    ToG(p.link_eps_count)[fb + k] = e1 - e0;
+    ToG(p.link_emit_base)[fb + k] = bl + e1;
+    ToG(p.link_emit_count)[fb + k] = e2 - e1;
   }
-  // ---- nursery chunks that held nothing younger than hi - 1 are free again
-  if (tid == 0) {
-    m->gc_frame = hi;
-    for (int w = 0; w < 2; ++w) {
-      KD_G ChunkRing *r = w ? &m->link : &m->tok;
-      int keep = 0;
-      for (int i = 0; i < r->n_retired; ++i) {
-        if (r->retired_last[i] < hi && r->n_free < kChunkRing) {
-          r->free_start[r->n_free++] = r->retired_start[i];
-        } else if (r->retired_last[i] >= hi) {
-          r->retired_start[keep] = r->retired_start[i];
-          r->retired_last[keep] = r->retired_last[i];
-          keep++;
-        }  // (a freed chunk the full free list cannot take is lost until InitDecoding)
-      }
-      r->n_retired = keep;
+  // ---- nursery chunks that held nothing younger than hi - 1 are free again (one wave
+  // per pool, one lane per retired chunk: the lists live in global memory, and a
+  // single lane walking them paid a memory round trip per entry)
+  if (tid == 0) m->gc_frame = hi;
+  if (wave < 2) {
+    KD_G ChunkRing *r = wave ? &m->link : &m->tok;
+    const int nr = r->n_retired, nfree = r->n_free;
+    const bool have = lane < nr;
+    const int32_t start = r->retired_start[have ? lane : 0], last = r->retired_last[have ? lane : 0];
+    const bool old = have && last < hi;
+    const unsigned long long mo = __ballot(old), mk = __ballot(have && !old);
+    const int fpos = nfree + RankIn(mo);
+    // (a freed chunk the full free list cannot take is lost until InitDecoding)
+    if (old && fpos < kChunkRing) r->free_start[fpos] = start;
+    if (have && !old) {
+      const int kp = RankIn(mk);
+      r->retired_start[kp] = start;
+      r->retired_last[kp] = last;
+    }
+    if (lane == 0) {
+      const int nf = nfree + __popcll(mo);
+      r->n_free = nf < kChunkRing ? nf : kChunkRing;
+      r->n_retired = __popcll(mk);
     }
   }
   __syncthreads();
@@ -1203,27 +1353,22 @@ __device__ __noinline__ uint32_t PeriodicPrune(CParams *pp, int utt, int F, int 
   CParams &p = *pp;
   TailShared &s = TailLds();
   Stage st = TailStage(p, false);
-#ifdef KD_PROFILE
-  long long lap = static_cast<long long>(__builtin_amdgcn_s_memtime());
-#endif
-  const int f_low = LatticePrune(p, s, utt, F, 0.0f, false, st, /*periodic=*/true, visited,
-                                 p.lat.lattice_beam * p.lat.prune_scale);
-#ifdef KD_PROFILE
-  if (threadIdx.x == 0) {  // (diagnostic build: bucket 18 = the sweep, 16 = frames it visited)
-    const long long now = static_cast<long long>(__builtin_amdgcn_s_memtime());
-    Lds().cyc[18] += now - lap;  // (the search's diagnostic buckets lie beyond the tail's LDS use)
-    Lds().cyc[16] += F - f_low;
-  }
-#else
-  (void)f_low;
-#endif
+  LatticePrune(p, s, utt, F, 0.0f, false, st, /*periodic=*/true, visited,
+               p.lat.lattice_beam * p.lat.prune_scale);
   const int hi = F - p.lat.prune_interval;
   uint32_t r = 0;
+#ifdef KD_PROFILE
+  const long long lap = static_cast<long long>(__builtin_amdgcn_s_memtime());
+#endif
   while (r == 0) {
     const int lo = Uni(ToG(p.mem)[utt].gc_frame);
     if (lo >= hi) break;
     r = LatticeCollect(p, s, utt, lo, hi - lo > kCollectFrames ? lo + kCollectFrames : hi);
   }
+#ifdef KD_PROFILE
+  // diagnostic build: the collector's cycles on top of bucket 17 (the search's link records)
+  if (threadIdx.x == 0) Lds().cyc[17] += static_cast<long long>(__builtin_amdgcn_s_memtime()) - lap;
+#endif
   return r;
 }
 
