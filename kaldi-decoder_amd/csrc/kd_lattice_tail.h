@@ -39,8 +39,12 @@ constexpr int kEpsRegs = KD_LEPS_REGS;  // epsilon links of a frame a lane keeps
 
 // A WINDOW of the backward sweep: consecutive frames whose links fit the lanes' registers
 // (kWinRegs each) and whose tokens fit half the key array, swept together (SweepWindow).
+// (link slots per lane: every round walks all of a lane's slots, so a window of fewer,
+// cheaper rounds beats a larger one -- measured on the bench workload at the default
+// prune_interval: 8 slots 10.5 k cycles per utterance-frame of periodic pruning, 4: 8.7 k,
+// 3: 8.5 k, 2: 8.4 k, 1: 9.0 k, 12: 12.0 k)
 #ifndef KD_WIN_REGS
-#define KD_WIN_REGS 8
+#define KD_WIN_REGS 3
 #endif
 constexpr int kWinMax = 64;  // frames per window, at most (one lane of a wave reads a frame's descriptor)
 constexpr int kWinRegs = KD_WIN_REGS;
