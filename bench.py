@@ -245,6 +245,10 @@ def main():
     ap.add_argument("--workload", default="hlg-lattice", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override per-GPU batch (utterances per step)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the side measurements whose launches are of another shape than the "
+                         "headline's (prune_interval off, host input): what tools/profile_round.sh "
+                         "runs under rocprofv3, so that the trace's average launch is the headline's")
     ap.add_argument("--steps-per-call", type=int, default=4,
                     help="steps (batches of B utterances) handed to the library in one "
                          "kd_batch_decode call: one kernel launch whose persistent workgroups take "
@@ -414,7 +418,7 @@ def main():
     # way -- the knob trades time for memory, and a 10 s utterance needs 5 MB) is reported
     # next to the headline as `value_prune_interval_off`.
     value_pi_off = None
-    if wl["lattice"] and not args.search_only and not args.prune_interval:
+    if wl["lattice"] and not args.search_only and not args.prune_interval and not args.headline_only:
         keep = bts
         bts = [cls(Gr, max_batch=per_slot, max_frames=T, stream=st.cuda_stream,
                    **{**wl["opts"], "prune_interval": 1 << 20}) for st in streams]
@@ -440,7 +444,7 @@ def main():
     # library stages to the device first -- never the headline (the boundary hands over
     # device pointers when the acoustic model runs on the GPU), reported for comparison.
     host_input = None
-    if not args.search_only and world == 1:
+    if not args.search_only and world == 1 and not args.headline_only:
         ts = []
         for _ in range(3):
             fence()

@@ -76,7 +76,7 @@ def main():
             bench = json.loads(txt[-1])
     summary = {
         "round": rnd,
-        "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu "
+        "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --headline-only "
                    "(+ one run each with --pmc FETCH_SIZE / --pmc WRITE_SIZE)",
         "kernel": KERNEL,
         "full_launches": len(full),
