@@ -46,7 +46,11 @@ constexpr int kEpsRegs = KD_LEPS_REGS;  // epsilon links of a frame a lane keeps
 #ifndef KD_WIN_REGS
 #define KD_WIN_REGS 3
 #endif
-constexpr int kWinMax = 64;  // frames per window, at most (one lane of a wave reads a frame's descriptor)
+#ifndef KD_WIN_MAX
+#define KD_WIN_MAX 64
+#endif
+constexpr int kWinMax = KD_WIN_MAX;  // frames per window, at most (one lane of a wave reads a frame's descriptor)
+static_assert(kWinMax >= 1 && kWinMax <= 64, "a lane of one wave per frame of the window");
 constexpr int kWinRegs = KD_WIN_REGS;
 constexpr int kWinLinks = kWinRegs * kBlock;
 constexpr int kWinToks = kLdsToks / 2;
@@ -1062,9 +1066,21 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
 // the pieces gives every piece its place, the archive space is taken in one piece per
 // pool -- so a pool that is exhausted is noticed before anything has moved -- and passes
 // B (tokens) and C (links) copy.
-constexpr int kCollectFrames = 256;  // frames per call
-constexpr int kMaxPieces = 8192;     // pieces per call and record kind
-constexpr int kPiece = 256;          // records per piece (x 2^k)
+// (the stress build, `make stress`, shrinks these so that small test cases reach the paths
+// that only very large collections take at the shipped sizes: piece sizes doubled until
+// the pieces fit, collections split over several calls)
+#ifndef KD_COLLECT_FRAMES
+#define KD_COLLECT_FRAMES 256
+#endif
+#ifndef KD_MAX_PIECES
+#define KD_MAX_PIECES 8192
+#endif
+constexpr int kCollectFrames = KD_COLLECT_FRAMES;  // frames per call
+constexpr int kMaxPieces = KD_MAX_PIECES;          // pieces per call and record kind
+constexpr int kPiece = 256;                        // records per piece (x 2^k)
+// (a non-empty block is at least one piece however large the pieces get: the doubling of
+// the piece size in LatticeCollect ends because of this)
+static_assert(kMaxPieces >= 2 * kCollectFrames, "one piece per frame / link block always fits");
 constexpr int kCU = 4;               // 64-wide steps of a piece a wave has in flight
 static_assert(kPiece == 64 * kCU, "a piece is one unrolled step (or 2^k of them)");
 static_assert(kChunkRing <= 64, "one lane per retired chunk");

@@ -20,3 +20,18 @@ def test_randomised_parity(seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "12", str(seed)],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("seed", [21])
+def test_randomised_parity_with_shrunk_capacities(seed):
+    """The same runs against `libkd_hip_stress.so` (make stress; part of `make all`): the
+    collector limited to 4 frames and 8 pieces per call -- so that collections are split
+    over several calls and piece sizes are doubled until the pieces fit, which the shipped
+    sizes only do beyond two million records -- and sweep windows of at most 3 frames with
+    one link slot per lane."""
+    lib = os.path.join(ROOT, "kaldi-decoder_amd", "python", "kaldi_decoder", "lib", "libkd_hip_stress.so")
+    assert os.path.exists(lib), "make -C kaldi-decoder_amd stress"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "15", str(seed)],
+                       capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "KD_HIP_LIB": "libkd_hip_stress.so"})
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
