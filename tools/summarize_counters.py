@@ -3,6 +3,10 @@
 per-launch averages over the full-size launches of SearchKernel."""
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "kaldi-decoder_amd", "python"))
+import bench  # noqa: E402  (the workload tools/call_timing.py runs: its options go into the note)
+OPTS = bench.WORKLOADS["hlg-lattice"]["opts"]
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 out = {}
 for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{rnd}_*", "*counter_collection.csv"))):
@@ -18,8 +22,9 @@ for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{rnd}_*", "*cou
     for k, v in acc.items():
         out[k] = sum(v) / len(v)
 d = {"note": "rocprofv3 --pmc passes (tools/pmc_counters.sh) over tools/call_timing.py 4: calls of 512 "
-             "utterances x 250 frames (one launch each, one in flight, prune_interval off), averages per "
-             "launch of SearchKernel<1> (search + FinalizeDecoding + GetRawLattice)",
+             f"utterances x 250 frames (one launch each, one in flight, prune_interval {OPTS['prune_interval']}), "
+             "averages per launch of SearchKernel<1> (search + periodic pruning + FinalizeDecoding + "
+             "GetRawLattice)",
      "counters": out}
 if "SQ_INSTS_VALU" in out:
     arcs = 8200.04 * 512 * 250  # arcs scanned per launch (bench line: arcs_scanned_per_frame x utterance-frames)
