@@ -75,11 +75,14 @@ def algorithmic_bytes(stats, V):
         max_tokens=int(stats[:, 8].max()), spill_frames=int(s[9]))
 
 
-def profiled_traffic(workload_desc):
+def profiled_traffic(workload_desc, utt_frames_per_launch, prune_interval):
     """HBM bytes per launch from the newest committed rocprofv3 PMC summary
     (profiles/rNN_summary.json, written by tools/summarize_profile.py from separate
     --pmc FETCH_SIZE / WRITE_SIZE passes of this same command); None if there is
-    no summary for this workload."""
+    no summary for this workload and these options.  The counters are per launch: a
+    summary taken on launches of another size (--steps-per-call) is scaled by the
+    utterance-frames per launch, which is what the traffic is proportional to, and the
+    source says so."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json"))):
@@ -87,8 +90,17 @@ def profiled_traffic(workload_desc):
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if d.get("bench_line_under_profiler", {}).get("config", {}).get("workload") == workload_desc:
-            best = (d["hbm_bytes_per_launch"], os.path.basename(path))
+        line = d.get("bench_line_under_profiler", {})
+        cfg = line.get("config", {})
+        if cfg.get("workload") != workload_desc or cfg.get("prune_interval") != prune_interval:
+            continue
+        theirs = line.get("roofline", {}).get("utterance_frames_per_launch")
+        src = os.path.basename(path)
+        if theirs and theirs != utt_frames_per_launch:
+            best = (d["hbm_bytes_per_launch"] * utt_frames_per_launch / theirs,
+                    f"{src} (measured on launches of {theirs} utterance-frames, scaled to {utt_frames_per_launch})")
+        else:
+            best = (d["hbm_bytes_per_launch"], src)
     return best
 
 
@@ -249,11 +261,11 @@ def main():
                     help="skip the side measurements whose launches are of another shape than the "
                          "headline's (prune_interval off, host input): what tools/profile_round.sh "
                          "runs under rocprofv3, so that the trace's average launch is the headline's")
-    ap.add_argument("--steps-per-call", type=int, default=4,
+    ap.add_argument("--steps-per-call", type=int, default=8,
                     help="steps (batches of B utterances) handed to the library in one "
                          "kd_batch_decode call: one kernel launch whose persistent workgroups take "
                          "all their utterances from one work queue")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=2,
                     help="library calls in flight, each on a batch object and stream of its own; "
                          "one host thread enqueues them (the decode call is asynchronous) and "
                          "collects them in order")
@@ -479,7 +491,7 @@ def main():
     elif rank == 0:
         alg_bytes, per_frame = algorithmic_bytes(stats, V)  # of one full launch (n_last steps)
         k_ms = float(np.mean([k for k, n in launches if n == n_last] or [k for k, _ in launches]))
-        traffic = profiled_traffic(wl["desc"])
+        traffic = profiled_traffic(wl["desc"], n_last * B * T, opts.get("prune_interval"))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         frames_total = world * B * T * steps_timed
         cap = bt.capacity()
