@@ -6,7 +6,10 @@
 //   FinalCosts   ComputeFinalCosts (:522-560), FinalRelativeCost (:562-572)
 //   Prune        PruneForwardLinksFinal (:425-520) and the backward sweep of
 //                FinalizeDecoding (:407-420) = PruneForwardLinks with delta 0 (:228-305) +
-//                PruneTokensForFrame (:310-334) for every frame
+//                PruneTokensForFrame (:310-334) for every frame; PruneActiveTokens
+//                (:198-223), the same sweep between two frames of the search; small
+//                frames are swept a window at a time (SweepWindow)
+//   Collect      what PruneActiveTokens leaves of old frames moves to the archive
 //   Export       GetRawLattice (:584-657): sizes, state numbering, then states, final
 //                weights and arcs into ONE contiguous region of the batch's output pool
 //
@@ -19,11 +22,16 @@
 // graph) - next.tot), links above lattice_beam are excised (dst = -1), the survivors
 // min-reduce into their source token's extra cost with ds_min_u32 on an order-preserving
 // float key held in LDS (one word per token of the frame).  Epsilon links point inside
-// the frame, so the frame is iterated to its fixpoint (from below: extras start at 0 and
-// only grow, which makes early excision safe).
+// the frame, so the frame is iterated to its fixpoint (frames swept one by one: from below,
+// extras start at 0 and only grow, which makes early excision safe; windows of small frames:
+// from above, links excised when the keys are final -- SweepWindow says why both give the
+// same bits).
 //
-// Export order is deterministic given the arena order: ids and arc positions are ranks
-// (ballot + popcount inside a frame, a prefix sum over the frames), not atomic counters.
+// State ids are frame-major like the reference's.  Inside a frame, and for arcs, the order
+// is the arena order in the general export (ranks: ballot + popcount, a prefix sum over the
+// frames) and the order in which the sweep listed the survivors in the staged export
+// (atomic list positions, an atomic counter per frame): lattices are equal as sets from
+// run to run, not as arrays.
 
 #ifndef KD_LEPS_REGS
 #define KD_LEPS_REGS 4
