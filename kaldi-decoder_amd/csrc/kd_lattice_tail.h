@@ -33,8 +33,11 @@
 // (atomic list positions, an atomic counter per frame): lattices are equal as sets from
 // run to run, not as arrays.
 
+// (epsilon links of a frame a lane keeps in registers on the frame-by-frame LDS path; one
+// is enough for frames of up to 768 epsilon links -- the bench workload's largest has 282 --
+// and leaves the windows more registers: 4 measured + 5 % on the sweeps' cycles)
 #ifndef KD_LEPS_REGS
-#define KD_LEPS_REGS 4
+#define KD_LEPS_REGS 1
 #endif
 // Extra-cost keys of one frame kept in LDS (144 KiB of 160 with one workgroup per CU): the
 // part of the search's LDS block below the frontier's state array.  The periodic sweep
