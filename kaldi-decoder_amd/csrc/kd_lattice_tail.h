@@ -529,6 +529,14 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
     d.pb = s.win.pb[j]; d.pn = s.win.pn[j];
     return d;
   };
+  // (a descriptor is the same in every lane: once it has arrived it is kept in scalar
+  // registers, which leaves the windows nine more vector registers)
+  auto uniform = [&](const Desc &v) {
+    Desc d;
+    d.base = Uni(v.base); d.eb = Uni(v.eb); d.pb = Uni(v.pb);
+    d.n = Uni(v.n); d.en = Uni(v.en); d.pn = Uni(v.pn);
+    return d;
+  };
   int flip = 0;  // which half of the key array the next LDS-resident frame or window takes
 #ifdef KD_PROFILE
   // diagnostic build: cycles in windows (bucket 16) and in frames swept one by one (18)
@@ -552,7 +560,7 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
   auto prof = [](int) {};
   auto prof_flush = []() {};
 #endif
-  Desc ahead = describe(f_top), ahead2 = f_top > 0 ? describe(f_top - 1) : ahead;
+  Desc ahead = uniform(describe(f_top)), ahead2 = f_top > 0 ? describe(f_top - 1) : ahead;
   Pre pre;
   bool have_pre = false;
   if (!win_ok(ahead, f_top) && fits_lds(ahead)) { fetch(ahead, pre); have_pre = true; }
@@ -565,7 +573,7 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
       if (stop) break;
       f = f_low;  // (the loop steps to the frame below the window)
       if (f > 0) {  // the builder read the descriptors of kWinMax frames
-        ahead = W < kWinMax ? from_window(W) : describe(f - 1);
+        ahead = uniform(W < kWinMax ? from_window(W) : describe(f - 1));
         ahead2 = f > 1 ? (W + 1 < kWinMax ? from_window(W + 1) : describe(f - 2)) : ahead;
         have_pre = !win_ok(ahead, f - 1) && fits_lds(ahead);
         if (have_pre) fetch(ahead, pre);
@@ -575,7 +583,7 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
     f_low = f;
     if (tid == 0) s.frame_changed = 0;  // (read behind the barriers at the frame's end)
     const Desc d = ahead;
-    ahead = ahead2;
+    ahead = uniform(ahead2);  // (requested a frame ago)
     if (f > 1) ahead2 = describe(f - 2);
     const long long base = d.base;
     const int n = d.n;
