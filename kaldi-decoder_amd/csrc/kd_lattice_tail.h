@@ -538,8 +538,10 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
     return d;
   };
   int flip = 0;  // which half of the key array the next LDS-resident frame or window takes
-#ifdef KD_PROFILE
-  // diagnostic build: cycles in windows (bucket 16) and in frames swept one by one (18)
+#if defined(KD_PROFILE) && defined(KD_PROF_TAIL)
+  // diagnostic build `prof_tail`: cycles in windows (bucket 16) and in frames swept one by
+  // one (18) -- a BREAKDOWN of time that buckets 21 (FinalizeDecoding) and 23 (periodic
+  // sweep + collector) already hold, so this build's bucket sum counts it twice
   long long prof_lap = static_cast<long long>(__builtin_amdgcn_s_memtime()), prof_cyc[2] = {0, 0};
   auto prof = [&](int which) {
     const long long now = static_cast<long long>(__builtin_amdgcn_s_memtime());
@@ -1396,7 +1398,7 @@ __device__ __noinline__ uint32_t PeriodicPrune(CParams *pp, int utt, int F, int 
                p.lat.lattice_beam * p.lat.prune_scale);
   const int hi = F - p.lat.prune_interval;
   uint32_t r = 0;
-#ifdef KD_PROFILE
+#if defined(KD_PROFILE) && defined(KD_PROF_TAIL)
   const long long lap = static_cast<long long>(__builtin_amdgcn_s_memtime());
 #endif
   while (r == 0) {
@@ -1404,8 +1406,9 @@ __device__ __noinline__ uint32_t PeriodicPrune(CParams *pp, int utt, int F, int 
     if (lo >= hi) break;
     r = LatticeCollect(p, s, utt, lo, hi - lo > kCollectFrames ? lo + kCollectFrames : hi);
   }
-#ifdef KD_PROFILE
-  // diagnostic build: the collector's cycles on top of bucket 17 (the search's link records)
+#if defined(KD_PROFILE) && defined(KD_PROF_TAIL)
+  // diagnostic build `prof_tail`: the collector's cycles on top of bucket 17 (the search's
+  // link records); part of bucket 23 too
   if (threadIdx.x == 0) Lds().cyc[17] += static_cast<long long>(__builtin_amdgcn_s_memtime()) - lap;
 #endif
   return r;

@@ -5,7 +5,8 @@
     KD_HIP_LIB=libkd_hip_prof.so python tools/prof_phases.py [hlg-lattice|hlg-1best|hl] [batch]
 
 Never quote this build's run time: the stamps forbid overlaps the real kernel
-has.  Read the shares."""
+has.  Read the shares.  (KD_HIP_LIB=libkd_hip_prof_tail.so breaks the lattice sweeps' time
+down into buckets 16-18 -- time that buckets 21 and 23 hold too: its sum counts it twice.)"""
 import os
 import sys
 
