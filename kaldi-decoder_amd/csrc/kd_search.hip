@@ -263,6 +263,20 @@ __device__ __forceinline__ StateRec LoadState(const StateRec *base, uint32_t i) 
   r.arc_begin = v.x; r.emit_end = v.y; r.arc_end = v.z; r.final_cost = __int_as_float(v.w);
   return r;
 }
+// The first half of a state record (arc_begin, emit_end: the emitting arc range) with one
+// global_load_dwordx2.  Where only the range is wanted this is not a saving of bandwidth
+// but of a wait: hipcc reuses the dead upper half of a dwordx4 destination at once, and
+// must then wait for the load to complete before it may overwrite those registers.
+typedef int v2i __attribute__((ext_vector_type(2)));
+struct ArcRange { int32_t arc_begin, emit_end; };
+static_assert(offsetof(StateRec, arc_begin) == 0 && offsetof(StateRec, emit_end) == 4 && sizeof(StateRec) == 16,
+              "LoadArcRange reads the first two words of a state record");
+__device__ __forceinline__ ArcRange LoadArcRange(const StateRec *base, uint32_t i) {
+  const v2i v = reinterpret_cast<const KD_G v2i *>(ToG(base))[2 * static_cast<size_t>(i)];
+  ArcRange r;
+  r.arc_begin = v.x; r.emit_end = v.y;
+  return r;
+}
 __device__ __forceinline__ ArcRec LoadArcRec(const ArcRec *base, uint32_t i) {
   const v4i v = reinterpret_cast<const KD_G v4i *>(ToG(base))[i];
   ArcRec r;
@@ -2101,7 +2115,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // overlaps the passes in between.
   constexpr int kNextRecs = (kT1Front + kBlock - 1) / kBlock;
   static_assert(kT1Narrow == 0, "kNextRecs assumes the whole workgroup runs the frame");
-  StateRec next_rec[kNextRecs];
+  ArcRange next_rec[kNextRecs];
   bool next_on[kNextRecs];
   {
     uint32_t st_next[kNextRecs];
@@ -2113,7 +2127,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       st_next[j] = next_on[j] ? s.key[h] & kStateMask : 0u;  // (before the key words become indices)
     }
 #pragma unroll
-    for (int j = 0; j < kNextRecs; ++j) next_rec[j] = LoadState(p.states, st_next[j]);
+    for (int j = 0; j < kNextRecs; ++j) next_rec[j] = LoadArcRange(p.states, st_next[j]);
   }
   for (int i = tid; i < n_out; i += nt) {
     const int h = T1Live(s)[i];
