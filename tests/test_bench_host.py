@@ -50,3 +50,12 @@ def test_committed_summary_matches_the_bench_line_next_to_it():
         assert b["roofline"]["traffic"] == s["hbm_bytes_per_launch"]
         # average launch: rocprofv3's trace against the HIP events of the bench line
         assert abs(s["avg_launch_ms"] - b["roofline"]["kernel_ms"]) / b["roofline"]["kernel_ms"] < 0.05
+
+
+def test_library_is_not_built_with_the_option_that_stalled_the_large_workload():
+    """DESIGN §5 "A 5 % that is not taken": -amdgpu-prealloc-sgpr-spill-vgprs made the bench
+    5 % faster and the large-LM workload stall or fault in 2 runs of 3.  Whoever turns it
+    back on has to have run `bench.py --workload hlg-large` a number of times first."""
+    mk = open(os.path.join(ROOT, "kaldi-decoder_amd", "Makefile")).read()
+    flags = [ln for ln in mk.splitlines() if ln.startswith("HIPFLAGS")]
+    assert flags and all("prealloc-sgpr-spill-vgprs" not in ln for ln in flags)
