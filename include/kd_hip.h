@@ -81,7 +81,6 @@ typedef struct kd_faster_options {
   int32_t min_active;
   float beam_delta;
   float hash_ratio;
-  /* capacity knobs (not in the reference) */
   /* capacity knobs (not in the reference).  They are STARTING sizes: whatever a decode
    * exhausts is doubled and the search resumes where it stopped (the reference, too, is
    * limited only by the machine's memory).  0 picks the default. */
@@ -233,12 +232,18 @@ int kd_batch_create_simple(const kd_graph *g, float beam, int64_t arena_tokens,
  * search: LatticeSimpleDecoder's semantics (ref: csrc/lattice-simple-decoder.cc)
  * and, with max_active / min_active set, the LatticeFasterDecoder the reference
  * only declares (ref: csrc/lattice-faster-decoder.h:23-134).  Costs are float,
- * every arc below the frame's cutoff is recorded as a forward link, and all
- * pruning happens in kd_batch_finalize_decoding (prune_interval / prune_scale are
- * validated like the reference's Check() and otherwise unused: with 288 GB of
- * HBM the periodic PruneActiveTokens is unnecessary and it never changes the
- * finalized lattice).  init / advance / num_frames_decoded / status / stats are
- * the kd_batch_* calls above.
+ * every arc below the frame's cutoff is recorded as a forward link.  Every
+ * prune_interval frames the search runs PruneActiveTokens (ref:
+ * csrc/lattice-simple-decoder.cc:57-59,198-223; tolerance lattice_beam *
+ * prune_scale) and moves what survives of the older frames to a compacted
+ * archive, so an utterance's memory follows its pruned lattice plus a window of
+ * recent frames; kd_batch_finalize_decoding then prunes exactly (delta 0), so the
+ * finalized lattice does not depend on prune_interval.  init / advance /
+ * num_frames_decoded / status / stats are the kd_batch_* calls above.
+ * kd_batch_reached_final on a lattice batch is FinalRelativeCost() != infinity
+ * (ref: csrc/lattice-simple-decoder.h:142-147); kd_batch_best_path_* are
+ * KD_E_STATE (lattice tokens carry no back-pointers: take the shortest path
+ * through the raw lattice, ref: csrc/lattice-simple-decoder.cc:574-580).
  */
 typedef struct kd_lattice_options {
   float beam;

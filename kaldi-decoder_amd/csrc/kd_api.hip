@@ -304,7 +304,10 @@ int GrowLinks(kd_batch *b) {
   return KD_OK;
 }
 
+constexpr uint64_t kMaxOutWords = 1ull << 33;  // 64 GiB of pinned host memory
 int GrowOut(kd_batch *b) {
+  if (b->out_cap >= kMaxOutWords)
+    return Fail(KD_E_CAPACITY, "lattice output pool full at 2^33 words");
   const uint64_t cap = b->out_cap * 2;
   // (what the pool holds is exported again after growing: nothing to keep)
   unsigned long long *np = nullptr;
@@ -318,26 +321,36 @@ int GrowOut(kd_batch *b) {
 }
 
 hipError_t AllocTables(kd_batch *b, int lg) {
+  // The new set is allocated before the old one is let go: if an allocation fails mid-way
+  // the batch keeps its old tables (and g_log2_slots), and stays usable at its old size.
   const size_t gs = static_cast<size_t>(b->workgroups) << lg;
+  DevBuf<uint32_t> key, arc, used, wl, log_h, log_arc, log_src;
+  DevBuf<unsigned long long> cost, log_nk;
+  DevBuf<float> log_ac, log_gr;
   hipError_t e = hipSuccess;
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-  A(b->g_key.Alloc(gs));
-  A(b->g_cost.Alloc(gs));
-  A(b->g_arc.Alloc(gs));
-  A(b->g_used.Alloc(gs));
-  A(b->g_wl.Alloc(2 * gs));
-  A(b->g_log_h.Alloc(2 * gs));
-  A(b->g_log_arc.Alloc(2 * gs));
-  A(b->g_log_src.Alloc(2 * gs));
-  A(b->g_log_nk.Alloc(2 * gs));
-  if (b->lattice || b->simple) A(b->g_log_ac.Alloc(2 * gs));
-  if (b->lattice) A(b->g_log_gr.Alloc(2 * gs));
-  if (e == hipSuccess) e = hipMemsetAsync(b->g_key.p, 0xFF, b->g_key.bytes(), b->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(b->g_cost.p, 0xFF, b->g_cost.bytes(), b->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(b->g_arc.p, 0xFF, b->g_arc.bytes(), b->stream);
+  A(key.Alloc(gs));
+  A(cost.Alloc(gs));
+  A(arc.Alloc(gs));
+  A(used.Alloc(gs));
+  A(wl.Alloc(2 * gs));
+  A(log_h.Alloc(2 * gs));
+  A(log_arc.Alloc(2 * gs));
+  A(log_src.Alloc(2 * gs));
+  A(log_nk.Alloc(2 * gs));
+  if (b->lattice || b->simple) A(log_ac.Alloc(2 * gs));
+  if (b->lattice) A(log_gr.Alloc(2 * gs));
+  if (e == hipSuccess) e = hipMemsetAsync(key.p, 0xFF, key.bytes(), b->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(cost.p, 0xFF, cost.bytes(), b->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(arc.p, 0xFF, arc.bytes(), b->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-  if (e == hipSuccess) b->g_log2_slots = lg;
-  return e;
+  if (e != hipSuccess) return e;  // (the locals free what was allocated)
+  auto S = [](auto &dst, auto &src) { std::swap(dst.p, src.p); std::swap(dst.n, src.n); };
+  S(b->g_key, key); S(b->g_cost, cost); S(b->g_arc, arc); S(b->g_used, used); S(b->g_wl, wl);
+  S(b->g_log_h, log_h); S(b->g_log_arc, log_arc); S(b->g_log_src, log_src); S(b->g_log_nk, log_nk);
+  S(b->g_log_ac, log_ac); S(b->g_log_gr, log_gr);
+  b->g_log2_slots = lg;
+  return hipSuccess;
 }
 
 int GrowTables(kd_batch *b) {
@@ -1036,6 +1049,9 @@ int kd_batch_status(kd_batch *b, uint32_t *out) {
 
 static int PreparePath(kd_batch *b, int32_t use_final_probs) {
   if (!b->initialized) return Fail(KD_E_STATE, "InitDecoding() has not been called");
+  // (lattice tokens carry forward links, not back-pointers: the path tail is not theirs,
+  // and rewinding the output pool here would orphan an exported lattice)
+  if (b->lattice) return Fail(KD_E_STATE, "a lattice batch has no back-pointers: use kd_batch_raw_lattice_*");
   KD_HIP_TRY(hipSetDevice(b->g->device));
   if (b->pending)
     if (int r = ReadBack(b)) return r;
@@ -1048,6 +1064,15 @@ static int PreparePath(kd_batch *b, int32_t use_final_probs) {
 
 int kd_batch_reached_final(kd_batch *b, int32_t *out) {
   if (!b || !out) return Fail(KD_E_INVALID, "bad argument");
+  if (b->lattice) {
+    // lattice-simple-decoder.h:142-147: "FinalRelativeCost() serves the same purpose as
+    // ReachedFinal()": infinity iff no final state is active.  A tail launch that only
+    // computes the final costs; an exported lattice in the output pool stays valid.
+    std::vector<float> rel(static_cast<size_t>(b->batch));
+    if (int r = kd_batch_final_relative_cost(b, rel.data())) return r;
+    for (int i = 0; i < b->batch; ++i) out[i] = std::isinf(rel[i]) ? 0 : 1;
+    return KD_OK;
+  }
   if (int r = PreparePath(b, b->path_valid ? b->path_use_final : 1)) return r;
   for (int i = 0; i < b->batch; ++i) out[i] = b->h_reached[i];
   return KD_OK;
@@ -1176,7 +1201,6 @@ int kd_batch_raw_lattice_copy(kd_batch *b, const int64_t *state_off, const int64
   if (!b->lattice || b->exported_use_final < 0 || b->pending)
     return Fail(KD_E_STATE, "call kd_batch_raw_lattice_prepare first");
   KD_HIP_TRY(hipSetDevice(b->g->device));
-  if (b->h_out_top == 0) return KD_OK;
   // an utterance's region: states {frame, graph state} | finals {state, weight} |
   // arcs {src, dst, ilabel, olabel, graph, ac}
   for (int i = 0; i < b->batch; ++i) {

@@ -140,7 +140,10 @@ __device__ __noinline__ uint32_t PathTail(CParams *pp, int utt, int F, uint32_t 
     s.r_sizes[2] = static_cast<int32_t>(__float_as_uint(fw));
   }
   if (len <= 0) { __syncthreads(); return 0; }
-  if (len >= st.cap) { __syncthreads(); return KD_UTT_OUT_FULL; }  // (a path of > 32 k arcs)
+  // a path longer than the workgroup's staging queue (2 * table slots: 262 k arcs at the
+  // default): the limit that was hit is the queue, not the output pool, so the host must
+  // enlarge the tables (GrowTables) -- growing the pool would fail the same way for ever
+  if (len >= st.cap) { __syncthreads(); return KD_UTT_TABLE_FULL; }
   if (tid == 0) {
     const unsigned long long words = 3ull * len;
     s.out_off = PoolTake(&p.ctl->out_top, p.out_base, p.lat.out_cap, words);

@@ -2559,6 +2559,34 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   int visited = do_init ? -1 : Uni(ToG(p.mem)[utt].visited);
 
   while (err == 0 && frame < target) {
+    if constexpr (M == 1) {
+      // PruneActiveTokens every prune_interval frames, BEFORE the frame is processed like
+      // the reference's (lattice-simple-decoder.cc:57-59) -- so a call that resumes on a
+      // multiple of the interval (streaming in chunks of 1, 5, 25, ... frames) performs the
+      // prune its predecessor left pending.  Bounds what FinalizeDecoding will have to look
+      // at and, with it, memory.
+      if (frame > 0 && frame % p.lat.prune_interval == 0 && frame - 1 > visited) {
+        __syncthreads();
+        KD_LAP(s, 13);
+        if (tid == 0) {  // (the collector takes archive chunks through the same cursors' owner)
+          KD_G UttMem *m = ToG(p.mem) + utt;
+          m->arena_next = s.arena_next; m->arena_end = s.arena_end;
+          m->link_next = s.link_next; m->link_end = s.link_end;
+        }
+        __syncthreads();
+        const uint32_t pe = Uni(PeriodicPrune(&p, utt, frame, visited));
+        visited = frame - 1;
+        __syncthreads();
+        // the sweep used the LDS block: the table is cleared again, the frontier comes
+        // back from the arena (this frame's log-likelihood row and the frame counters
+        // lie beyond what the sweep touches)
+        FullClear<true>(tl, s);
+        front_lds = false;
+        upper_dirty = false;
+        KD_LAP(s, 23);
+        if (pe) { err |= pe; break; }
+      }
+    }
     KD_LAP(s, 13);
     Counters cnt;
     bool small = false;
@@ -2670,31 +2698,6 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     }
     if (r != 0) { err |= r; break; }
     frame++;
-    if constexpr (M == 1) {
-      // PruneActiveTokens every prune_interval frames (lattice-simple-decoder.cc:57-59):
-      // bounds what FinalizeDecoding will have to look at and, with it, memory
-      if (frame < target && frame > 0 && frame % p.lat.prune_interval == 0 && frame - 1 > visited) {
-        __syncthreads();
-        KD_LAP(s, 13);
-        if (tid == 0) {  // (the collector takes archive chunks through the same cursors' owner)
-          KD_G UttMem *m = ToG(p.mem) + utt;
-          m->arena_next = s.arena_next; m->arena_end = s.arena_end;
-          m->link_next = s.link_next; m->link_end = s.link_end;
-        }
-        __syncthreads();
-        const uint32_t pe = Uni(PeriodicPrune(&p, utt, frame, visited));
-        visited = frame - 1;
-        __syncthreads();
-        if (pe) { err |= pe; }
-        // the sweep used the LDS block: the table is cleared again, the frontier comes
-        // back from the arena (the next frame's log-likelihood row and the frame counters
-        // lie beyond what the sweep touches)
-        FullClear<true>(tl, s);
-        front_lds = false;
-        upper_dirty = false;
-        KD_LAP(s, 23);
-      }
-    }
   }
 
   // fold the small frames' per-lane work counters into the launch totals

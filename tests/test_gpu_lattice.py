@@ -351,6 +351,57 @@ def test_periodic_pruning_bounds_memory(oracle):
     assert cap["links_used"] < created // 2, (cap, created)  # the pool never held them all
 
 
+def test_streaming_in_chunks_of_prune_interval_still_prunes(oracle):
+    """AdvanceDecoding in chunks that end on multiples of prune_interval (25 frames a call):
+    the prune a call leaves pending is performed by the next one, before its first frame,
+    as the reference's Decode() does at the top of every frame
+    (lattice-simple-decoder.cc:57-59) -- the footprint stays bounded and the finalized
+    lattice is the canonical one."""
+    import torch
+    g = synth.ctc_topo(100)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    T, V = 1500, 100
+    lp = synth.make_logprobs(T, V, 77, peak=7.0)
+    dev = torch.from_numpy(lp).cuda()
+    opts = dict(beam=8.0, lattice_beam=4.0, min_active=0)
+    kw = dict(arena_tokens=1 << 16, arena_links=1 << 18, max_frames=T, no_grow=1)
+    for chunk in (25, 5, 50):
+        lb = cabi.LatticeBatch(G, max_batch=1, prune_interval=25, **kw, **opts)
+        lb.init_decoding()
+        while lb.num_frames_decoded()[0] < T:
+            lb.advance_device([dev.data_ptr()], [T], V, max_num_frames=chunk)
+        can = oracle.CanonLatticeDecoder(OG, **opts)
+        can.decode(lp)
+        cap = lb.capacity()
+        assert cap["links_used"] < can.links_created() // 2, (chunk, cap)
+        lb.finalize_decoding()
+        _assert_same_lattice(lb.raw_lattices()[0], can.get_raw_lattice(), f"chunk {chunk}")
+
+
+def test_reached_final_on_a_lattice_batch_leaves_the_export_alone(oracle):
+    """kd_batch_reached_final on a lattice batch is FinalRelativeCost() != infinity
+    (lattice-simple-decoder.h:142-147) and must not disturb an exported lattice."""
+    g = synth.hlg_graph(V=40, n_words=200, n_hist=200, avg_succ=8, seed=4)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lps = [synth.make_logprobs(40, 40, i, peak=6.0, lexicon=g["lexicon"]) for i in range(3)]
+    # (the last utterance: three frames only -- no final state is active yet)
+    lps[2] = lps[2][:3]
+    opts = dict(beam=10.0, lattice_beam=6.0, min_active=0)
+    lb = cabi.LatticeBatch(G, max_batch=3, **opts)
+    lb.decode_host(lps)
+    rf = lb.reached_final()
+    lats = lb.raw_lattices()
+    rf2 = lb.reached_final()
+    for i, lp in enumerate(lps):
+        can = oracle.CanonLatticeDecoder(OG, **opts)
+        can.decode(lp)
+        want = can.final_relative_cost() != float("inf")
+        assert bool(rf[i]) == want and bool(rf2[i]) == want, i
+        _assert_same_lattice(lats[i], can.get_raw_lattice(), f"utt {i}")
+    with pytest.raises(RuntimeError, match="back-pointers"):
+        lb.best_paths()
+
+
 def test_decode_from_host_matrices_in_one_launch(oracle):
     """kd_batch_decode with KD_MEM_HOST: the matrices are staged, then the same one-launch
     Decode (ragged lengths); lattice and 1-best batches."""
