@@ -359,15 +359,33 @@ def main():
         enqueue(slot, n_steps)
         return collect(slot)
 
-    def deliver(out):
-        # the only exchange between ranks: finished results go to rank 0, in call order so
-        # every rank runs its collectives alike
-        if world > 1 and out is not None:
-            if wl["lattice"]:
-                # (left in rank 0's HBM: the gather is the exchange, not a host copy)
-                sharded.gather_lattices(out, dst=0, keep_on_device=True)
-            else:
-                sharded.gather_paths([(p.ilabel, p.olabel) for p in out], dst=0)
+    # The only exchange between ranks: finished lattices go to rank 0 (north_star: "RCCL over
+    # xGMI only for gather of final lattices").  The batches export into device buffers lent
+    # to them (kd_batch_set_output_buffer), so a call's result is handed to RCCL as device
+    # memory -- no host packing, no upload -- and the exchange (an all_gather of sizes, then
+    # grouped point-to-point receives of exactly those sizes on rank 0) runs on a WORKER thread
+    # and a stream of its own (sharded.ResultGatherer): the thread that enqueues the decode
+    # calls never waits for another rank.  With one rank the same path runs and the exchange
+    # is empty.  (1-best workloads: the label sequences, packed on the host -- a few KB.)
+    gatherer = sharded.ResultGatherer(dst=0, keep=False)
+    out_bufs = None
+    if wl["lattice"] and not args.search_only:
+        out_bufs = [torch.zeros(per_slot << 13, dtype=torch.int64, device="cuda") for _ in range(n_fly)]
+        for bt_, buf_ in zip(bts, out_bufs):
+            bt_.set_output_buffer(buf_)
+
+    def deliver(out, slot):
+        if out is None:
+            return
+        if out_bufs is not None:
+            used, table = bts[slot].raw_lattice_table()
+            with torch.cuda.stream(streams[slot]):  # (ahead of the slot's next launch, which rewrites the buffer)
+                payload = sharded.pool_payload(out_bufs[slot], used, table)
+                ready = torch.cuda.Event()
+                ready.record(streams[slot])
+            gatherer.submit(payload, ready)
+        elif world > 1:
+            sharded.gather_paths([(p.ilabel, p.olabel) for p in out], dst=0)
 
     def fence():
         if world > 1:
@@ -386,10 +404,11 @@ def main():
             enqueue(i % n_fly, sizes[i])
         for i in range(len(sizes)):
             r = collect(i % n_fly)
+            deliver(r[0], i % n_fly)  # (before the slot's next launch rewrites its output buffer)
             if i + n_fly < len(sizes):
                 enqueue(i % n_fly, sizes[i + n_fly])
             res.append(r + (sizes[i], i % n_fly))
-            deliver(r[0])
+        gatherer.flush()  # (the exchange of every call of this run has completed)
         return res
 
     # every slot's batch gets at least one untimed full call when warmup is requested
@@ -434,6 +453,9 @@ def main():
         keep = bts
         bts = [cls(Gr, max_batch=per_slot, max_frames=T, stream=st.cuda_stream,
                    **{**wl["opts"], "prune_interval": 1 << 20}) for st in streams]
+        if out_bufs is not None:
+            for bt_, buf_ in zip(bts, out_bufs):
+                bt_.set_output_buffer(buf_)
         run_steps(2 * n_fly * G)
         fence()
         # (as long a timed region as the headline's: the pipeline's fill and drain -- one call's
@@ -457,6 +479,7 @@ def main():
     # device pointers when the acoustic model runs on the GPU), reported for comparison.
     host_input = None
     if not args.search_only and world == 1 and not args.headline_only:
+        # one call at a time (what round 2 reported) ...
         ts = []
         for _ in range(3):
             fence()
@@ -464,9 +487,31 @@ def main():
             bts[0].decode_host(all_lps[:per_slot])
             (bts[0].raw_lattices() if wl["lattice"] else bts[0].best_paths())
             ts.append(time.perf_counter() - t1)
-        host_input = dict(value=per_slot * T * SUBSAMPLING / float(np.median(ts)), unit="audio_frames/s",
-                          ms_per_call=float(np.median(ts)) * 1e3,
-                          note=f"one call of {per_slot} utterances at a time, log-probs in pageable "
+        serial_s = float(np.median(ts))
+        # ... and the same pipeline as the headline's, fed host matrices: the calls are kept
+        # n_fly deep (kd_batch_decode_host_async), so one batch's rows cross PCIe while the
+        # other batches' launches run
+        def host_round(n_calls):
+            for i in range(min(n_fly, n_calls)):
+                bts[i % n_fly].decode_host(all_lps[(i % n_fly) * per_slot:(i % n_fly + 1) * per_slot], sync=False)
+            for i in range(n_calls):
+                bt_i = bts[i % n_fly]
+                bt_i.sync()
+                (bt_i.raw_lattices() if wl["lattice"] else bt_i.best_paths())
+                if i + n_fly < n_calls:
+                    bt_i.decode_host(all_lps[(i % n_fly) * per_slot:(i % n_fly + 1) * per_slot], sync=False)
+        host_round(n_fly)
+        fence()
+        n_calls = 3 * n_fly
+        t1 = time.perf_counter()
+        host_round(n_calls)
+        fence()
+        piped_s = (time.perf_counter() - t1) / n_calls
+        host_input = dict(value=per_slot * T * SUBSAMPLING / piped_s, unit="audio_frames/s",
+                          ms_per_call=piped_s * 1e3,
+                          one_call_at_a_time=dict(value=per_slot * T * SUBSAMPLING / serial_s,
+                                                  ms_per_call=serial_s * 1e3),
+                          note=f"calls of {per_slot} utterances, {n_fly} in flight, log-probs in pageable "
                                f"host memory ({per_slot * T * V * 4 / 2**20:.0f} MB per call)")
     # one batch of B utterances alone on the GPU, nothing else in flight: what a caller
     # who submits a single batch gets
@@ -501,8 +546,10 @@ def main():
             "value": frames_total * SUBSAMPLING / elapsed,
             "unit": "audio_frames/s",
             "n_gpus": world,
-            "steps": steps_timed,
-            "steps_requested": args.steps,
+            # `steps` is what --steps asked for; the timed region repeats them `repeats` times
+            # (until it lasts --min-seconds): `steps_timed` steps went into `value`
+            "steps": args.steps,
+            "steps_timed": steps_timed,
             "repeats": repeats,
             "warmup": args.warmup,
             "ms_per_step": elapsed / steps_timed * 1e3,
@@ -560,6 +607,7 @@ def main():
         print(json.dumps(res))
     if cpu_pool is not None:
         cpu_pool.close()
+    gatherer.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -162,6 +162,14 @@ int kd_batch_decode_async(kd_batch *b, int32_t batch, const float *const *loglik
 int kd_batch_decode(kd_batch *b, int32_t batch, const float *const *loglikes,
                     const int32_t *num_rows, const int32_t *offset, int32_t num_cols,
                     int64_t row_stride, int mem_kind, int32_t want);
+/* The same for HOST matrices without waiting for the kernel (ref: DecodableCtc(feats),
+ * csrc/decodable-ctc.h:15-16, copies its matrix; here the rows go to the device): returns
+ * when the rows have left the caller's memory and the launch is enqueued behind them on the
+ * batch's stream; pair with kd_batch_sync.  A caller that keeps two batches going this way
+ * has one batch's copies overlap the other's search. */
+int kd_batch_decode_host_async(kd_batch *b, int32_t batch, const float *const *loglikes,
+                               const int32_t *num_rows, const int32_t *offset, int32_t num_cols,
+                               int64_t row_stride, int32_t want);
 
 /* FasterDecoder::NumFramesDecoded per utterance (ref: csrc/faster-decoder.h:104). */
 int kd_batch_num_frames_decoded(kd_batch *b, int32_t *out);
@@ -290,6 +298,23 @@ int kd_batch_raw_lattice_copy(kd_batch *b, const int64_t *state_off, const int64
                               int32_t *ilabel, int32_t *olabel, float *graph_cost,
                               float *ac_cost, int32_t *state_frame, int32_t *state_graph,
                               int32_t *final_state, float *final_graph);
+
+/* ---- exported results in DEVICE memory ---------------------------------------------
+ * By default the kernel writes exported lattices (and best paths) into a pinned host pool
+ * of the batch.  A caller that wants them on the GPU -- the multi-GPU gather hands RCCL a
+ * device buffer: no host packing, no upload -- lends a device buffer of `cap_words`
+ * 8-byte words; the kernel then writes there, and the host-array calls above copy what
+ * they need back on demand.  NULL returns to the batch's own pool.  Not growable: a full
+ * buffer is KD_E_CAPACITY.  (No counterpart in the reference: its lattices are host
+ * objects, csrc/lattice-simple-decoder.cc:584-657.) */
+int kd_batch_set_output_buffer(kd_batch *b, void *device_words, int64_t cap_words);
+/* After a decode with KD_DECODE_LATTICE (or kd_batch_raw_lattice_prepare): how many words of
+ * the output pool / buffer are in use, and per utterance {first word, states, arcs, finals,
+ * start state}.  An utterance's region: states {frame, graph state} x ns | finals {state,
+ * weight} x nf | arcs {src, dst | ilabel, olabel | graph, ac} x na, ordered as
+ * kd_batch_raw_lattice_copy delivers them. */
+int kd_batch_raw_lattice_table(kd_batch *b, int64_t *used_words, int64_t *table /* [batch][5] */);
+
 
 /* Diagnostic builds only (make -C kaldi-decoder_amd prof, -DKD_PROFILE): shader
  * clock cycles lane 0 spent per phase, 24 int64 per utterance (bucket names in

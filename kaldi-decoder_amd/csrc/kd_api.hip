@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -78,6 +79,14 @@ struct kd_batch {
   DevBuf<int32_t> link_src, link_dst, link_arc;
   DevBuf<float> link_ac, link_graph, link_delta;
   unsigned long long *out_pool = nullptr;  // pinned host memory, written by the kernel
+  // ... unless the caller has lent a DEVICE buffer for the exported results
+  // (kd_batch_set_output_buffer): the kernel writes there, and the pinned pool is a mirror
+  // that is filled only when somebody asks for host arrays
+  unsigned long long *out_ext = nullptr;
+  uint64_t out_ext_cap = 0, out_own_cap = 0;
+  bool mirror_valid = true;
+  std::vector<uint8_t> h_lat_arena;  // the export of utterance i is in arena order (general export)
+  bool canon_done = true;
   // ---- per utterance
   DevBuf<long long> frame_base, link_emit_base, link_eps_base;
   DevBuf<int32_t> frame_count, link_emit_count, link_eps_count, frame_state_off, frame_arc_off;
@@ -223,7 +232,7 @@ struct kd_batch {
     p.lat.finalized = lat_finalized.p;
     p.lat.frame_state_off = frame_state_off.p;
     p.lat.frame_arc_off = frame_arc_off.p;
-    p.lat.out = out_pool;
+    p.lat.out = out_ext ? out_ext : out_pool;
     p.lat.out_cap = out_cap;
     return p;
   }
@@ -306,6 +315,9 @@ int GrowLinks(kd_batch *b) {
 
 constexpr uint64_t kMaxOutWords = 1ull << 33;  // 64 GiB of pinned host memory
 int GrowOut(kd_batch *b) {
+  if (b->out_ext)
+    return Fail(KD_E_CAPACITY, "the output buffer lent with kd_batch_set_output_buffer is full (" +
+                               std::to_string(b->out_ext_cap) + " words): lend a larger one");
   if (b->out_cap >= kMaxOutWords)
     return Fail(KD_E_CAPACITY, "lattice output pool full at 2^33 words");
   const uint64_t cap = b->out_cap * 2;
@@ -316,6 +328,7 @@ int GrowOut(kd_batch *b) {
   (void)hipHostFree(b->out_pool);
   b->out_pool = np;
   b->out_cap = cap;
+  b->out_own_cap = cap;
   b->grow_events++;
   return KD_OK;
 }
@@ -449,6 +462,81 @@ std::string StatusMessage(const kd_batch *b, int i) {
   return m;
 }
 
+// An exported lattice that the kernel left in arena order (the general export: an
+// un-finalized lattice, or one that outgrew the sweep's lists): states inside a frame and
+// arcs come in an order that depends on wave scheduling.  Here -- in the pinned output pool,
+// which is host memory -- it is put into the order the staged export produces on the device:
+// states by (frame, graph state), arcs by (source state id, graph arc), finals by state id;
+// the arcs shrink from four words to three.  Same input, same arrays (ref: GetRawLattice,
+// lattice-simple-decoder.cc:584-657, is deterministic too).
+void CanonicalizeExport(unsigned long long *region, int32_t *sizes) {
+  const size_t ns = static_cast<size_t>(sizes[0]), na = static_cast<size_t>(sizes[1]), nf = static_cast<size_t>(sizes[2]);
+  if (ns == 0) return;
+  unsigned long long *o_state = region, *o_final = region + ns, *o_arc = o_final + nf;
+  std::vector<int32_t> order(ns), newid(ns);
+  for (size_t i = 0; i < ns; ++i) order[i] = static_cast<int32_t>(i);
+  // a state word is {frame, graph state}: one token per state and frame, so the key is unique
+  auto key = [&](int32_t i) {
+    const unsigned long long w = o_state[i];
+    return (w & 0xFFFFFFFFull) << 32 | w >> 32;
+  };
+  std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return key(x) < key(y); });
+  std::vector<unsigned long long> tmp(ns);
+  for (size_t k = 0; k < ns; ++k) { newid[order[k]] = static_cast<int32_t>(k); tmp[k] = o_state[order[k]]; }
+  std::copy(tmp.begin(), tmp.end(), o_state);
+  if (sizes[3] >= 0) sizes[3] = newid[sizes[3]];
+  for (size_t k = 0; k < nf; ++k) {
+    const uint32_t id = static_cast<uint32_t>(o_final[k]);
+    o_final[k] = (o_final[k] & 0xFFFFFFFF00000000ull) | static_cast<uint32_t>(newid[id]);
+  }
+  std::sort(o_final, o_final + nf, [](unsigned long long x, unsigned long long y) {
+    return static_cast<uint32_t>(x) < static_cast<uint32_t>(y);
+  });
+  struct Arc { unsigned long long ends, labels, costs; uint32_t arc; };
+  std::vector<Arc> arcs(na);
+  for (size_t k = 0; k < na; ++k) {
+    const unsigned long long *w = o_arc + 4 * k;
+    const uint32_t src = static_cast<uint32_t>(w[0]), dst = static_cast<uint32_t>(w[0] >> 32);
+    arcs[k] = Arc{static_cast<unsigned long long>(static_cast<uint32_t>(newid[dst])) << 32 |
+                      static_cast<uint32_t>(newid[src]),
+                  w[1], w[2], static_cast<uint32_t>(w[3])};
+  }
+  std::sort(arcs.begin(), arcs.end(), [](const Arc &x, const Arc &y) {
+    const uint32_t sx = static_cast<uint32_t>(x.ends), sy = static_cast<uint32_t>(y.ends);
+    return sx != sy ? sx < sy : x.arc < y.arc;
+  });
+  for (size_t k = 0; k < na; ++k) {
+    o_arc[3 * k] = arcs[k].ends;
+    o_arc[3 * k + 1] = arcs[k].labels;
+    o_arc[3 * k + 2] = arcs[k].costs;
+  }
+}
+
+// The exported results where the HOST can read them: the pinned pool itself, or -- with a
+// lent device buffer -- its mirror, filled here (one copy of the used prefix); then the
+// arena-ordered exports are put in order, once.
+int HostResults(kd_batch *b) {
+  if (!b->mirror_valid) {
+    const uint64_t used = b->h_out_top;
+    if (used > b->out_own_cap) {
+      unsigned long long *np = nullptr;
+      if (hipHostMalloc(reinterpret_cast<void **>(&np), used * 8, hipHostMallocDefault) != hipSuccess)
+        return Fail(KD_E_CAPACITY, "cannot allocate the host mirror of the output buffer");
+      (void)hipHostFree(b->out_pool);
+      b->out_pool = np;
+      b->out_own_cap = used;
+    }
+    if (used) KD_HIP_TRY(hipMemcpy(b->out_pool, b->out_ext, used * 8, hipMemcpyDeviceToHost));
+    b->mirror_valid = true;
+  }
+  if (!b->canon_done) {
+    for (int i = 0; i < b->batch; ++i)
+      if (b->h_lat_arena[i]) CanonicalizeExport(b->out_pool + b->h_lat_off[i], &b->h_lat_sizes[4 * i]);
+    b->canon_done = true;
+  }
+  return KD_OK;
+}
+
 // Waits for the launch in flight and takes its results; grows whatever a stopped
 // utterance ran out of and launches again until every utterance is where it was sent.
 int ReadBack(kd_batch *b) {
@@ -479,7 +567,10 @@ int ReadBack(kd_batch *b) {
         for (int i = 0; i < b->batch; ++i) {
           for (int k = 0; k < 4; ++k) b->h_lat_sizes[4 * i + k] = uo[i].sizes[k];
           b->h_lat_off[i] = uo[i].out_off;
+          b->h_lat_arena[i] = (uo[i].phase & kPhaseArenaOrder) && uo[i].out_off >= 0;
         }
+        b->canon_done = false;
+        b->mirror_valid = b->out_ext == nullptr;
         b->exported_use_final = (b->l_tail_flags & kUttExport) ? 1 : 0;
       }
     }
@@ -494,6 +585,7 @@ int ReadBack(kd_batch *b) {
       }
       b->path_valid = true;
       b->path_use_final = (b->l_tail_flags & kUttPathNoFinal) ? 0 : 1;
+      b->mirror_valid = b->out_ext == nullptr;
     }
     if (!any) return KD_OK;
     if (b->o.no_grow || (any & ~kRecoverable)) return Fail(KD_E_CAPACITY, StatusMessage(b, first_bad));
@@ -733,7 +825,9 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   // output pool (pinned): exported lattices, or best paths (three words an arc)
   b->out_cap = std::max<uint64_t>(1ull << 16, static_cast<uint64_t>(max_batch) << (lopts ? 13 : 11));
   A(hipHostMalloc(reinterpret_cast<void **>(&b->out_pool), b->out_cap * 8, hipHostMallocDefault));
+  b->out_own_cap = b->out_cap;
   b->h_lat_off.assign(max_batch, -1);
+  b->h_lat_arena.assign(max_batch, 0);
   if (e == hipSuccess) e = hipEventCreate(&b->ev0);
   if (e == hipSuccess) e = hipEventCreate(&b->ev1);
   if (e == hipSuccess && lopts) {
@@ -767,6 +861,26 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   if (e != hipSuccess) {
     delete b;
     return Fail(KD_E_HIP, std::string("batch allocation: ") + hipGetErrorString(e));
+  }
+  if (std::getenv("KD_DEBUG_ALLOC")) {  // (diagnostic: which array does a faulting address belong to?)
+    auto D = [&](const char *name, const void *p, size_t bytes) {
+      std::fprintf(stderr, "KD_ALLOC %-16s %p .. %p (%zu B)\n", name, p,
+                   static_cast<const void *>(static_cast<const char *>(p) + bytes), bytes);
+    };
+#define KD_D(x) D(#x, b->x.p, b->x.bytes())
+    KD_D(tok_state); KD_D(tok_prev); KD_D(tok_arc); KD_D(tok_cost); KD_D(tok_extra); KD_D(tok_newid);
+    KD_D(lat_scratch); KD_D(link_src); KD_D(link_dst); KD_D(link_arc); KD_D(link_ac); KD_D(link_graph);
+    KD_D(link_delta); KD_D(frame_base); KD_D(link_emit_base); KD_D(link_eps_base); KD_D(frame_count);
+    KD_D(link_emit_count); KD_D(link_eps_count); KD_D(frame_state_off); KD_D(frame_arc_off);
+    KD_D(frames_decoded); KD_D(status); KD_D(mem); KD_D(stats); KD_D(lat_fbc); KD_D(lat_frel);
+    KD_D(lat_any_final); KD_D(lat_finalized); KD_D(g_key); KD_D(g_arc); KD_D(g_used); KD_D(g_wl);
+    KD_D(g_log_h); KD_D(g_log_arc); KD_D(g_log_src); KD_D(g_cost); KD_D(g_log_nk); KD_D(g_log_ac);
+    KD_D(g_log_gr); KD_D(bctl);
+#undef KD_D
+    D("out_pool", b->out_pool, b->out_cap * 8);
+    D("ctl_host", b->ctl_host, b->ctl_bytes);
+    D("graph.states", g->states.p, g->states.bytes());
+    D("graph.arcs", g->arcs.p, g->arcs.bytes());
   }
   b->h_decoded.assign(max_batch, -1);
   b->h_status.assign(max_batch, 0);
@@ -948,6 +1062,30 @@ int kd_batch_decode_async(kd_batch *b, int32_t batch, const float *const *loglik
   return Enqueue(b);
 }
 
+int kd_batch_decode_host_async(kd_batch *b, int32_t batch, const float *const *loglikes,
+                               const int32_t *num_rows, const int32_t *offset, int32_t num_cols,
+                               int64_t row_stride, int32_t want) {
+  if (!b || !loglikes || !num_rows || num_cols <= 0) return Fail(KD_E_INVALID, "bad argument");
+  if (batch <= 0 || batch > b->max_batch) return Fail(KD_E_INVALID, "bad batch size");
+  if (row_stride < num_cols) return Fail(KD_E_INVALID, "row_stride < num_cols");
+  KD_HIP_TRY(hipSetDevice(b->g->device));
+  if (b->pending) (void)ReadBack(b);  // (the staging block is this batch's: its last launch is over)
+  ResetForInit(b, batch);
+  if (int r = PlanAdvance(b, num_rows, offset, -1, true)) return r;
+  // the rows go to the device on the batch's stream, ahead of the launch: while they are
+  // copied (the call returns when the last row has left the caller's memory) the launches
+  // of OTHER batches keep the CUs busy
+  if (int r = StageHost(b, loglikes, num_cols, row_stride, nullptr)) return r;
+  const uint32_t tail = TailFlags(b, want);
+  UttCtl *uc = b->h_ctl();
+  for (int i = 0; i < batch; ++i) uc[i].flags |= tail;
+  b->l_num_cols = num_cols;
+  b->l_row_stride = num_cols;
+  b->l_tail_flags = tail;
+  b->initialized = true;
+  return Enqueue(b);
+}
+
 int kd_batch_decode(kd_batch *b, int32_t batch, const float *const *loglikes, const int32_t *num_rows,
                     const int32_t *offset, int32_t num_cols, int64_t row_stride, int mem_kind,
                     int32_t want) {
@@ -957,22 +1095,8 @@ int kd_batch_decode(kd_batch *b, int32_t batch, const float *const *loglikes, co
     return ReadBack(b);
   }
   if (mem_kind != KD_MEM_HOST) return Fail(KD_E_INVALID, "bad mem_kind");
-  if (!b || !loglikes || !num_rows || num_cols <= 0) return Fail(KD_E_INVALID, "bad argument");
-  if (batch <= 0 || batch > b->max_batch) return Fail(KD_E_INVALID, "bad batch size");
-  if (row_stride < num_cols) return Fail(KD_E_INVALID, "row_stride < num_cols");
-  KD_HIP_TRY(hipSetDevice(b->g->device));
-  if (b->pending) (void)ReadBack(b);
-  ResetForInit(b, batch);
-  if (int r = PlanAdvance(b, num_rows, offset, -1, true)) return r;
-  if (int r = StageHost(b, loglikes, num_cols, row_stride, nullptr)) return r;
-  const uint32_t tail = TailFlags(b, want);
-  UttCtl *uc = b->h_ctl();
-  for (int i = 0; i < batch; ++i) uc[i].flags |= tail;
-  b->l_num_cols = num_cols;
-  b->l_row_stride = num_cols;
-  b->l_tail_flags = tail;
-  b->initialized = true;
-  if (int r = Enqueue(b)) return r;
+  if (int r = kd_batch_decode_host_async(b, batch, loglikes, num_rows, offset, num_cols, row_stride, want))
+    return r;
   return ReadBack(b);
 }
 
@@ -1094,6 +1218,7 @@ int kd_batch_best_path_copy(kd_batch *b, const int64_t *path_offset, int32_t *il
                             float *final_weight) {
   if (!b || !path_offset) return Fail(KD_E_INVALID, "bad argument");
   if (!b->path_valid || b->pending) return Fail(KD_E_STATE, "call kd_batch_best_path_prepare first");
+  if (int r = HostResults(b)) return r;
   if (final_weight)
     std::memcpy(final_weight, b->h_final_weight.data(), 2 * b->batch * sizeof(float));
   // an utterance's region of the (pinned) output pool: {ilabel, olabel} {state, graph} {ac, -}
@@ -1188,6 +1313,7 @@ int kd_batch_raw_lattice_prepare(kd_batch *b, int32_t use_final_probs, int32_t *
     b->h_out_top = 0;
     if (int r = LaunchTail(b, use_final_probs ? kUttExport : kUttExportNoFinal)) return r;
   }
+  if (int r = HostResults(b)) return r;  // (ordering an arena-order export moves its start state)
   std::memcpy(sizes, b->h_lat_sizes.data(), 4 * b->batch * sizeof(int32_t));
   return KD_OK;
 }
@@ -1201,6 +1327,7 @@ int kd_batch_raw_lattice_copy(kd_batch *b, const int64_t *state_off, const int64
   if (!b->lattice || b->exported_use_final < 0 || b->pending)
     return Fail(KD_E_STATE, "call kd_batch_raw_lattice_prepare first");
   KD_HIP_TRY(hipSetDevice(b->g->device));
+  if (int r = HostResults(b)) return r;
   // an utterance's region: states {frame, graph state} | finals {state, weight} |
   // arcs {src, dst, ilabel, olabel, graph, ac}
   for (int i = 0; i < b->batch; ++i) {
@@ -1231,6 +1358,43 @@ int kd_batch_raw_lattice_copy(kd_batch *b, const int64_t *state_off, const int64
   return KD_OK;
 }
 
+int kd_batch_set_output_buffer(kd_batch *b, void *device_words, int64_t cap_words) {
+  if (!b) return Fail(KD_E_INVALID, "bad argument");
+  if (device_words && cap_words <= 0) return Fail(KD_E_INVALID, "bad capacity");
+  KD_HIP_TRY(hipSetDevice(b->g->device));
+  if (b->pending)
+    if (int r = ReadBack(b)) return r;
+  b->out_ext = static_cast<unsigned long long *>(device_words);
+  b->out_ext_cap = device_words ? static_cast<uint64_t>(cap_words) : 0;
+  b->out_cap = device_words ? b->out_ext_cap : b->out_own_cap;
+  // whatever was exported lies in the other pool: nothing is exported any more
+  b->exported_use_final = -1;
+  b->path_valid = false;
+  b->mirror_valid = true;
+  b->canon_done = true;
+  return KD_OK;
+}
+
+int kd_batch_raw_lattice_table(kd_batch *b, int64_t *used_words, int64_t *table) {
+  if (!b || !used_words || !table) return Fail(KD_E_INVALID, "bad argument");
+  if (!b->lattice) return Fail(KD_E_STATE, "not a lattice batch");
+  KD_HIP_TRY(hipSetDevice(b->g->device));
+  if (b->pending)
+    if (int r = ReadBack(b)) return r;
+  if (b->exported_use_final < 0)
+    return Fail(KD_E_STATE, "nothing exported: decode with KD_DECODE_LATTICE or call kd_batch_raw_lattice_prepare");
+  for (int i = 0; i < b->batch; ++i)
+    if (b->h_lat_arena[i] && !b->canon_done)
+      return Fail(KD_E_STATE, "utterance " + std::to_string(i) + "'s export is in arena order (an "
+                              "un-finalized lattice): take it through kd_batch_raw_lattice_copy");
+  *used_words = static_cast<int64_t>(b->h_out_top);
+  for (int i = 0; i < b->batch; ++i) {
+    table[5 * i] = b->h_lat_off[i];
+    for (int k = 0; k < 4; ++k) table[5 * i + 1 + k] = b->h_lat_sizes[4 * i + k];
+  }
+  return KD_OK;
+}
+
 int kd_batch_stats(kd_batch *b, int64_t *out) {
   if (!b || !out) return Fail(KD_E_INVALID, "bad argument");
   KD_HIP_TRY(hipSetDevice(b->g->device));
@@ -1246,12 +1410,11 @@ int kd_batch_stats(kd_batch *b, int64_t *out) {
 
 int kd_batch_phase_cycles(kd_batch *b, int64_t *out) {
   if (!b || !out) return Fail(KD_E_INVALID, "bad argument");
-#ifndef KD_PROFILE
+#if !defined(KD_PROFILE) && !defined(KD_DEBUG_WAVE)
   return Fail(KD_E_STATE, "kd_batch_phase_cycles: not a diagnostic (KD_PROFILE) build");
 #else
   KD_HIP_TRY(hipSetDevice(b->g->device));
-  if (b->pending)
-    if (int r = ReadBack(b)) return r;
+  if (b->pending) (void)ReadBack(b);  // (a diagnostic read-out: also of a launch that failed)
   std::vector<long long> h(static_cast<size_t>(b->batch) * kStatStride);
   KD_HIP_TRY(hipMemcpy(h.data(), b->stats.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
   for (int i = 0; i < b->batch; ++i)

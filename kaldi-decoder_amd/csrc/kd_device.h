@@ -87,6 +87,9 @@ struct UttOut {
   int32_t phase;          // kPhase* below
 };
 constexpr int32_t kPhaseDecoding = 0, kPhaseFinalized = 1;
+// ... ORed with: the exported lattice is in arena order, four words an arc (the fourth names
+// the graph arc): the host puts it into the canonical order (kd_api.hip, CanonicalizeExport)
+constexpr int32_t kPhaseArenaOrder = 2;
 
 // Per-utterance allocation state, device resident.  Frames take contiguous blocks from
 // the chunk of each pool the utterance is filling (its "nursery"); a block that does not

@@ -89,6 +89,7 @@ struct TailShared {
   int32_t r_sizes[4];
   long long r_out_off;
   float r_final_rel;
+  int32_t r_arena_order;  // the export is the general one's (arena order, four words an arc)
 };
 static_assert(sizeof(TailShared) <= offsetof(Shared, ll),
               "the tail reuses the search's LDS block, below what a periodic sweep must leave alone");
@@ -271,6 +272,16 @@ __device__ __forceinline__ int SweepWindow(CParams &p, TailShared &s, const Stag
   const int tid = threadIdx.x, lane = tid & 63;
   const float lattice_beam = p.lat.lattice_beam;
   WinShared &w = s.win;
+  // (The previous window's descriptors are read once more AFTER it returned -- LatticePrune's
+  // from_window() takes the next frames' descriptors from them -- by every wave for itself.
+  // Without this barrier the first wave could be back here, overwriting them, while a wave
+  // that lagged a few thousand cycles was still reading: that wave then saw another frame's
+  // sizes, took another branch than the rest of the workgroup and met them at the wrong
+  // barrier -- a launch that never ends, or indices into nowhere.  Rare (the builder's own
+  // global loads come first), and sensitive to anything that shifts the waves' timing: the
+  // stall / memory fault of round 2's hlg-large runs with another register allocation, and
+  // one bench run in six of round 3 after an unrelated edit of this function.)
+  LdsBarrier();
   if (tid < 64) {  // the descriptors of frames f, f - 1, ...; how many fit
     const int k = f - lane;
     const bool in = lane < kWinMax && k >= 0;
@@ -389,10 +400,47 @@ __device__ __forceinline__ int SweepWindow(CParams &p, TailShared &s, const Stag
     LdsBarrier();
     if (!w.flag[round % 3]) break;
   }
-  // every key is final: the links that stay above the beam go (:264)
+  // Every key is final.  PERIODIC sweeps: how far down does the reference go?  Frame g that
+  // an earlier sweep has visited (g <= visited) is swept again only if an extra cost of
+  // frame g + 1 moved by more than delta in THIS sweep (must_prune_forward_links,
+  // lattice-simple-decoder.cc:208-216, :286-290; a frame never swept before started from
+  // the zeros the search wrote).  The window was relaxed as a whole, which is right for
+  // its frames down to the first one that rule excludes -- values only travel downwards --
+  // so that frame and the ones below it are left exactly as they were: `cut` frames count.
+  int cut = W;
+  if (periodic && f - (W - 1) <= visited + 1) {
+    for (int g0 = tid; g0 < NT; g0 += 4 * kBlock) {
+      int j[4];
+      float was[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int g = g0 + u * kBlock < NT ? g0 + u * kBlock : g0;
+        int lo = 0, hi = W;  // tok_off[lo] <= g < tok_off[hi]
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (w.tok_off[mid] <= g) lo = mid; else hi = mid;
+        }
+        j[u] = lo;
+        // (only the frames whose verdict decides about a visited frame below them)
+        was[u] = f - lo <= visited + 1 ? ToG(p.tok_extra)[w.base[lo] + (g - w.tok_off[lo])] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int g = g0 + u * kBlock;
+        if (g < NT && f - j[u] <= visited + 1 && Moved(was[u], KeyFloat(B[g]), delta)) w.fchanged[j[u]] = 1;
+      }
+    }
+    LdsBarrier();  // the frames' flags are complete
+    const bool excluded = lane >= 1 && lane < W && f - lane <= visited && !w.fchanged[lane - 1];
+    const unsigned long long ex = __ballot(excluded);  // (the same answer in every wave)
+    if (ex) cut = __builtin_ctzll(ex);
+  }
+  // the links that stay above the beam go (:264)
 #pragma unroll
   for (int r = 0; r < kWinRegs; ++r) {
-    if (meta[r] == kDead || (meta[r] & kDoneBit)) continue;
+    if (meta[r] == kDead) continue;
+    if (((meta[r] >> kSrcBits) & 0xFF) >= cut) { meta[r] = kDead; continue; }  // (frame not swept)
+    if (meta[r] & kDoneBit) continue;
     const float link_extra_cost = KeyFloat(B[dst[r]]) + dl[r];
     if (!(link_extra_cost <= lattice_beam)) {
       ToG(p.link_dst)[at[r]] = -1;
@@ -401,16 +449,13 @@ __device__ __forceinline__ int SweepWindow(CParams &p, TailShared &s, const Stag
   }
   // the tokens' extras go to the pool (a token without a surviving link: +inf, which is
   // how PruneTokensForFrame's verdict is recorded here)
-  // (frames above `visited` are swept whatever they hold: a window of such frames does
-  // not look at the old extras)
-  const bool need_was = periodic && f - (W - 1) <= visited;
-  for (int g0 = tid; g0 < NT; g0 += 4 * kBlock) {
+  const int NTc = w.tok_off[cut];
+  for (int g0 = tid; g0 < NTc; g0 += 4 * kBlock) {
     int j[4];
     long long gi[4];
-    float was[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int g = g0 + u * kBlock < NT ? g0 + u * kBlock : g0;
+      const int g = g0 + u * kBlock < NTc ? g0 + u * kBlock : g0;
       int lo = 0, hi = W;  // tok_off[lo] <= g < tok_off[hi]
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -418,14 +463,12 @@ __device__ __forceinline__ int SweepWindow(CParams &p, TailShared &s, const Stag
       }
       j[u] = lo;
       gi[u] = w.base[lo] + (g - w.tok_off[lo]);
-      was[u] = need_was ? ToG(p.tok_extra)[gi[u]] : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int g = g0 + u * kBlock;
-      if (g >= NT) continue;
+      if (g >= NTc) continue;
       const float ex = KeyFloat(B[g]);
-      if (periodic && f - j[u] <= visited && Moved(was[u], ex, delta)) w.fchanged[j[u]] = 1;
       ToG(p.tok_extra)[gi[u]] = ex;
       if (st.on && ex != FInf()) StageTok(s, st, gi[u], f - j[u]);
     }
@@ -436,18 +479,15 @@ __device__ __forceinline__ int SweepWindow(CParams &p, TailShared &s, const Stag
       if (meta[r] != kDead) StageArc(s, st, at[r], f - ((meta[r] >> kSrcBits) & 0xFF), (meta[r] & kEmitBit) ? 1 : 0);
     if (tid < W && w.n[tid] == 0) s.empty_frame = 1;
   }
-  next_b = B + w.tok_off[W - 1];
-  next_base = w.base[W - 1];
-  stop = false;
-  if (periodic) {
-    LdsBarrier();  // the frames' flags are complete
-    const bool quiet = lane < W && f - lane <= visited && !w.fchanged[lane];
-    stop = __ballot(quiet) != 0ull;  // (the same answer in every wave)
-  }
+  next_b = B + w.tok_off[cut - 1];
+  next_base = w.base[cut - 1];
+  // the sweep ends here if a frame of the window was excluded, or if the frame below the
+  // window is one that the rule excludes
+  stop = periodic && (cut < W || (f - W <= visited && !w.fchanged[W - 1]));
   // (the next window's builder, or a frame that reads these extras from global memory,
   // starts with a full barrier of its own, after which w and B's other half are reused)
   LdsBarrier();
-  return W;
+  return cut;
 }
 
 // FinalizeDecoding: the exact backward sweep over all frames -- and, with `periodic`,
@@ -728,7 +768,9 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
       LdsBarrier();
       prof(1);
       if (periodic) {
-        const bool stop = f <= visited && !s.frame_changed;
+        // (frame f - 1, visited by an earlier sweep, is swept again only if an extra cost
+        // of frame f moved by more than delta: lattice-simple-decoder.cc:208-216)
+        const bool stop = f - 1 <= visited && !s.frame_changed;
         LdsBarrier();  // (everybody has read the flag before the next frame clears it)
         if (stop) break;
       }
@@ -791,7 +833,7 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
       if (!changed || pn == 0) break;
     }
     if (periodic) {
-      const bool stop = f <= visited && !s.frame_changed;
+      const bool stop = f - 1 <= visited && !s.frame_changed;
       __syncthreads();
       if (stop) break;
     }
@@ -812,10 +854,15 @@ __device__ __forceinline__ int LatticePrune(CParams &p, TailShared &s, int utt, 
 }
 
 // GetRawLattice from the lists FinalizeDecoding left (Stage).  States are numbered
-// frame-major like the reference's (:623-640 walks the frames in order): the lists come
-// in whatever order the sweep's windows and waves produced them, so a token's id is its
-// frame's offset (a prefix sum over per-frame counts) plus its rank inside the frame (an
-// atomic counter per frame) -- a counting sort over a thousand entries, once per utterance.
+// frame-major like the reference's (:623-640 walks the frames in order) and, inside a frame,
+// by graph state; arcs are ordered by (source state id, graph arc): the SAME arrays whatever
+// order the sweep's windows and waves listed the survivors in (the reference's own order --
+// token-list and link-list order, :584-657 -- is a property of its containers; what a caller
+// can rely on there, and here, is that the same input gives the same arrays).  Two counting
+// sorts over a thousand entries, once per utterance: tokens by frame (an atomic counter per
+// frame, a prefix sum over the frames), then by state inside the frame (a token's rank is
+// the number of its frame's tokens with a lower state: frames of the pruned lattice hold a
+// handful); arcs by source id, then by graph arc inside the source's handful.
 __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &s, int utt, int F,
                                                         bool any_final, const Stage &st) {
   const int tid = threadIdx.x;
@@ -823,35 +870,52 @@ __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &
   if (s.empty_frame || ns == 0) return 0;  // GetRawLattice returns false (:615-619)
   const long long fb = static_cast<long long>(utt) * (p.max_frames + 1);
   KD_G int32_t *soff = ToG(p.lat.frame_state_off) + fb;
+  // scratch: three more of the workgroup's idle queue arrays (2 * table slots words each)
+  const long long gslots = 1ll << p.g_log2_slots, wg = blockIdx.x;
+  KD_G uint32_t *sc_a = reinterpret_cast<KD_G uint32_t *>(ToG(p.g_log_ac) + wg * 2 * gslots);
+  KD_G uint32_t *sc_b = reinterpret_cast<KD_G uint32_t *>(ToG(p.g_log_gr) + wg * 2 * gslots);
+  KD_G uint32_t *sc_c = ToG(p.g_wl) + wg * 2 * gslots;
   if (tid == 0) { s.n_finals = 0; s.start_id = -1; }
   for (int k = tid; k <= F; k += kBlock) soff[k] = 0;
   __syncthreads();
-  // ranks inside the frames; the final states among the last frame's tokens (:645-652)
+  // tokens per frame (and a provisional place inside the frame)
   for (int j = tid; j < ns; j += kBlock) {
-    const uint32_t g = st.tok_g[j];
     const int f = static_cast<int>(st.tok_f[j]);
-    ToG(p.lat.tok_newid)[g] = atomicAdd(ToFlat(&soff[f]), 1);
-    if (f == F) {
-      const float fc = ToG(p.states)[ToG(p.tok_state)[g]].final_cost;
-      if (!any_final || fc != FInf()) atomicAdd(&s.n_finals, 1);
-    }
+    sc_c[j] = static_cast<uint32_t>(atomicAdd(ToFlat(&soff[f]), 1));
   }
   __syncthreads();
   int carry = 0;
   for (int k0 = 0; k0 <= F; k0 += kBlock) {  // counts -> offsets
     const int k = k0 + tid;
-    const int v = k <= F ? soff[k] : 0;
+    // (the counters were bumped by L2 atomics, which do not refresh this CU's L1: an
+    // agent-scope load reads what L2 holds)
+    const int v = k <= F ? __hip_atomic_load(ToFlat(&soff[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     int total;
     const int before = BlockExclScanI(s, v, total);
     if (k <= F) soff[k] = carry + before;
     carry += total;
   }
   __syncthreads();
+  // the frames' segments: graph state (bit 31: a final state of the last frame) and token
+  for (int j = tid; j < ns; j += kBlock) {
+    const uint32_t g = st.tok_g[j];
+    const int f = static_cast<int>(st.tok_f[j]);
+    const int32_t state = ToG(p.tok_state)[g];
+    bool fin = false;
+    if (f == F) {  // :645-652
+      const float fc = ToG(p.states)[state].final_cost;
+      fin = !any_final || fc != FInf();
+      if (fin) atomicAdd(&s.n_finals, 1);
+    }
+    const int at = soff[f] + static_cast<int>(sc_c[j]);
+    sc_a[at] = static_cast<uint32_t>(state) | (fin ? 0x80000000u : 0u);
+    sc_b[at] = g;
+  }
+  __syncthreads();
   const int nf = s.n_finals;
   if (tid == 0) {
     const unsigned long long words = static_cast<unsigned long long>(ns) + nf + 3ull * na;
     s.out_off = PoolTake(&p.ctl->out_top, p.out_base, p.lat.out_cap, words);
-    s.count = 0;  // (finals written so far)
   }
   __syncthreads();
   const long long off = s.out_off;
@@ -859,30 +923,66 @@ __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &
   KD_G unsigned long long *o_state = ToG(p.lat.out) + off, *o_final = o_state + ns,
                           *o_arc = o_final + nf;
   auto pack = [](uint32_t lo, uint32_t hi) { return static_cast<unsigned long long>(hi) << 32 | lo; };
+  // a token's id: its frame's offset + the number of the frame's tokens with a lower state
+  // (one token per state and frame); the finals likewise, among the last frame's finals
   for (int j = tid; j < ns; j += kBlock) {
-    const uint32_t g = st.tok_g[j];
     const int f = static_cast<int>(st.tok_f[j]);
-    const int id = soff[f] + ToG(p.lat.tok_newid)[g];
-    const int32_t state = ToG(p.tok_state)[g];
-    ToG(p.lat.tok_newid)[g] = id;
-    o_state[id] = pack(static_cast<uint32_t>(f), static_cast<uint32_t>(state));
-    if (f == 0 && state == p.start) s.start_id = id;  // :623-629
-    if (f == F) {
+    const int at = soff[f] + static_cast<int>(sc_c[j]);
+    const int lo = soff[f], hi = f < F ? soff[f + 1] : ns;
+    const uint32_t mine = sc_a[at], state = mine & 0x7FFFFFFFu;
+    int rank = 0, frank = 0;
+    for (int k = lo; k < hi; ++k) {
+      const uint32_t o = sc_a[k];
+      const bool lower = (o & 0x7FFFFFFFu) < state;
+      rank += lower;
+      frank += lower && (o >> 31);
+    }
+    const int id = lo + rank;
+    ToG(p.lat.tok_newid)[sc_b[at]] = id;
+    o_state[id] = pack(static_cast<uint32_t>(f), state);
+    if (f == 0 && static_cast<int32_t>(state) == p.start) s.start_id = id;  // :623-629
+    if (mine >> 31) {
       const float fc = ToG(p.states)[state].final_cost;
-      if (!any_final || fc != FInf()) {
-        const int k = AggInc(&s.count);
-        o_final[k] = pack(static_cast<uint32_t>(id), __float_as_uint(any_final ? fc : 0.0f));
-      }
+      o_final[frank] = pack(static_cast<uint32_t>(id), __float_as_uint(any_final ? fc : 0.0f));
     }
   }
   __syncthreads();  // every listed token's id is in place
+  // arcs per source state (the prefix sum reuses sc_a as counters: ns + 1 words)
+  for (int k = tid; k <= ns; k += kBlock) sc_a[k] = 0;
+  __syncthreads();
+  for (int j = tid; j < na; j += kBlock) {
+    const int sid = ToG(p.lat.tok_newid)[ToG(p.link_src)[st.arc_at[j]]];
+    sc_c[j] = atomicAdd(ToFlat(&sc_a[sid]), 1u);  // provisional place inside the source's arcs
+  }
+  __syncthreads();
+  carry = 0;
+  for (int k0 = 0; k0 <= ns; k0 += kBlock) {
+    const int k = k0 + tid;
+    const int v = k <= ns ? static_cast<int>(__hip_atomic_load(ToFlat(&sc_a[k]), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT)) : 0;
+    int total;
+    const int before = BlockExclScanI(s, v, total);
+    if (k <= ns) sc_a[k] = static_cast<uint32_t>(carry + before);
+    carry += total;
+  }
+  __syncthreads();
+  for (int j = tid; j < na; j += kBlock) {  // the sources' segments: the links' graph arcs
+    const long long at = st.arc_at[j];
+    const int sid = ToG(p.lat.tok_newid)[ToG(p.link_src)[at]];
+    sc_b[sc_a[sid] + sc_c[j]] = static_cast<uint32_t>(ToG(p.link_arc)[at]);
+  }
+  __syncthreads();
   for (int j = tid; j < na; j += kBlock) {
     const long long at = st.arc_at[j];
     const int32_t src = ToG(p.link_src)[at], dst = ToG(p.link_dst)[at], arc = ToG(p.link_arc)[at];
     const float gr = ToG(p.link_graph)[at], ac = ToG(p.link_ac)[at];
+    const int sid = ToG(p.lat.tok_newid)[src];
+    const int lo = static_cast<int>(sc_a[sid]), hi = static_cast<int>(sc_a[sid + 1]);
+    int rank = 0;  // (a token has one link per graph arc: the arc orders its links)
+    for (int k = lo; k < hi; ++k) rank += sc_b[k] < static_cast<uint32_t>(arc);
     const ArcRec ar = LoadArcRec(p.arcs, static_cast<uint32_t>(arc));
-    KD_G unsigned long long *w = o_arc + 3ll * j;
-    w[0] = pack(static_cast<uint32_t>(ToG(p.lat.tok_newid)[src]), static_cast<uint32_t>(ToG(p.lat.tok_newid)[dst]));
+    KD_G unsigned long long *w = o_arc + 3ll * (lo + rank);
+    w[0] = pack(static_cast<uint32_t>(sid), static_cast<uint32_t>(ToG(p.lat.tok_newid)[dst]));
     w[1] = pack(static_cast<uint32_t>(ar.ilabel), static_cast<uint32_t>(ar.olabel));
     w[2] = pack(__float_as_uint(gr), __float_as_uint(ac));
   }
@@ -914,8 +1014,9 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
   __syncthreads();
   // (a token without surviving forward links has extra_cost +inf: FinalizeDecoding's or a
   // periodic sweep's doing -- the reference deletes it, :310-334; the search writes 0)
-  (void)finalized;
-  auto alive = [&](long long g) { return ToG(p.tok_extra)[g] != FInf(); };
+  // (PruneActiveTokens never calls PruneTokensForFrame(0) -- :216-219 prunes frame f + 1 --
+  // so until FinalizeDecoding the reference still lists frame 0's link-less tokens)
+  auto alive = [&](long long g, int f = 1) { return (f == 0 && !finalized) || ToG(p.tok_extra)[g] != FInf(); };
   constexpr int kT = 4;
   // pass 1: live tokens and surviving links of every frame
   for (int f = wave; f <= F; f += kWaves) {
@@ -927,7 +1028,7 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
 #pragma unroll
       for (int u = 0; u < kT; ++u) {
         const int i = c0 + u * 64 + lane;
-        a[u] = i < n && alive(base + i);
+        a[u] = i < n && alive(base + i, f);
       }
 #pragma unroll
       for (int u = 0; u < kT; ++u) cnt += __popcll(__ballot(a[u]));
@@ -985,7 +1086,7 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
   const int nf = s.n_finals;
   // the utterance's region of the output pool: states | finals | arcs, in 8-byte words
   if (tid == 0) {
-    const unsigned long long words = static_cast<unsigned long long>(ns) + nf + 3ull * na;
+    const unsigned long long words = static_cast<unsigned long long>(ns) + nf + 4ull * na;
     s.out_off = PoolTake(&p.ctl->out_top, p.out_base, p.lat.out_cap, words);
   }
   __syncthreads();
@@ -1001,7 +1102,7 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
     int before = soff[f], fin_before = 0;
     for (int c0 = 0; c0 < n; c0 += 64) {
       const int i = c0 + lane;
-      const bool a = i < n && alive(base + i);
+      const bool a = i < n && alive(base + i, f);
       const int32_t st = i < n ? ToG(p.tok_state)[base + i] : 0;
       const unsigned long long m = __ballot(a);
       const int id = before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
@@ -1049,7 +1150,8 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0));
             const int32_t arc = ToG(p.link_arc)[at];
             const ArcRec ar = LoadArcRec(p.arcs, static_cast<uint32_t>(arc));
-            KD_G unsigned long long *w = o_arc + 3ll * k;
+            KD_G unsigned long long *w = o_arc + 4ll * k;
+            w[3] = pack(static_cast<uint32_t>(arc), 0u);  // (what the host orders a source's arcs by)
             w[0] = pack(static_cast<uint32_t>(ToG(p.lat.tok_newid)[ToG(p.link_src)[at]]),
                         static_cast<uint32_t>(ToG(p.lat.tok_newid)[dst[u]]));
             w[1] = pack(static_cast<uint32_t>(ar.ilabel), static_cast<uint32_t>(ar.olabel));
@@ -1067,6 +1169,7 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
     s.r_sizes[2] = nf;
     s.r_sizes[3] = s.start_id;
     s.r_out_off = off;
+    s.r_arena_order = 1;
   }
   return 0;
 }
@@ -1422,6 +1525,7 @@ __device__ __noinline__ uint32_t LatticeTail(CParams *pp, int utt, int F, uint32
   if (threadIdx.x == 0) {
     s.r_sizes[0] = 0; s.r_sizes[1] = 0; s.r_sizes[2] = 0; s.r_sizes[3] = -1;
     s.r_out_off = -1;
+    s.r_arena_order = 0;
   }
 #ifdef KD_PROFILE
   // diagnostic build: cycles of the tail's three parts, buckets 20-22 of the utterance
@@ -1460,7 +1564,8 @@ __device__ __noinline__ uint32_t LatticeTail(CParams *pp, int utt, int F, uint32
     LatticePrune(p, s, utt, F, final_best_cost, any_final, st);
     if (threadIdx.x == 0) ToG(p.lat.finalized)[utt] = 1;
     finalized = true;
-    staged = st.on && !s.stage_overflow;
+    // (the export's scratch arrays are as long as the lists, and one of them holds ns + 1 words)
+    staged = st.on && !s.stage_overflow && s.n_tok_staged < st.cap;
     tail_lap(21);
   }
   uint32_t r = 0;

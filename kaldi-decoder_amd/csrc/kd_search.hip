@@ -56,6 +56,18 @@
 namespace kd {
 namespace {
 
+// The wave tier (kd_wave_tier.h: a frame of at most 64 tokens run by ONE wave, without
+// workgroup barriers) is an experiment of round 3 that is NOT in the shipped build.  With the
+// first wave running such frames alone the bench lost 6 % (31.5 M against 33.7 M audio
+// frames/s): one wave's frame is as long a chain of dependent memory and LDS round trips
+// (~40 k cycles) as the workgroup's.  With one utterance per wave, twelve per workgroup
+// (tools/experiments/wave_slots_stage2.patch), a launch of 768 utterances took 35 ms against
+// 30 ms: everything beyond the wave tier -- larger frames, PruneActiveTokens, the tails: 9 of
+// the 16 M cycles of an utterance -- still needs the whole workgroup and serialises the slots.
+// DESIGN.md section 5.  `make knob NAME=wave KNOBS=-DKD_WAVE_TIER` builds the first variant.
+#ifndef KD_WAVE_TIER
+#define KD_NO_WAVE_TIER
+#endif
 #ifndef KD_BLOCK
 #define KD_BLOCK 768
 #endif
@@ -2821,8 +2833,9 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       o.sizes[2] = ts.r_sizes[2]; o.sizes[3] = ts.r_sizes[3];
       o.out_off = ts.r_out_off;
       o.final_rel = ts.r_final_rel;
+      if (ts.r_arena_order) o.phase |= kPhaseArenaOrder;
     }
-    if (Uni(ToG(p.lat.finalized)[utt]) != 0) o.phase = kPhaseFinalized;
+    if (Uni(ToG(p.lat.finalized)[utt]) != 0) o.phase |= kPhaseFinalized;
   } else {
     // 1-best decoders: ReachedFinal and GetBestPath of what has been decoded so far
     if (err == 0 && frame == target && frame >= 0 && (ud.flags & kUttBestPath)) {

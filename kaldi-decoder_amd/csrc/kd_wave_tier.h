@@ -14,8 +14,8 @@
 // memory round trips with twelve waves in lock step.  One wave needs no barrier (its lanes
 // run in lock step; LDS operations of a wave complete in order), so a frame costs its
 // memory round trips and nothing else, and the other waves of the workgroup are free to
-// run OTHER utterances' frames meanwhile (RunSlots): twelve independent latency chains per
-// CU instead of one.
+// run OTHER utterances' frames meanwhile: twelve independent latency chains per CU instead
+// of one.  (NOT in the shipped build: -DKD_WAVE_TIER, see the note in kd_search.hip.)
 //
 // Same semantics as SmallFrame / FrameFront + FrameBack (DESIGN.md "Order dependence"):
 // float costs `cur + ac + graph`, the cutoff is the value the reference's running cutoff
@@ -55,21 +55,32 @@ static_assert(sizeof(WaveLds) % 16 == 0, "wave regions are 16-byte aligned");
 // this keeps the COMPILER from moving a lane's read above another lane's write.
 __device__ __forceinline__ void WaveSync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// Wave-wide minimum and inclusive prefix sum on the VALU's data-parallel primitives (DPP:
+// row shifts inside the four rows of sixteen lanes, then the row broadcasts) -- seven
+// vector instructions, no LDS round trip.  (__shfl_* compile to ds_bpermute: six dependent
+// LDS-latency steps per reduction, ~700 cycles; a frame of the wave tier does ten of them.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int DppMove(int identity, int v) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
 __device__ __forceinline__ uint32_t WaveMinU32(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const uint32_t y = static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), d, 64));
-    v = y < v ? y : v;
-  }
-  return v;
+  auto mn = [](uint32_t a, int b) { const uint32_t y = static_cast<uint32_t>(b); return y < a ? y : a; };
+  const int id = -1;  // 0xFFFFFFFF
+  v = mn(v, DppMove<0x111, 0xf>(id, static_cast<int>(v)));  // row_shr:1
+  v = mn(v, DppMove<0x112, 0xf>(id, static_cast<int>(v)));  // row_shr:2
+  v = mn(v, DppMove<0x114, 0xf>(id, static_cast<int>(v)));  // row_shr:4
+  v = mn(v, DppMove<0x118, 0xf>(id, static_cast<int>(v)));  // row_shr:8: lane 15 of a row holds the row's
+  v = mn(v, DppMove<0x142, 0xa>(id, static_cast<int>(v)));  // row_bcast:15 into rows 1 and 3
+  v = mn(v, DppMove<0x143, 0xc>(id, static_cast<int>(v)));  // row_bcast:31 into rows 2 and 3
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
 }
 __device__ __forceinline__ int WaveInclScan(int v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int y = __shfl_up(v, d, 64);
-    if (lane >= d) v += y;
-  }
+  v += DppMove<0x111, 0xf>(0, v);
+  v += DppMove<0x112, 0xf>(0, v);
+  v += DppMove<0x114, 0xf>(0, v);
+  v += DppMove<0x118, 0xf>(0, v);  // inclusive within each row of sixteen
+  v += DppMove<0x142, 0xa>(0, v);  // rows 1 and 3 += the total of the row below
+  v += DppMove<0x143, 0xc>(0, v);  // rows 2 and 3 += the total of rows 0 and 1
   return v;
 }
 __device__ __forceinline__ int LaneRank(unsigned long long m) {

@@ -251,10 +251,12 @@ bool ShortestPath(const Lattice &in, Lattice *out) {
     for (size_t k = 0; k < arcs.size(); ++k) {
       const LatticeArc &a = arcs[k];
       const float n1 = d1[s] + a.weight.graph, n2 = d2[s] + a.weight.acoustic;
-      // Exact (graph, acoustic) ties: the device exports a frame's states and arcs in
-      // arena order, which varies from run to run, so "first found" would too.  The arc
-      // with the smaller (olabel, ilabel) wins -- tied arcs that carry the same labels
-      // give the same symbol sequences whichever is taken.
+      // Exact (graph, acoustic) ties.  The device exports states ordered by (frame, graph
+      // state) and arcs by (source state, graph arc) -- the same arrays from run to run --
+      // so the visit order here, and with it every tie (also the choice among equally good
+      // final states below: the lowest state id), is deterministic.  Among tied arcs the one
+      // with the smaller (olabel, ilabel) wins, which also makes the choice independent of
+      // arc order where the labels differ.
       bool tie_wins = false;
       if (n1 == d1[a.nextstate] && n2 == d2[a.nextstate] && back_state[a.nextstate] >= 0) {
         const LatticeArc &cur = in.Arcs(back_state[a.nextstate])[back_arc[a.nextstate]];

@@ -31,12 +31,13 @@ SYMBOLS = (
     "kd_faster_options_default", "kd_batch_create", "kd_batch_destroy",
     "kd_batch_set_options", "kd_batch_init_decoding", "kd_batch_advance",
     "kd_batch_advance_async", "kd_batch_sync", "kd_batch_num_frames_decoded",
-    "kd_batch_status", "kd_batch_reached_final", "kd_batch_best_path_prepare",
+    "kd_batch_decode_host_async", "kd_batch_status", "kd_batch_reached_final", "kd_batch_best_path_prepare",
     "kd_batch_best_path_copy", "kd_batch_frame_tokens", "kd_batch_stats",
     "kd_batch_last_kernel_ms", "kd_batch_device_bytes", "kd_batch_phase_cycles",
     "kd_lattice_options_default", "kd_batch_create_lattice", "kd_batch_finalize_decoding",
     "kd_batch_final_relative_cost", "kd_batch_raw_lattice_prepare", "kd_batch_raw_lattice_copy",
     "kd_batch_create_simple", "kd_batch_decode_async", "kd_batch_decode", "kd_batch_capacity",
+    "kd_batch_set_output_buffer", "kd_batch_raw_lattice_table",
 )
 
 
@@ -103,6 +104,8 @@ def lib():
                                         C.c_void_p, C.c_int32, C.c_int64, C.c_int32]
     L.kd_batch_decode.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), _i32p, C.c_void_p,
                                   C.c_int32, C.c_int64, C.c_int, C.c_int32]
+    L.kd_batch_decode_host_async.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), _i32p,
+                                             C.c_void_p, C.c_int32, C.c_int64, C.c_int32]
     L.kd_batch_capacity.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int64)]
     L.kd_batch_num_frames_decoded.argtypes = [C.c_void_p, _i32p]
     L.kd_batch_status.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.uint32)]
@@ -129,6 +132,9 @@ def lib():
     _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
     L.kd_batch_raw_lattice_copy.argtypes = [C.c_void_p, _i64p, _i64p, _i64p, _i32p, _i32p, _i32p,
                                             _i32p, _f32p, _f32p, _i32p, _i32p, _i32p, _f32p]
+    L.kd_batch_set_output_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.kd_batch_raw_lattice_table.argtypes = [C.c_void_p, C.POINTER(C.c_int64),
+                                             np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
     _lib = L
     return L
 
@@ -306,8 +312,41 @@ class Batch:
         if sync:
             self.sync()
 
-    def decode_host(self, mats, offsets=None, finalize=True, lattice=True, best_path=True):
-        """Decode() over host matrices (staged to the device first), one launch."""
+    def decode_tensor(self, log_probs, lengths=None, finalize=True, lattice=True, best_path=True,
+                      sync=True):
+        """Decode() of a whole padded batch held as ONE device tensor, the way icefall holds its
+        `nnet_output`: `log_probs` float32 [B, T, V] on this batch's GPU (any batch / time
+        strides, unit stride over V), `lengths` [B] valid frames per utterance (default: T).
+        The per-utterance row-0 pointers are built vectorially from data_ptr() + i * stride:
+        no per-utterance Python call.  Same launch as decode_device (kd_batch_decode_async;
+        ref DecodableCtc(feats) + Decode(), csrc/decodable-ctc.cc:22-31)."""
+        import torch
+        t = log_probs
+        if t.dim() != 3 or t.dtype != torch.float32 or not t.is_cuda:
+            raise ValueError("decode_tensor needs a float32 CUDA tensor [B, T, V]")
+        if t.stride(2) != 1:
+            raise ValueError("decode_tensor needs unit stride over the last (V) dimension")
+        B, T, V = t.shape
+        if lengths is None:
+            rows = np.full(B, T, np.int32)
+        else:
+            rows = np.ascontiguousarray(
+                lengths.detach().cpu().numpy() if hasattr(lengths, "detach") else lengths, np.int32)
+            if rows.shape != (B,) or (rows < 0).any() or (rows > T).any():
+                raise ValueError("lengths must be [B] with 0 <= length <= T")
+        ptrs = np.uint64(t.data_ptr()) + np.arange(B, dtype=np.uint64) * np.uint64(4 * t.stride(0))
+        self.batch = B
+        self._keep = t  # (the launch reads the tensor: it must outlive an asynchronous call)
+        want = ((KD_DECODE_FINALIZE if finalize else 0) | (KD_DECODE_LATTICE if lattice else 0) |
+                (KD_DECODE_BEST_PATH if best_path else 0))
+        _check(lib().kd_batch_decode_async(self.h, B, ptrs.ctypes.data_as(C.POINTER(C.c_void_p)),
+                                           rows, None, V, t.stride(1) if T > 1 else V, want))
+        if sync:
+            self.sync()
+
+    def decode_host(self, mats, offsets=None, finalize=True, lattice=True, best_path=True, sync=True):
+        """Decode() over host matrices (staged to the device first), one launch; with
+        sync=False the call returns once the rows are on their way (kd_batch_decode_host_async)."""
         mats = [np.ascontiguousarray(m, np.float32) for m in mats]
         self.batch = len(mats)
         V = mats[0].shape[1]
@@ -315,9 +354,13 @@ class Batch:
         off = None if offsets is None else np.ascontiguousarray(offsets, np.int32)
         want = ((KD_DECODE_FINALIZE if finalize else 0) | (KD_DECODE_LATTICE if lattice else 0) |
                 (KD_DECODE_BEST_PATH if best_path else 0))
-        _check(lib().kd_batch_decode(self.h, self.batch, self._ptrs([m.ctypes.data for m in mats]),
-                                     rows, None if off is None else off.ctypes.data, V, V,
-                                     KD_MEM_HOST, want))
+        ptrs = np.asarray([m.ctypes.data for m in mats], np.uint64)
+        self._keep = mats
+        _check(lib().kd_batch_decode_host_async(self.h, self.batch,
+                                                ptrs.ctypes.data_as(C.POINTER(C.c_void_p)), rows,
+                                                None if off is None else off.ctypes.data, V, V, want))
+        if sync:
+            self.sync()
 
     def sync(self):
         _check(lib().kd_batch_sync(self.h))
@@ -412,6 +455,29 @@ class LatticeBatch(Batch):
         out = np.zeros(self.batch, np.float32)
         _check(lib().kd_batch_final_relative_cost(self.h, out))
         return out
+
+    def set_output_buffer(self, words):
+        """Lends the batch a device buffer (a 1-D int64 CUDA tensor) for its exported lattices:
+        the kernel writes them there instead of into the batch's pinned host pool, so that a
+        gather can hand the buffer to RCCL as it is.  None: back to the host pool."""
+        if words is None:
+            self._out_buf = None
+            _check(lib().kd_batch_set_output_buffer(self.h, None, 0))
+            return
+        import torch
+        if not (words.is_cuda and words.dtype == torch.int64 and words.dim() == 1 and words.is_contiguous()):
+            raise ValueError("set_output_buffer needs a contiguous 1-D int64 CUDA tensor")
+        self._out_buf = words  # (kept alive: the kernel writes into it)
+        _check(lib().kd_batch_set_output_buffer(self.h, words.data_ptr(), words.numel()))
+
+    def raw_lattice_table(self):
+        """After a decode that exported the lattices: (words in use, table [B, 5] of {first
+        word, states, arcs, finals, start state}) -- with a lent output buffer `buf`,
+        buf[:used] and the table are the call's whole result (sharded.unpack_pool reads them)."""
+        used = C.c_int64(0)
+        table = np.zeros((self.batch, 5), np.int64)
+        _check(lib().kd_batch_raw_lattice_table(self.h, C.byref(used), table))
+        return int(used.value), table
 
     def raw_lattices(self, use_final_probs=True):
         """GetRawLattice of every utterance: a sequence of RawLattice (built on access --

@@ -129,14 +129,173 @@ def gather_lattices(lats, dst=0, group=None, as_lattices=False, keep_on_device=F
     if isinstance(lats, RawLattices):
         got = gather_paths([(pack_lattice_batch(lats), None)], dst=dst, group=group, _single=True,
                            _keep_on_device=keep_on_device)
-        if got is None or keep_on_device or not as_lattices:
+        if got is None:
+            return None
+        if keep_on_device:  # (one int32 tensor per rank whatever the world size)
+            import torch
+            return [g if isinstance(g, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(g))
+                    for g in got]
+        if not as_lattices:
             return got
         return [lat for blob in got for lat in unpack_lattice_batch(blob)]
+    if keep_on_device:
+        raise ValueError("keep_on_device gathers the RawLattices of one decode call (one blob per rank)")
     got = gather_paths([(lattice_blob(lat), None) for lat in lats], dst=dst, group=group,
                        _single=True)
     if got is None or not as_lattices:
         return got
     return [lattice_from_blob(b) for b in got]
+
+
+def pool_payload(words, used, table):
+    """One call's exported lattices as ONE 1-D int64 tensor for the gather, built without
+    touching the lattice data: [n utterances, words used | table (5 per utterance) | the used
+    prefix of the output buffer].  `words` is the buffer the batch was lent
+    (LatticeBatch.set_output_buffer: device memory under RCCL); the few header words are
+    uploaded next to it."""
+    import torch
+    head = np.concatenate([np.asarray([len(table), used], np.int64), np.asarray(table, np.int64).reshape(-1)])
+    return torch.cat([torch.from_numpy(head).to(words.device), words[:used]])
+
+
+def unpack_pool(payload):
+    """Inverse of pool_payload on the host: a cabi.RawLattices over the payload's words (an
+    utterance's region: states {frame, graph state} | finals {state, weight} | arcs {src, dst |
+    ilabel, olabel | graph, ac}, include/kd_hip.h)."""
+    from .cabi import RawLattices
+    buf = np.ascontiguousarray(payload.cpu().numpy() if hasattr(payload, "cpu") else payload, np.int64)
+    n, used = int(buf[0]), int(buf[1])
+    table = buf[2:2 + 5 * n].reshape(n, 5)
+    pool = buf[2 + 5 * n:2 + 5 * n + used].view(np.int32).reshape(-1, 2)
+    sizes = table[:, 1:5].copy()
+    so, ao, fo = (np.zeros(n + 1, np.int64) for _ in range(3))
+    so[1:], ao[1:], fo[1:] = np.cumsum(sizes[:, 0]), np.cumsum(sizes[:, 1]), np.cumsum(sizes[:, 2])
+    ns, na, nf = int(so[-1]), int(ao[-1]), int(fo[-1])
+    sf, sg, fs = (np.empty(m, np.int32) for m in (ns, ns, nf))
+    fg = np.empty(nf, np.float32)
+    src, dst, il, ol = (np.empty(na, np.int32) for _ in range(4))
+    gc, ac = np.empty(na, np.float32), np.empty(na, np.float32)
+    for i in range(n):
+        off, s_n, a_n, f_n = int(table[i, 0]), int(sizes[i, 0]), int(sizes[i, 1]), int(sizes[i, 2])
+        if s_n == 0 or off < 0:
+            continue
+        st = pool[off:off + s_n]
+        fi = pool[off + s_n:off + s_n + f_n]
+        ar = pool[off + s_n + f_n:off + s_n + f_n + 3 * a_n].reshape(a_n, 6)
+        sf[so[i]:so[i + 1]], sg[so[i]:so[i + 1]] = st[:, 0], st[:, 1]
+        fs[fo[i]:fo[i + 1]], fg[fo[i]:fo[i + 1]] = fi[:, 0], fi[:, 1].view(np.float32)
+        a0, a1 = ao[i], ao[i + 1]
+        src[a0:a1], dst[a0:a1], il[a0:a1], ol[a0:a1] = ar[:, 0], ar[:, 1], ar[:, 2], ar[:, 3]
+        gc[a0:a1], ac[a0:a1] = ar[:, 4].view(np.float32), ar[:, 5].view(np.float32)
+    return RawLattices(sizes, so, ao, fo, (src, dst, il, ol, gc, ac), (sf, sg), (fs, fg))
+
+
+def gather_exact(payload, dst=0, group=None):
+    """One 1-D tensor per rank to `dst`, exact sizes, no padding: an all_gather of the
+    lengths, then point-to-point -- every other rank sends its tensor as it is, `dst` posts one
+    receive of exactly that length per rank (grouped: batch_isend_irecv; on RCCL that is one
+    grouped launch over the direct xGMI links, not a ring).  The tensor stays where it is: a
+    device tensor goes out of device memory and arrives in `dst`'s device memory.  Returns the
+    list of per-rank tensors on `dst` (its own payload included, not copied), None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [payload]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = torch.tensor([payload.numel()], dtype=torch.int64, device=payload.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    if rank != dst:
+        if payload.numel():
+            dist.send(payload, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+        return None
+    sizes = [int(x) for x in torch.cat(sizes).tolist()]  # (the one host read of the exchange)
+    bufs = [payload if r == rank else torch.empty(sizes[r], dtype=payload.dtype, device=payload.device)
+            for r in range(world)]
+    ops = [dist.P2POp(dist.irecv, bufs[r], dist.get_global_rank(group, r) if group is not None else r, group)
+           for r in range(world) if r != rank and sizes[r]]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return bufs
+
+
+class ResultGatherer:
+    """The gather of finished results, OFF the thread that enqueues decode calls.
+
+    submit(payload) hands a call's packed results (a 1-D tensor: device memory under RCCL)
+    to a worker thread and returns at once; the worker runs gather_exact for the calls in the
+    order they were submitted -- every rank submits the same number of calls in the same
+    order, so the collectives pair up -- on a stream of its own when the payload is on a GPU,
+    so neither the host thread nor the search stream waits for another rank.  `on_done(seq)`
+    is called (on the worker) when call `seq`'s payload has been sent: the buffer may be
+    reused.  close() waits for everything and returns rank `dst`'s list of per-call results
+    (each a list of per-rank tensors), None on the other ranks."""
+
+    def __init__(self, dst=0, group=None, keep=True, on_done=None):
+        import queue
+        import threading
+        self.dst, self.group, self.keep, self.on_done = dst, group, keep, on_done
+        self.q = queue.Queue()
+        self.results = []
+        self.error = None
+        self.n = 0
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        import torch
+        stream = None
+        try:
+            while True:
+                item = self.q.get()
+                if item is None:
+                    return
+                seq, payload, ready = item
+                if payload.is_cuda:
+                    if stream is None:
+                        torch.cuda.set_device(payload.device)
+                        stream = torch.cuda.Stream(device=payload.device)
+                    with torch.cuda.stream(stream):
+                        if ready is not None:
+                            stream.wait_event(ready)  # (the export is on the search stream)
+                        got = gather_exact(payload, self.dst, self.group)
+                    stream.synchronize()
+                else:
+                    got = gather_exact(payload, self.dst, self.group)
+                if self.keep and got is not None:
+                    self.results.append(got)
+                if self.on_done is not None:
+                    self.on_done(seq)
+                self.q.task_done()
+        except BaseException as e:  # (reported by close(): a dead worker must not hang the ranks silently)
+            self.error = e
+
+    def submit(self, payload, ready=None):
+        seq = self.n
+        self.n += 1
+        self.q.put((seq, payload, ready))
+        return seq
+
+    def flush(self):
+        """Waits until everything submitted so far has been gathered."""
+        while self.q.unfinished_tasks and self.t.is_alive() and self.error is None:
+            import time
+            time.sleep(0.0002)
+        if self.error is not None:
+            raise self.error
+
+    def close(self):
+        self.flush()
+        self.q.put(None)
+        self.t.join()
+        if self.error is not None:
+            raise self.error
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_rank(self.group) != self.dst:
+            return None
+        return self.results
 
 
 def gather_paths(paths, dst=0, group=None, _single=False, _keep_on_device=False):

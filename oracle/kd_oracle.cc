@@ -1022,6 +1022,20 @@ struct LatticeSimpleDecoder {
     FinalizeDecoding();
     return !final_costs.empty();
   }
+  // Decode() up to, and without, FinalizeDecoding (.cc:53-66): the state the reference is in
+  // when its loop ends -- what a caller of the declared LatticeFasterDecoder's
+  // AdvanceDecoding + GetRawLattice would see.  Test infrastructure for the KAT on
+  // PruneActiveTokens' early stop (.cc:208-216, :290).
+  void DecodeNoFinal(const Decodable &d) {
+    InitDecoding();
+    while (!d.IsLastFrame(NumFramesDecoded() - 1)) {
+      if (NumFramesDecoded() % config.prune_interval == 0)
+        PruneActiveTokens(config.lattice_beam * config.prune_scale);
+      ProcessEmitting(d);
+      PruneCurrentTokens(config.beam);
+      ProcessNonemitting();
+    }
+  }
   Token *FindOrAddToken(int32_t state, int32_t frame, float tot_cost, bool *changed) {  // .cc:82-120
     Token *&toks = active_toks[frame].toks;
     auto it = cur_toks.find(state);
@@ -1805,6 +1819,10 @@ int kdo_latsimple_decode(void *h, const float *p, int32_t rows, int32_t cols, in
   bool r = false;
   if (Guard([&] { r = static_cast<LatHandle *>(h)->dec.Decode(dec); })) return -1;
   return r ? 1 : 0;
+}
+int kdo_latsimple_decode_nofinal(void *h, const float *p, int32_t rows, int32_t cols, int32_t offset) {
+  Decodable dec{p, rows, cols, offset};
+  return Guard([&] { static_cast<LatHandle *>(h)->dec.DecodeNoFinal(dec); });
 }
 int kdo_latsimple_finalize(void *h) { return Guard([&] { static_cast<LatHandle *>(h)->dec.FinalizeDecoding(); }); }
 int32_t kdo_latsimple_num_frames_decoded(void *h) { return static_cast<LatHandle *>(h)->dec.NumFramesDecoded(); }

@@ -74,6 +74,7 @@ def lib():
     L.kdo_latsimple_free.argtypes = [C.c_void_p]
     L.kdo_latsimple_init.argtypes = [C.c_void_p]
     L.kdo_latsimple_decode.argtypes = [C.c_void_p, _f32p, C.c_int32, C.c_int32, C.c_int32]
+    L.kdo_latsimple_decode_nofinal.argtypes = [C.c_void_p, _f32p, C.c_int32, C.c_int32, C.c_int32]
     L.kdo_latsimple_finalize.argtypes = [C.c_void_p]
     L.kdo_latsimple_num_frames_decoded.argtypes = [C.c_void_p]
     L.kdo_latsimple_final_relative_cost.restype = C.c_float
@@ -365,6 +366,16 @@ class LatticeSimpleDecoder:
         if r < 0:
             raise _err()
         return bool(r)
+
+    def decode_nofinal(self, log_probs, offset=0):
+        """Decode()'s loop without the FinalizeDecoding that ends it (lattice-simple-decoder.cc:53-66)."""
+        lp = np.ascontiguousarray(log_probs, dtype=np.float32)
+        if lib().kdo_latsimple_decode_nofinal(self.h, lp, lp.shape[0], lp.shape[1], offset) != 0:
+            raise _err()
+
+    def finalize_decoding(self):
+        if lib().kdo_latsimple_finalize(self.h) != 0:
+            raise _err()
 
     def num_frames_decoded(self):
         return lib().kdo_latsimple_num_frames_decoded(self.h)

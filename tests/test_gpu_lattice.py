@@ -402,6 +402,138 @@ def test_reached_final_on_a_lattice_batch_leaves_the_export_alone(oracle):
         lb.best_paths()
 
 
+def test_decode_tensor_padded_batch_with_lengths(oracle):
+    """The [B, T, V] (+ lengths) entry: one padded device tensor, ragged
+    lengths, a non-contiguous view (every second time step of a longer tensor) -- same
+    lattices as the canonical oracle on each utterance's valid rows; tolerance 0."""
+    import torch
+    g = synth.hlg_graph(V=40, n_words=200, n_hist=200, avg_succ=8, seed=4)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T, V = 5, 48, 40
+    lens = [48, 31, 1, 17, 40]
+    lps = [synth.make_logprobs(T, V, i, peak=6.0, lexicon=g["lexicon"]) for i in range(B)]
+    opts = dict(beam=10.0, lattice_beam=6.0, min_active=0)
+    dense = torch.from_numpy(np.stack(lps)).cuda()
+    wide = torch.zeros(B, 2 * T, V + 24, device="cuda")
+    wide[:, ::2, :V] = dense
+    for t in (dense, wide[:, ::2, :V]):
+        lb = cabi.LatticeBatch(G, max_batch=B, **opts)
+        lb.decode_tensor(t, torch.tensor(lens))
+        assert lb.num_frames_decoded().tolist() == lens
+        lats = lb.raw_lattices()
+        for i in range(B):
+            can = oracle.CanonLatticeDecoder(OG, **opts)
+            can.decode(lps[i][:lens[i]])
+            _assert_same_lattice(lats[i], can.get_raw_lattice(), f"utt {i}")
+    bt = cabi.Batch(G, max_batch=B, beam=10.0)
+    bt.decode_tensor(dense)  # lengths default to T
+    paths = bt.best_paths()
+    for i in range(B):
+        d = oracle.FasterDecoder(OG, beam=10.0, policy=1)
+        d.decode(lps[i])
+        assert paths[i].ilabel.tolist() == d.get_best_path().ilabel.tolist()
+    with pytest.raises(ValueError, match="unit stride"):
+        lb.decode_tensor(wide[:, :T, ::2])
+
+
+_RAW_FIELDS = ("src", "dst", "ilabel", "olabel", "graph_cost", "ac_cost", "state_frame",
+               "state_graph", "final_state", "final_graph")
+
+
+def _same_arrays(a, b):
+    return (a.ok == b.ok and a.num_states == b.num_states and a.start == b.start and
+            all(getattr(a, k).tobytes() == getattr(b, k).tobytes() for k in _RAW_FIELDS))
+
+
+def test_exported_lattices_are_the_same_arrays_run_to_run(oracle):
+    """GetRawLattice is deterministic in the reference (token-list and link-list order,
+    lattice-simple-decoder.cc:584-657): same input, same arrays.  Here the order in which
+    the search and the sweeps come across tokens and links depends on wave scheduling, so
+    the export sorts: states by (frame, graph state), arcs by (source state, graph arc),
+    finals by state.  The same batch decoded in one launch, again in one launch, stepwise
+    (Init / Advance in chunks / Finalize / GetRawLattice: the general export, ordered on
+    the host) and with another prune_interval must give byte-identical arrays; so must the
+    un-finalized export twice."""
+    import torch
+    g = synth.hlg_graph(V=60, n_words=400, n_hist=400, avg_succ=10, seed=7)
+    G = cabi.Graph(g)
+    B, T, V = 6, 80, 60
+    lps = [synth.make_logprobs(T, V, 20 + i, peak=5.0, lexicon=g["lexicon"]) for i in range(B)]
+    dev = torch.from_numpy(np.stack(lps)).cuda()
+    opts = dict(beam=11.0, lattice_beam=7.0, min_active=0)
+
+    def one_launch(**kw):
+        lb = cabi.LatticeBatch(G, max_batch=B, **{**opts, **kw})
+        lb.decode_tensor(dev)
+        return [lb.raw_lattices()[i] for i in range(B)], lb
+
+    def stepwise(chunk, **kw):
+        lb = cabi.LatticeBatch(G, max_batch=B, **{**opts, **kw})
+        lb.init_decoding()
+        while lb.num_frames_decoded()[0] < T:
+            lb.advance_device([dev[i].data_ptr() for i in range(B)], [T] * B, V, max_num_frames=chunk)
+        raw = [lb.raw_lattices()[i] for i in range(B)]       # un-finalized: the general export
+        raw2 = [lb.raw_lattices(False)[i] for i in range(B)]  # (forces another export launch)
+        raw3 = [lb.raw_lattices()[i] for i in range(B)]
+        lb.finalize_decoding()
+        return [lb.raw_lattices()[i] for i in range(B)], raw, raw3
+
+    a, lb_a = one_launch()
+    b, _ = one_launch()
+    c, _ = one_launch(prune_interval=7)
+    d, d_raw, d_raw3 = stepwise(13)
+    e, e_raw, _ = stepwise(80, prune_interval=10**6)
+    for i in range(B):
+        assert a[i].ok and len(a[i].src) > 20
+        assert _same_arrays(a[i], b[i]), i
+        assert _same_arrays(a[i], c[i]), i
+        assert _same_arrays(a[i], d[i]), i
+        assert _same_arrays(a[i], e[i]), i
+        assert _same_arrays(d_raw[i], d_raw3[i]), i
+        # the canonical order itself
+        f, sg = a[i].state_frame.astype(np.int64), a[i].state_graph.astype(np.int64)
+        key = f << 32 | sg
+        assert (np.diff(key) > 0).all()
+        assert (np.diff(a[i].src.astype(np.int64)) >= 0).all()
+        assert (np.diff(a[i].final_state.astype(np.int64)) > 0).all()
+
+
+def test_lattices_exported_into_a_lent_device_buffer(oracle):
+    """kd_batch_set_output_buffer: the kernel writes the exported lattices into a device
+    tensor of the caller's (what the multi-GPU gather hands to RCCL); buffer + table unpack to
+    the very arrays raw_lattices() gives -- of this batch (through the host mirror) and of a
+    batch that exports into its own pinned pool.  A buffer that is too small is an error."""
+    import torch
+    from kaldi_decoder import sharded
+    g = synth.hlg_graph(V=60, n_words=400, n_hist=400, avg_succ=10, seed=7)
+    G = cabi.Graph(g)
+    B, T, V = 6, 80, 60
+    lps = [synth.make_logprobs(T, V, 20 + i, peak=5.0, lexicon=g["lexicon"]) for i in range(B)]
+    dev = torch.from_numpy(np.stack(lps)).cuda()
+    opts = dict(beam=11.0, lattice_beam=7.0, min_active=0)
+    ref = cabi.LatticeBatch(G, max_batch=B, **opts)
+    ref.decode_tensor(dev)
+    want = ref.raw_lattices()
+    lb = cabi.LatticeBatch(G, max_batch=B, **opts)
+    buf = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
+    lb.set_output_buffer(buf)
+    for _ in range(2):  # (a second call reuses the buffer from its start)
+        lb.decode_tensor(dev)
+        used, table = lb.raw_lattice_table()
+        assert 0 < used <= buf.numel() and table.shape == (B, 5)
+        got = sharded.unpack_pool(sharded.pool_payload(buf, used, table))
+        mine = lb.raw_lattices()
+        for i in range(B):
+            assert _same_arrays(got[i], want[i]), i
+            assert _same_arrays(mine[i], want[i]), i
+    lb.set_output_buffer(torch.zeros(64, dtype=torch.int64, device="cuda"))
+    with pytest.raises(RuntimeError, match="output buffer"):
+        lb.decode_tensor(dev)
+    lb.set_output_buffer(None)
+    lb.decode_tensor(dev)
+    assert _same_arrays(lb.raw_lattices()[0], want[0])
+
+
 def test_decode_from_host_matrices_in_one_launch(oracle):
     """kd_batch_decode with KD_MEM_HOST: the matrices are staged, then the same one-launch
     Decode (ragged lengths); lattice and 1-best batches."""

@@ -222,3 +222,94 @@ def test_gather_of_whole_call_results_world2_gloo(spans):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _threaded_worker(rank, world, port, n_calls, q):
+    """bench.py's multi-GPU path on CPU: every rank submits `n_calls` packed call results to a
+    ResultGatherer (a worker thread runs the exact-size gathers in order) while the "decode"
+    thread goes on; rank 0 gets every call's per-rank payloads bit for bit."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sent = []
+    gat = sharded.ResultGatherer(dst=0, on_done=sent.append)
+
+    def payload(r, c):  # ranks and calls of different sizes, one of them empty
+        n_utts = 0 if (r == 2 and c == 1) else 1 + (3 * r + c) % 4
+        lo = 1000 * r + 10 * c
+        return sharded.pack_lattice_batch(_fake_batch(lo, lo + n_utts))
+
+    for c in range(n_calls):
+        gat.submit(torch.from_numpy(payload(rank, c)))
+    got = gat.close()
+    assert sent == list(range(n_calls))
+    if rank == 0:
+        ok = len(got) == n_calls
+        for c in range(n_calls):
+            ok = ok and len(got[c]) == world
+            for r in range(world):
+                ok = ok and got[c][r].numpy().tobytes() == payload(r, c).tobytes()
+                lats = sharded.unpack_lattice_batch(got[c][r].numpy())
+                lo = 1000 * r + 10 * c
+                ok = ok and all(_same_lattice(lats[k], _fake_lattice(lo + k)) for k in range(len(lats)))
+        q.put(ok)
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_threaded_exact_size_gather_world4_gloo():
+    """north_star: "RCCL over xGMI only for gather of final lattices" -- here over gloo, four
+    ranks: exact sizes (no pad-to-max), grouped point-to-point to rank 0, run by a worker
+    thread so that the thread that enqueues decode calls never waits for another rank."""
+    world = 4
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_threaded_worker, args=(r, world, port, 3, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_result_gatherer_single_process():
+    gat = sharded.ResultGatherer()
+    a, b = torch.arange(5, dtype=torch.int32), torch.zeros(0, dtype=torch.int32)
+    gat.submit(a)
+    gat.submit(b)
+    got = gat.close()
+    assert len(got) == 2 and got[0][0] is a and got[1][0] is b
+
+
+def _fake_pool(lo, hi):
+    """The output buffer and table a LatticeBatch with a lent buffer would hold after a call
+    whose lattices are _fake_lattice(lo..hi-1) (regions in reverse order, as the kernel may
+    place them in any order): include/kd_hip.h, kd_batch_raw_lattice_table."""
+    ls = [_fake_lattice(u) for u in range(lo, hi)]
+    words, table, pos = [], np.zeros((len(ls), 5), np.int64), 0
+    for i in reversed(range(len(ls))):
+        l = ls[i]
+        st = np.stack([l.state_frame, l.state_graph], 1).astype(np.int32)
+        fi = np.stack([l.final_state, l.final_graph.view(np.int32)], 1).astype(np.int32)
+        ar = np.stack([l.src, l.dst, l.ilabel, l.olabel, l.graph_cost.view(np.int32),
+                       l.ac_cost.view(np.int32)], 1).astype(np.int32)
+        region = np.concatenate([st.reshape(-1), fi.reshape(-1), ar.reshape(-1)]).view(np.int64)
+        table[i] = [pos, l.num_states, len(l.src), len(l.final_state), l.start]
+        words.append(region)
+        pos += len(region)
+    return torch.from_numpy(np.concatenate(words + [np.zeros(7, np.int64)])), pos, table
+
+
+def test_pool_payload_roundtrip():
+    for lo, hi in ((0, 7), (3, 4)):
+        buf, used, table = _fake_pool(lo, hi)
+        got = sharded.unpack_pool(sharded.pool_payload(buf, used, table))
+        assert len(got) == hi - lo
+        for k, u in enumerate(range(lo, hi)):
+            assert _same_lattice(got[k], _fake_lattice(u))
