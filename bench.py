@@ -373,6 +373,20 @@ def main():
         out_bufs = [torch.zeros(per_slot << 13, dtype=torch.int64, device="cuda") for _ in range(n_fly)]
         for bt_, buf_ in zip(bts, out_bufs):
             bt_.set_output_buffer(buf_)
+        # a lent buffer does not grow (the library's own pool does): size it on one untimed
+        # call per slot -- doubled until the call's lattices fit, with room to spare
+        for slot_ in range(n_fly):
+            while True:
+                try:
+                    bts[slot_].decode_device(ptrs_of[slot_], [T] * per_slot, V)
+                    used_, _ = bts[slot_].raw_lattice_table()
+                    if 2 * used_ <= out_bufs[slot_].numel():
+                        break
+                except RuntimeError as e:
+                    if "output buffer" not in str(e):
+                        raise
+                out_bufs[slot_] = torch.zeros(2 * out_bufs[slot_].numel(), dtype=torch.int64, device="cuda")
+                bts[slot_].set_output_buffer(out_bufs[slot_])
 
     def deliver(out, slot):
         if out is None:

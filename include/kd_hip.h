@@ -289,9 +289,12 @@ int kd_batch_final_relative_cost(kd_batch *b, float *out);
  * sizes[4*i..] = {states, arcs, finals, start state}; all zero / start -1 is the
  * reference's `false` (some frame has no token).  copy writes utterance i's
  * arcs at arc_off[i], its states' (frame, graph state) labels at state_off[i]
- * and its final weights at final_off[i].  States are numbered frame-major.
- * use_final_probs = 0 after kd_batch_finalize_decoding is an error, as in the
- * reference (:594-597). */
+ * and its final weights at final_off[i].  States are numbered frame-major and,
+ * inside a frame, by graph state; arcs are ordered by (source state, graph arc),
+ * finals by state: the same input gives the same arrays from run to run, as the
+ * reference's GetRawLattice does (its own order is its containers' iteration
+ * order, :623-644).  use_final_probs = 0 after kd_batch_finalize_decoding is an
+ * error, as in the reference (:594-597). */
 int kd_batch_raw_lattice_prepare(kd_batch *b, int32_t use_final_probs, int32_t *sizes);
 int kd_batch_raw_lattice_copy(kd_batch *b, const int64_t *state_off, const int64_t *arc_off,
                               const int64_t *final_off, int32_t *src, int32_t *dst,
@@ -299,14 +302,25 @@ int kd_batch_raw_lattice_copy(kd_batch *b, const int64_t *state_off, const int64
                               float *ac_cost, int32_t *state_frame, int32_t *state_graph,
                               int32_t *final_state, float *final_graph);
 
+/* ---- logits in, log-softmax fused -------------------------------------------------------
+ * The reference's DecodableCtc takes log-probabilities (ref: csrc/decodable-ctc.cc:28); its
+ * callers apply log_softmax to the network output first.  With this switch on, the matrices
+ * handed to advance / decode hold LOGITS and every row is normalised (x - logsumexp(x),
+ * float) where the kernel stages it in LDS -- no extra pass over [B, T, V] in HBM.  Rows of
+ * more than 2048 columns are not staged: KD_E_INVALID.  Costs then agree with a decode of
+ * torch.log_softmax(logits) to float rounding (the tests state 1e-4 relative), not bit for
+ * bit; with the switch off nothing changes. */
+int kd_batch_set_log_softmax(kd_batch *b, int32_t on);
+
 /* ---- exported results in DEVICE memory ---------------------------------------------
- * By default the kernel writes exported lattices (and best paths) into a pinned host pool
- * of the batch.  A caller that wants them on the GPU -- the multi-GPU gather hands RCCL a
- * device buffer: no host packing, no upload -- lends a device buffer of `cap_words`
- * 8-byte words; the kernel then writes there, and the host-array calls above copy what
- * they need back on demand.  NULL returns to the batch's own pool.  Not growable: a full
- * buffer is KD_E_CAPACITY.  (No counterpart in the reference: its lattices are host
- * objects, csrc/lattice-simple-decoder.cc:584-657.) */
+ * The kernel writes exported lattices into a pinned host pool of the batch.  A caller that
+ * wants them on the GPU as well -- the multi-GPU gather hands RCCL a device buffer: no host
+ * packing, no upload -- lends a device buffer of `cap_words` 8-byte words: the export that
+ * is fused into a decode (KD_DECODE_FINALIZE | KD_DECODE_LATTICE) then writes every word
+ * there too, at the same offsets; the host-array calls above keep reading the pinned pool.
+ * NULL ends the loan.  The lent buffer does not grow: a call whose lattices do not fit is
+ * KD_E_CAPACITY.  (No counterpart in the reference: its lattices are host objects,
+ * csrc/lattice-simple-decoder.cc:584-657.) */
 int kd_batch_set_output_buffer(kd_batch *b, void *device_words, int64_t cap_words);
 /* After a decode with KD_DECODE_LATTICE (or kd_batch_raw_lattice_prepare): how many words of
  * the output pool / buffer are in use, and per utterance {first word, states, arcs, finals,

@@ -79,12 +79,10 @@ struct kd_batch {
   DevBuf<int32_t> link_src, link_dst, link_arc;
   DevBuf<float> link_ac, link_graph, link_delta;
   unsigned long long *out_pool = nullptr;  // pinned host memory, written by the kernel
-  // ... unless the caller has lent a DEVICE buffer for the exported results
-  // (kd_batch_set_output_buffer): the kernel writes there, and the pinned pool is a mirror
-  // that is filled only when somebody asks for host arrays
+  // ... and, if the caller has lent a DEVICE buffer for the exported lattices
+  // (kd_batch_set_output_buffer), there too, word for word (the staged export)
   unsigned long long *out_ext = nullptr;
-  uint64_t out_ext_cap = 0, out_own_cap = 0;
-  bool mirror_valid = true;
+  uint64_t out_ext_cap = 0;
   std::vector<uint8_t> h_lat_arena;  // the export of utterance i is in arena order (general export)
   bool canon_done = true;
   // ---- per utterance
@@ -119,7 +117,7 @@ struct kd_batch {
   int64_t l_row_stride = 0;
   uint32_t l_tail_flags = 0;
   // lattice state
-  bool lattice = false, finalized = false, simple = false;
+  bool lattice = false, finalized = false, simple = false, log_softmax = false;
   bool lat_stats_valid = false;  // h_final_rel is current
   int32_t exported_use_final = -1;  // the output pool holds GetRawLattice(use_final_probs = this)
   kd_lattice_options lo{};
@@ -205,6 +203,7 @@ struct kd_batch {
     p.out_base = out_base;
     p.lattice = lattice ? 1 : 0;
     p.simple = simple ? 1 : 0;
+    p.log_softmax = log_softmax ? 1 : 0;
     p.g_log_ac = g_log_ac.p;
     p.g_log_gr = g_log_gr.p;
     p.tok_extra = tok_extra.p;
@@ -232,8 +231,9 @@ struct kd_batch {
     p.lat.finalized = lat_finalized.p;
     p.lat.frame_state_off = frame_state_off.p;
     p.lat.frame_arc_off = frame_arc_off.p;
-    p.lat.out = out_ext ? out_ext : out_pool;
-    p.lat.out_cap = out_cap;
+    p.lat.out = out_pool;
+    p.lat.out2 = out_ext;
+    p.lat.out_cap = out_ext ? std::min<uint64_t>(out_cap, out_ext_cap) : out_cap;
     return p;
   }
 };
@@ -315,7 +315,7 @@ int GrowLinks(kd_batch *b) {
 
 constexpr uint64_t kMaxOutWords = 1ull << 33;  // 64 GiB of pinned host memory
 int GrowOut(kd_batch *b) {
-  if (b->out_ext)
+  if (b->out_ext && b->out_ext_cap <= b->out_cap)
     return Fail(KD_E_CAPACITY, "the output buffer lent with kd_batch_set_output_buffer is full (" +
                                std::to_string(b->out_ext_cap) + " words): lend a larger one");
   if (b->out_cap >= kMaxOutWords)
@@ -328,7 +328,6 @@ int GrowOut(kd_batch *b) {
   (void)hipHostFree(b->out_pool);
   b->out_pool = np;
   b->out_cap = cap;
-  b->out_own_cap = cap;
   b->grow_events++;
   return KD_OK;
 }
@@ -437,6 +436,9 @@ int Enqueue(kd_batch *b) {
   SearchParams p = b->Params();
   p.num_cols = b->l_num_cols;
   p.row_stride = b->l_row_stride;
+  if (b->log_softmax && b->l_num_cols > SearchMaxLdsCols())
+    return Fail(KD_E_INVALID, "log-softmax is fused into the staging of a row in LDS: at most " +
+                              std::to_string(SearchMaxLdsCols()) + " columns");
   const int wgs = std::min(b->batch, b->workgroups);
   KD_HIP_TRY(hipEventRecord(b->ev0, b->stream));
   KD_HIP_TRY(LaunchSearch(p, wgs, b->stream));
@@ -512,23 +514,8 @@ void CanonicalizeExport(unsigned long long *region, int32_t *sizes) {
   }
 }
 
-// The exported results where the HOST can read them: the pinned pool itself, or -- with a
-// lent device buffer -- its mirror, filled here (one copy of the used prefix); then the
-// arena-ordered exports are put in order, once.
+// The exported results as the host reads them: arena-ordered exports are put in order, once.
 int HostResults(kd_batch *b) {
-  if (!b->mirror_valid) {
-    const uint64_t used = b->h_out_top;
-    if (used > b->out_own_cap) {
-      unsigned long long *np = nullptr;
-      if (hipHostMalloc(reinterpret_cast<void **>(&np), used * 8, hipHostMallocDefault) != hipSuccess)
-        return Fail(KD_E_CAPACITY, "cannot allocate the host mirror of the output buffer");
-      (void)hipHostFree(b->out_pool);
-      b->out_pool = np;
-      b->out_own_cap = used;
-    }
-    if (used) KD_HIP_TRY(hipMemcpy(b->out_pool, b->out_ext, used * 8, hipMemcpyDeviceToHost));
-    b->mirror_valid = true;
-  }
   if (!b->canon_done) {
     for (int i = 0; i < b->batch; ++i)
       if (b->h_lat_arena[i]) CanonicalizeExport(b->out_pool + b->h_lat_off[i], &b->h_lat_sizes[4 * i]);
@@ -570,7 +557,6 @@ int ReadBack(kd_batch *b) {
           b->h_lat_arena[i] = (uo[i].phase & kPhaseArenaOrder) && uo[i].out_off >= 0;
         }
         b->canon_done = false;
-        b->mirror_valid = b->out_ext == nullptr;
         b->exported_use_final = (b->l_tail_flags & kUttExport) ? 1 : 0;
       }
     }
@@ -585,7 +571,6 @@ int ReadBack(kd_batch *b) {
       }
       b->path_valid = true;
       b->path_use_final = (b->l_tail_flags & kUttPathNoFinal) ? 0 : 1;
-      b->mirror_valid = b->out_ext == nullptr;
     }
     if (!any) return KD_OK;
     if (b->o.no_grow || (any & ~kRecoverable)) return Fail(KD_E_CAPACITY, StatusMessage(b, first_bad));
@@ -825,7 +810,6 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   // output pool (pinned): exported lattices, or best paths (three words an arc)
   b->out_cap = std::max<uint64_t>(1ull << 16, static_cast<uint64_t>(max_batch) << (lopts ? 13 : 11));
   A(hipHostMalloc(reinterpret_cast<void **>(&b->out_pool), b->out_cap * 8, hipHostMallocDefault));
-  b->out_own_cap = b->out_cap;
   b->h_lat_off.assign(max_batch, -1);
   b->h_lat_arena.assign(max_batch, 0);
   if (e == hipSuccess) e = hipEventCreate(&b->ev0);
@@ -1358,20 +1342,24 @@ int kd_batch_raw_lattice_copy(kd_batch *b, const int64_t *state_off, const int64
   return KD_OK;
 }
 
+int kd_batch_set_log_softmax(kd_batch *b, int32_t on) {
+  if (!b) return Fail(KD_E_INVALID, "bad argument");
+  if (b->pending)
+    if (int r = ReadBack(b)) return r;
+  b->log_softmax = on != 0;
+  return KD_OK;
+}
+
 int kd_batch_set_output_buffer(kd_batch *b, void *device_words, int64_t cap_words) {
   if (!b) return Fail(KD_E_INVALID, "bad argument");
+  if (!b->lattice) return Fail(KD_E_STATE, "not a lattice batch");
   if (device_words && cap_words <= 0) return Fail(KD_E_INVALID, "bad capacity");
   KD_HIP_TRY(hipSetDevice(b->g->device));
   if (b->pending)
     if (int r = ReadBack(b)) return r;
   b->out_ext = static_cast<unsigned long long *>(device_words);
   b->out_ext_cap = device_words ? static_cast<uint64_t>(cap_words) : 0;
-  b->out_cap = device_words ? b->out_ext_cap : b->out_own_cap;
-  // whatever was exported lies in the other pool: nothing is exported any more
-  b->exported_use_final = -1;
-  b->path_valid = false;
-  b->mirror_valid = true;
-  b->canon_done = true;
+  b->exported_use_final = -1;  // (what was exported is not in the new buffer)
   return KD_OK;
 }
 
@@ -1384,9 +1372,10 @@ int kd_batch_raw_lattice_table(kd_batch *b, int64_t *used_words, int64_t *table)
   if (b->exported_use_final < 0)
     return Fail(KD_E_STATE, "nothing exported: decode with KD_DECODE_LATTICE or call kd_batch_raw_lattice_prepare");
   for (int i = 0; i < b->batch; ++i)
-    if (b->h_lat_arena[i] && !b->canon_done)
-      return Fail(KD_E_STATE, "utterance " + std::to_string(i) + "'s export is in arena order (an "
-                              "un-finalized lattice): take it through kd_batch_raw_lattice_copy");
+    if (b->h_lat_arena[i])
+      return Fail(KD_E_STATE, "utterance " + std::to_string(i) + "'s export is in arena order (an un-finalized "
+                              "lattice, or one exported apart from the decode): only the host arrays of "
+                              "kd_batch_raw_lattice_copy are ordered; the lent buffer holds the staged export");
   *used_words = static_cast<int64_t>(b->h_out_top);
   for (int i = 0; i < b->batch; ++i) {
     table[5 * i] = b->h_lat_off[i];

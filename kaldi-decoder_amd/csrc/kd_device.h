@@ -137,6 +137,12 @@ struct LatticeParams {
   // finals {state id, weight} x nf | arcs {src, dst, ilabel, olabel, graph, ac} x na
   unsigned long long *out;   // (pinned host memory)
   unsigned long long out_cap;
+  // a device buffer the caller lent (kd_batch_set_output_buffer) or null: the staged export
+  // writes every word there too, at the same offsets -- the host reads its arrays from the
+  // pinned pool as ever (no copy back through a blit kernel that would have to wait for a CU
+  // among the persistent search workgroups: measured 18 ms a call), the multi-GPU gather
+  // hands the device copy to RCCL
+  unsigned long long *out2;
 };
 
 struct SearchParams {
@@ -191,6 +197,8 @@ struct SearchParams {
   // lattice mode (LatticeSimpleDecoder / LatticeFasterDecoder semantics)
   int32_t lattice;           // 0: FasterDecoder (double costs), 1: lattice decoders (float costs)
   int32_t simple;            // 1: SimpleDecoder semantics (plain beam, prune after closure)
+  int32_t log_softmax;       // 1: the matrices hold logits; each row is normalised (x - logsumexp(x))
+                             // when it is staged in LDS (kd_batch_set_log_softmax)
   float *g_log_ac;           // queue: acoustic cost (emitting) / source cost at generation (epsilon)
   float *g_log_gr;           // queue: graph cost of the arc (lattice mode)
   float *tok_extra;          // [token pool] extra_cost of each token
@@ -214,6 +222,7 @@ struct SearchParams {
 // `workgroups` persistent workgroups take the batch's utterances from the work queue.
 hipError_t LaunchSearch(const SearchParams &p, int workgroups, hipStream_t stream);
 size_t SearchLdsBytes();
+int SearchMaxLdsCols();       // widest row the kernel stages in LDS (wider ones are read in place)
 int SearchWorkgroupsPerCu();  // resident workgroups a CU holds (build geometry)
 
 // Order-preserving map double -> uint64 (so integer atomicMin orders costs).

@@ -922,6 +922,10 @@ __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &
   if (off < 0) return KD_UTT_OUT_FULL;
   KD_G unsigned long long *o_state = ToG(p.lat.out) + off, *o_final = o_state + ns,
                           *o_arc = o_final + nf;
+  // (the lent device buffer, if any: the same words at the same offsets)
+  const bool two = p.lat.out2 != nullptr;
+  KD_G unsigned long long *d_state = ToG(two ? p.lat.out2 : p.lat.out) + off, *d_final = d_state + ns,
+                          *d_arc = d_final + nf;
   auto pack = [](uint32_t lo, uint32_t hi) { return static_cast<unsigned long long>(hi) << 32 | lo; };
   // a token's id: its frame's offset + the number of the frame's tokens with a lower state
   // (one token per state and frame); the finals likewise, among the last frame's finals
@@ -940,10 +944,12 @@ __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &
     const int id = lo + rank;
     ToG(p.lat.tok_newid)[sc_b[at]] = id;
     o_state[id] = pack(static_cast<uint32_t>(f), state);
+    if (two) d_state[id] = pack(static_cast<uint32_t>(f), state);
     if (f == 0 && static_cast<int32_t>(state) == p.start) s.start_id = id;  // :623-629
     if (mine >> 31) {
       const float fc = ToG(p.states)[state].final_cost;
       o_final[frank] = pack(static_cast<uint32_t>(id), __float_as_uint(any_final ? fc : 0.0f));
+      if (two) d_final[frank] = pack(static_cast<uint32_t>(id), __float_as_uint(any_final ? fc : 0.0f));
     }
   }
   __syncthreads();  // every listed token's id is in place
@@ -985,6 +991,12 @@ __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &
     w[0] = pack(static_cast<uint32_t>(sid), static_cast<uint32_t>(ToG(p.lat.tok_newid)[dst]));
     w[1] = pack(static_cast<uint32_t>(ar.ilabel), static_cast<uint32_t>(ar.olabel));
     w[2] = pack(__float_as_uint(gr), __float_as_uint(ac));
+    if (two) {
+      KD_G unsigned long long *d = d_arc + 3ll * (lo + rank);
+      d[0] = w[0];
+      d[1] = w[1];
+      d[2] = w[2];
+    }
   }
   __syncthreads();
   if (tid == 0) {

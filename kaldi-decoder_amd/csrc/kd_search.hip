@@ -1654,7 +1654,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
 template <int M>
 __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true> &t, int frame,
                                                Counters &cnt, const Team &tm,
-                                               const float (&ll_next)[kPfRegs], bool have_next) {
+                                               const KD_G float *next_row, bool have_next) {
   constexpr int KD_BUCKET = kBucketSmall;
   (void)KD_BUCKET;
   CParams &p = c.p;
@@ -1879,6 +1879,14 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   using EpsNo = std::false_type;
   using EpsYes = std::true_type;
 
+#ifdef KD_ROW_EARLY  // (A/B knob: the request where it was until round 3)
+  float ll_next[kPfRegs];
+#pragma unroll
+  for (int k = 0; k < kPfRegs; ++k) {
+    const int v = tid + k * kBlock;
+    ll_next[k] = have_next && nt == kBlock && v < p.num_cols ? next_row[v] : 0.0f;
+  }
+#endif
   if (tid < kMaskWords) wlmask[tid] = 0;  // worklist 0 collects the emitting insert's tokens
   c.run_min = kCostInf<M>;
   GetCutoff<true>(c, tm);
@@ -1933,6 +1941,19 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   PublishMin(c);
   tm.Sync(false);
   KD_LAP(s, 3);
+  // The next frame's log-likelihood row is requested HERE, next to the work items' arc
+  // gathers, and stored when the emitting filter is done with this frame's row.  (Requested
+  // when the frame began -- as until round 3 -- its latency was not hidden but exposed: the
+  // frame's first scratch reload waits for every load in flight, s_waitcnt vmcnt(0), and
+  // that was the row.  2.9 k cycles a frame sat in "GetCutoff".)
+#ifndef KD_ROW_EARLY
+  float ll_next[kPfRegs];
+#pragma unroll
+  for (int k = 0; k < kPfRegs; ++k) {
+    const int v = tid + k * kBlock;
+    ll_next[k] = have_next && nt == kBlock && v < p.num_cols ? next_row[v] : 0.0f;
+  }
+#endif
   item_loop(EpsNo{});
   queue_sync();
   KD_LAP(s, 4);
@@ -2484,6 +2505,39 @@ __device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long 
 #include "kd_path_tail.h"
 #include "kd_wave_tier.h"
 
+// Fused log-softmax (kd_batch_set_log_softmax): the caller's matrices hold
+// logits, and the row a frame reads is normalised where it already sits -- in LDS -- by the
+// whole workgroup: x - (max + log(sum(exp(x - max)))), float, the partial sums combined in a
+// fixed order (so a row comes out the same whichever workgroup stages it).  The reference
+// leaves log_softmax to the caller (DecodableCtc takes log-probs, csrc/decodable-ctc.cc:28);
+// icefall applies it to the network output before decoding.
+__device__ __forceinline__ void NormalizeRow(Shared &s, int V) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *red = reinterpret_cast<float *>(s.red64);
+  float m = -FLT_MAX;
+  for (int v = tid; v < V; v += kBlock) m = fmaxf(m, s.ll[v]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  if (lane == 0) red[wave] = m;
+  LdsBarrier();
+  float mx = red[0];
+#pragma unroll
+  for (int w = 1; w < kWaves; ++w) mx = fmaxf(mx, red[w]);
+  LdsBarrier();
+  float sum = 0.0f;
+  for (int v = tid; v < V; v += kBlock) sum += expf(s.ll[v] - mx);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+  if (lane == 0) red[wave] = sum;
+  LdsBarrier();
+  float total = red[0];
+#pragma unroll
+  for (int w = 1; w < kWaves; ++w) total += red[w];
+  const float lse = mx + logf(total);
+  for (int v = tid; v < V; v += kBlock) s.ll[v] -= lse;
+  LdsBarrier();
+}
+
 // What one workgroup does for one utterance of the work queue: InitDecoding if asked,
 // the frames up to the utterance's target, then -- lattice decoders, when asked -- the
 // tail: ComputeFinalCosts, FinalizeDecoding's backward prune and GetRawLattice into the
@@ -2562,6 +2616,10 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     if (!c.ll_in_lds || f < 0 || f >= target) return;
     const KD_G float *row = row_of(f);
     for (int v = tid; v < p.num_cols; v += kBlock) s.ll[v] = row[v];
+    if (p.log_softmax) {  // (logits: normalised here, once per staging)
+      LdsBarrier();
+      NormalizeRow(s, p.num_cols);
+    }
   };
   // At the top of the loop the per-frame counters are reset and s.ll holds the
   // frame's log-likelihood row: a frame boundary costs one barrier.
@@ -2661,17 +2719,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       const Team tm{kT1Narrow > 0 && c.n_in <= kT1Narrow ? 256 : kBlock, gen};
       const bool have_next = c.ll_in_lds && frame + 1 < target;
       if (tid < tm.nt) {
-        float ll_next[kPfRegs];
-#pragma unroll
-        for (int k = 0; k < kPfRegs; ++k) ll_next[k] = 0.0f;
-        if (have_next && tm.nt == kBlock) {
-          const KD_G float *row = row_of(frame + 1);
-#pragma unroll
-          for (int k = 0; k < kPfRegs; ++k) {
-            const int v = tid + k * kBlock;
-            if (v < p.num_cols) ll_next[k] = row[v];
-          }
-        }
+        const KD_G float *ll_next = row_of(have_next ? frame + 1 : frame);
         c.ll_row = row_of(frame);
         if (!front_lds) LoadFront(c, tm);
         // (two copies of the frame on purpose: in each the compiler knows where the
@@ -2701,6 +2749,9 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       }
       if (tm.nt != kBlock) LdsBarrier();  // the next frame's row is in place
       r = Uni(s.ctl[frame & 1].r);
+      // (logits: the row the frame swapped in for the next one; a frame that is run again
+      // below stages its rows afresh)
+      if (p.log_softmax && r == 0 && have_next) NormalizeRow(s, p.num_cols);
       upper_dirty = true;
       best_stale = true;
       if (r == 0) {
@@ -2895,6 +2946,7 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
 }  // namespace
 
 size_t SearchLdsBytes() { return sizeof(Shared); }
+int SearchMaxLdsCols() { return kVmax; }
 int SearchWorkgroupsPerCu() { return KD_WG_PER_CU; }
 
 namespace {

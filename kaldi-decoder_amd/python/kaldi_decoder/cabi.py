@@ -37,7 +37,7 @@ SYMBOLS = (
     "kd_lattice_options_default", "kd_batch_create_lattice", "kd_batch_finalize_decoding",
     "kd_batch_final_relative_cost", "kd_batch_raw_lattice_prepare", "kd_batch_raw_lattice_copy",
     "kd_batch_create_simple", "kd_batch_decode_async", "kd_batch_decode", "kd_batch_capacity",
-    "kd_batch_set_output_buffer", "kd_batch_raw_lattice_table",
+    "kd_batch_set_output_buffer", "kd_batch_raw_lattice_table", "kd_batch_set_log_softmax",
 )
 
 
@@ -133,6 +133,7 @@ def lib():
     L.kd_batch_raw_lattice_copy.argtypes = [C.c_void_p, _i64p, _i64p, _i64p, _i32p, _i32p, _i32p,
                                             _i32p, _f32p, _f32p, _i32p, _i32p, _i32p, _f32p]
     L.kd_batch_set_output_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.kd_batch_set_log_softmax.argtypes = [C.c_void_p, C.c_int32]
     L.kd_batch_raw_lattice_table.argtypes = [C.c_void_p, C.POINTER(C.c_int64),
                                              np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
     _lib = L
@@ -262,6 +263,11 @@ class Batch:
         for k, v in opts.items():
             setattr(self.opts, k, v)
         _check(lib().kd_batch_set_options(self.h, C.byref(self.opts)))
+
+    def set_log_softmax(self, on=True):
+        """The matrices handed to advance / decode hold logits: log_softmax is fused into the
+        kernel's row staging (kd_batch_set_log_softmax)."""
+        _check(lib().kd_batch_set_log_softmax(self.h, 1 if on else 0))
 
     def init_decoding(self, batch=None):
         self.batch = self.max_batch if batch is None else batch

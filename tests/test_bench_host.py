@@ -48,14 +48,27 @@ def test_committed_summary_matches_the_bench_line_next_to_it():
         assert under["config"]["prune_interval"] == b["config"]["prune_interval"]
         assert under["roofline"]["utterance_frames_per_launch"] == b["roofline"]["utterance_frames_per_launch"]
         assert b["roofline"]["traffic"] == s["hbm_bytes_per_launch"]
-        # average launch: rocprofv3's trace against the HIP events of the bench line
-        assert abs(s["avg_launch_ms"] - b["roofline"]["kernel_ms"]) / b["roofline"]["kernel_ms"] < 0.05
+        # average launch: rocprofv3's trace against the HIP events of the SAME (profiled) run
+        assert abs(s["avg_launch_ms"] - under["roofline"]["kernel_ms"]) / under["roofline"]["kernel_ms"] < 0.05
+        # ... and against the un-profiled line: the same launches, stretched by however much the
+        # calls in flight overlap -- between the launch-alone duration and the bench's own figure
+        # (under the profiler the host thread is slower and the calls overlap less)
+        lo = 0.95 * min(b["roofline"]["launch_alone"]["kernel_ms"], under["roofline"]["launch_alone"]["kernel_ms"])
+        assert lo <= s["avg_launch_ms"] <= 1.05 * b["roofline"]["kernel_ms"]
 
 
-def test_library_is_not_built_with_the_option_that_stalled_the_large_workload():
-    """DESIGN §5 "A 5 % that is not taken": -amdgpu-prealloc-sgpr-spill-vgprs made the bench
-    5 % faster and the large-LM workload stall or fault in 2 runs of 3.  Whoever turns it
-    back on has to have run `bench.py --workload hlg-large` a number of times first."""
+def test_the_barrier_that_the_spill_option_depends_on_is_in_place():
+    """DESIGN section 4, "A barrier that was missing": -amdgpu-prealloc-sgpr-spill-vgprs (+ 3 % on
+    the bench) made round 2's large-LM workload stall 2 runs in 3 -- by shifting the waves'
+    timing onto a race in the lattice sweep, not by itself.  The option is on again since the
+    race is fixed; this keeps the two together: SweepWindow must synchronise BEFORE its first
+    wave rewrites the window descriptors that the other waves may still be reading."""
     mk = open(os.path.join(ROOT, "kaldi-decoder_amd", "Makefile")).read()
     flags = [ln for ln in mk.splitlines() if ln.startswith("HIPFLAGS")]
-    assert flags and all("prealloc-sgpr-spill-vgprs" not in ln for ln in flags)
+    assert flags
+    src = open(os.path.join(ROOT, "kaldi-decoder_amd", "csrc", "kd_lattice_tail.h")).read()
+    body = src[src.index("__device__ __forceinline__ int SweepWindow("):]
+    body = body[:body.index("__syncthreads();")]
+    # (comment lines out: the barrier call itself must precede the builder)
+    code = "\n".join(ln for ln in body.splitlines() if not ln.strip().startswith("//"))
+    assert "LdsBarrier();" in code and code.index("LdsBarrier();") < code.index("if (tid < 64) {")

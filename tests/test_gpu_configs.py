@@ -11,6 +11,16 @@ from kaldi_decoder import cabi, synth
 
 pytestmark = pytest.mark.gpu
 INT_MAX = 2**31 - 1
+_GRAPHS = {}
+
+
+def _bench_graph(workload):
+    """bench.py's graph of `workload`, synthesised once per test session (the large-LM graph
+    takes a minute)."""
+    import bench
+    if workload not in _GRAPHS:
+        _GRAPHS[workload] = synth.hlg_graph(**bench.WORKLOADS[workload]["graph"])
+    return _GRAPHS[workload]
 
 
 def test_cfg2_full_size_hl_max_active_3000(oracle):
@@ -60,7 +70,7 @@ def test_cfg5_large_lm_hlg_beam17_default_capacities(oracle):
     import torch
     import bench
     wl = bench.WORKLOADS["hlg-large"]
-    g = synth.hlg_graph(**wl["graph"])
+    g = _bench_graph("hlg-large")
     assert len(g["ilabel"]) * 16 > 2 * 10**9  # > 2 GB of 16-byte arcs
     G, OG = cabi.Graph(g), oracle.Graph(g)
     B, T, V = 4, wl["frames"], wl["V"]
@@ -85,6 +95,83 @@ def test_cfg5_large_lm_hlg_beam17_default_capacities(oracle):
         pr, pc = ref.get_best_path(), can.get_best_path()
         assert pr.isyms.tolist() == pc.isyms.tolist() and pr.osyms.tolist() == pc.osyms.tolist(), i
         assert gl.arc_set() <= ref.get_raw_lattice().arc_set(), i
+
+
+def _logprobs(T, V, ids, lexicon):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        return list(ex.map(lambda u: synth.make_logprobs(T, V, u, peak=12.0, lexicon=lexicon), ids))
+
+
+def test_bench_scale_hlg_1024_per_call_two_calls_in_flight(oracle):
+    """The configuration bench.py times (BASELINE configs[2] at its quoted size and more): 1024
+    distinct utterances in ONE call -- 256 persistent workgroups taking four utterances each
+    from the work queue, pools and tables at the library's defaults -- with a second call of
+    1024 other utterances in flight on a stream of its own.  64 sampled utterances (both
+    calls; the first, the last and every 32nd): lattice SET EQUALITY with the canonical
+    oracle -- states, arcs with bit-equal costs, no duplicates -- and FinalRelativeCost."""
+    import torch
+    import bench
+    wl = bench.WORKLOADS["hlg-lattice"]
+    g = _bench_graph("hlg-lattice")
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    N, T, V = 1024, wl["frames"], wl["V"]
+    lps = _logprobs(T, V, range(5000, 5000 + 2 * N), g["lexicon"])
+    devs = [torch.from_numpy(np.stack(lps[k * N:(k + 1) * N])).cuda() for k in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    lbs = [cabi.LatticeBatch(G, max_batch=N, max_frames=T, stream=st.cuda_stream, **wl["opts"])
+           for st in streams]
+    for rep in range(2):  # (the second round reuses pools, tables and queues)
+        for k in range(2):
+            lbs[k].decode_tensor(devs[k], sync=False)
+        for k in range(2):
+            lbs[k].sync()
+    oopts = {k: v for k, v in wl["opts"].items() if k != "prune_interval"}
+    sample = sorted(set(list(range(0, N, 32)) + [N - 1]))
+    checked = 0
+    for k in range(2):
+        assert lbs[k].num_frames_decoded().tolist() == [T] * N
+        lats, frc = lbs[k].raw_lattices(), lbs[k].final_relative_cost()
+        for i in sample:
+            can = oracle.CanonLatticeDecoder(OG, **oopts)
+            can.decode(lps[k * N + i])
+            cl, gl = can.get_raw_lattice(), lats[i]
+            assert gl.state_set() == cl.state_set(), (k, i)
+            assert gl.arc_set() == cl.arc_set() and len(gl.src) == len(cl.src), (k, i)
+            assert gl.final_set() == cl.final_set(), (k, i)
+            assert frc[i] == np.float32(can.final_relative_cost()), (k, i)
+            checked += 1
+    assert checked >= 64
+
+
+def test_bench_scale_large_lm_256_per_launch_three_times(oracle):
+    """BASELINE configs[4]'s graph (141 M arcs, beam 17) at bench scale: 256 utterances in one
+    launch, one per workgroup, library-default capacities (the pools and tables grow in the
+    first call), three times over -- the workload whose launches stalled in round 2 when a
+    compiler option shifted the waves' timing (the race fixed in SweepWindow).  16 sampled
+    utterances equal the canonical oracle's lattices each time."""
+    import torch
+    import bench
+    wl = bench.WORKLOADS["hlg-large"]
+    g = _bench_graph("hlg-large")
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    N, T, V = 256, wl["frames"], wl["V"]
+    lps = _logprobs(T, V, range(7000, 7000 + N), g["lexicon"])
+    dev = torch.from_numpy(np.stack(lps)).cuda()
+    oopts = {k: v for k, v in wl["opts"].items() if k != "prune_interval"}
+    lb = cabi.LatticeBatch(G, max_batch=N, max_frames=T, **wl["opts"])
+    want = {}
+    for i in range(0, N, 16):
+        can = oracle.CanonLatticeDecoder(OG, **oopts)
+        can.decode(lps[i])
+        want[i] = can.get_raw_lattice()
+    for rep in range(3):
+        lb.decode_tensor(dev)
+        assert lb.num_frames_decoded().tolist() == [T] * N
+        lats = lb.raw_lattices()
+        for i, cl in want.items():
+            assert lats[i].state_set() == cl.state_set(), (rep, i)
+            assert lats[i].arc_set() == cl.arc_set() and len(lats[i].src) == len(cl.src), (rep, i)
 
 
 @pytest.mark.parametrize("kind", ["H", "HL", "HLG"])

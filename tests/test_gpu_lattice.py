@@ -534,6 +534,60 @@ def test_lattices_exported_into_a_lent_device_buffer(oracle):
     assert _same_arrays(lb.raw_lattices()[0], want[0])
 
 
+def test_fused_log_softmax_matches_decoding_the_log_probs(oracle):
+    """kd_batch_set_log_softmax: the batch is handed LOGITS and normalises each
+    row where it stages it in LDS.  Against a decode of torch.log_softmax(logits): the same
+    1-best labels and states, per-arc costs and FinalRelativeCost within 1e-4 relative (float
+    rounding of another summation order; the tolerance north_star states for costs), for the
+    lattice decoder and the 1-best decoder, one launch and stepwise.  Switched off again the
+    batch is bit-exact with the oracle."""
+    import torch
+    g = synth.hlg_graph(V=60, n_words=400, n_hist=400, avg_succ=10, seed=7)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T, V = 5, 70, 60
+    rng = np.random.default_rng(5)
+    lps = [synth.make_logprobs(T, V, 50 + i, peak=5.0, lexicon=g["lexicon"]) for i in range(B)]
+    # logits: the log-probs shifted by an arbitrary amount per row and scaled back by softmax
+    logits = torch.from_numpy(np.stack(lps)) + torch.from_numpy(rng.normal(0, 3, (B, T, 1)).astype(np.float32))
+    logits = logits.cuda()
+    ref_lp = torch.log_softmax(logits, dim=-1)
+
+    def close(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        if a.shape != b.shape or not np.array_equal(np.isinf(a), np.isinf(b)):
+            return False
+        fin = np.isfinite(b)
+        return bool(np.all(np.abs(a[fin] - b[fin]) <= 1e-4 * np.maximum(1.0, np.abs(b[fin]))))
+
+    bt_ref, bt = cabi.Batch(G, max_batch=B, beam=11.0), cabi.Batch(G, max_batch=B, beam=11.0)
+    bt_ref.decode_tensor(ref_lp)
+    bt.set_log_softmax(True)
+    bt.decode_tensor(logits)
+    for a, b in zip(bt.best_paths(), bt_ref.best_paths()):
+        assert a.ilabel.tolist() == b.ilabel.tolist() and a.state.tolist() == b.state.tolist()
+        assert close(a.ac_cost, b.ac_cost) and close(a.graph_cost, b.graph_cost)
+    opts = dict(beam=11.0, lattice_beam=7.0, min_active=0)
+    lb_ref, lb = cabi.LatticeBatch(G, max_batch=B, **opts), cabi.LatticeBatch(G, max_batch=B, **opts)
+    lb_ref.decode_tensor(ref_lp)
+    lb.set_log_softmax(True)
+    lb.init_decoding(B)
+    while lb.num_frames_decoded()[0] < T:  # stepwise: every staging site of the row
+        lb.advance_device([logits[i].data_ptr() for i in range(B)], [T] * B, V, max_num_frames=9)
+    lb.finalize_decoding()
+    assert close(lb.final_relative_cost(), lb_ref.final_relative_cost())
+    for i in range(B):
+        a, b = lb.raw_lattices()[i], lb_ref.raw_lattices()[i]
+        # (a link a hair's breadth from the lattice beam may fall on either side of it)
+        common = {x[:6] for x in a.arc_set()} & {x[:6] for x in b.arc_set()}
+        assert len(common) >= 0.98 * max(len(a.src), len(b.src)), i
+    lb.set_log_softmax(False)
+    lb.decode_tensor(ref_lp)
+    for i in range(B):
+        can = oracle.CanonLatticeDecoder(OG, **opts)
+        can.decode(ref_lp[i].cpu().numpy())
+        _assert_same_lattice(lb.raw_lattices()[i], can.get_raw_lattice(), f"off {i}")
+
+
 def test_decode_from_host_matrices_in_one_launch(oracle):
     """kd_batch_decode with KD_MEM_HOST: the matrices are staged, then the same one-launch
     Decode (ragged lengths); lattice and 1-best batches."""
