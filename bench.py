@@ -269,7 +269,7 @@ def main():
                     help="library calls in flight, each on a batch object and stream of its own; "
                          "one host thread enqueues them (the decode call is asynchronous) and "
                          "collects them in order")
-    ap.add_argument("--min-seconds", type=float, default=2.5,
+    ap.add_argument("--min-seconds", type=float, default=6.0,
                     help="repeat the K timed steps until the timed region lasts this long")
     ap.add_argument("--prune-interval", type=int, default=0,
                     help="lattice workloads: PruneActiveTokens every this many frames (0: the "
@@ -367,7 +367,10 @@ def main():
     # and a stream of its own (sharded.ResultGatherer): the thread that enqueues the decode
     # calls never waits for another rank.  With one rank the same path runs and the exchange
     # is empty.  (1-best workloads: the label sequences, packed on the host -- a few KB.)
-    gatherer = sharded.ResultGatherer(dst=0, keep=False)
+    # (a process group of its own: the worker's collectives never interleave with the
+    # barriers and reductions the decode thread issues on the default group)
+    gather_group = dist.new_group() if world > 1 else None
+    gatherer = sharded.ResultGatherer(dst=0, group=gather_group, keep=False)
     out_bufs = None
     if wl["lattice"] and not args.search_only:
         out_bufs = [torch.zeros(per_slot << 13, dtype=torch.int64, device="cuda") for _ in range(n_fly)]
