@@ -1,6 +1,9 @@
 #!/bin/bash
-# round 3: validation of the final build -- GPU tests, minutes of fuzz, the large-LM soak,
-# then the profile round (tools/profile_round.sh rNN)
+# tools/validate_round.sh rNN -- on the GPU box (through gpurun): validation of a round's final
+# build -- GPU tests, minutes of fuzz (shipped and stress libraries), the large-LM workload
+# three times, then the profile round (tools/profile_round.sh rNN) and the bench at other
+# call shapes.
+R=${1:-r03}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 ulimit -c 0
@@ -11,11 +14,11 @@ for i in 1 2 3; do
   timeout 900 python bench.py --no-cpu --headline-only --workload hlg-large --min-seconds 1.0 > gpurun_out/r3_large_$i.json 2> /tmp/b.err
   echo "hlg-large run $i rc=$? $(python -c "import json;d=json.load(open('gpurun_out/r3_large_$i.json'));print('%.2fM kernel %.1f ms alone %.1f frac %.3f'%(d['value']/1e6, d['roofline']['kernel_ms'], d['roofline']['launch_alone']['kernel_ms'], d['roofline']['launch_alone']['frac']))" 2>/dev/null)"
 done
-bash tools/profile_round.sh rNN 2>&1 | tail -3
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/bench_${1:-r03}.json"))
-print("r03 value %.2fM ms/step %.3f kernel_ms %.1f alone %.1f frac %.3f single %.2f ms off %.2fM traffic %s cpu %s" % (d["value"]/1e6, d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["launch_alone"]["kernel_ms"], d["roofline"]["frac"], d["single_batch_ms"], (d["value_prune_interval_off"] or 0)/1e6, d["roofline"]["traffic"], d.get("cpu_baseline",{}).get("value")))
+bash tools/profile_round.sh $R 2>&1 | tail -3
+python - "$R" <<'PY'
+import json, sys
+d=json.load(open("gpurun_out/bench_%s.json" % sys.argv[1]))
+print("value %.2fM ms/step %.3f kernel_ms %.1f alone %.1f frac %.3f single %.2f ms off %.2fM traffic %s cpu %s" % (d["value"]/1e6, d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["launch_alone"]["kernel_ms"], d["roofline"]["frac"], d["single_batch_ms"], (d["value_prune_interval_off"] or 0)/1e6, d["roofline"]["traffic"], d.get("cpu_baseline",{}).get("value")))
 PY
 for args in "--steps-per-call 12 --steps 96" "--steps-per-call 16 --steps 128" "--steps-per-call 8 --inflight 3 --steps 96"; do
   timeout 300 python bench.py --no-cpu --headline-only $args > /tmp/b.json 2>/dev/null
