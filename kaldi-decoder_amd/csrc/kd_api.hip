@@ -95,8 +95,8 @@ struct kd_batch {
   DevBuf<float> lat_fbc, lat_frel;
   DevBuf<int32_t> lat_any_final, lat_finalized;
   // ---- per workgroup: spill table, candidate queue, live list, worklists
-  DevBuf<uint32_t> g_key, g_arc, g_used, g_wl, g_log_h, g_log_arc, g_log_src;
-  DevBuf<unsigned long long> g_cost, g_log_nk;
+  DevBuf<uint32_t> g_slot, g_used, g_wl, g_log_h, g_log_arc, g_log_src;
+  DevBuf<unsigned long long> g_log_nk;
   DevBuf<float> g_log_ac, g_log_gr;
   // ---- launch control: UttCtl[B] | order[B] | UttOut[B] | HostTops in pinned host memory
   // the GPU reads and writes in place; BatchCtl (the atomic counters) in device memory
@@ -149,9 +149,9 @@ struct kd_batch {
            link_delta.bytes() + frame_base.bytes() + frame_count.bytes() +
            link_emit_base.bytes() + link_eps_base.bytes() + link_emit_count.bytes() +
            link_eps_count.bytes() + frame_state_off.bytes() + frame_arc_off.bytes() +
-           g_key.bytes() + g_arc.bytes() + g_log_h.bytes() + g_log_arc.bytes() +
+           g_slot.bytes() + g_log_h.bytes() + g_log_arc.bytes() +
            g_log_src.bytes() + g_log_nk.bytes() + g_log_ac.bytes() + g_log_gr.bytes() +
-           g_used.bytes() + g_wl.bytes() + g_cost.bytes() + staging.bytes() + stats.bytes() +
+           g_used.bytes() + g_wl.bytes() + staging.bytes() + stats.bytes() +
            bctl.bytes();
   }
 
@@ -180,9 +180,7 @@ struct kd_batch {
     p.status = status.p;
     p.mem = mem.p;
     p.stats = stats.p;
-    p.g_key = g_key.p;
-    p.g_cost = g_cost.p;
-    p.g_arc = g_arc.p;
+    p.g_slot = g_slot.p;
     p.g_used = g_used.p;
     p.g_wl = g_wl.p;
     p.g_log_h = g_log_h.p;
@@ -336,14 +334,12 @@ hipError_t AllocTables(kd_batch *b, int lg) {
   // The new set is allocated before the old one is let go: if an allocation fails mid-way
   // the batch keeps its old tables (and g_log2_slots), and stays usable at its old size.
   const size_t gs = static_cast<size_t>(b->workgroups) << lg;
-  DevBuf<uint32_t> key, arc, used, wl, log_h, log_arc, log_src;
-  DevBuf<unsigned long long> cost, log_nk;
+  DevBuf<uint32_t> slot, used, wl, log_h, log_arc, log_src;
+  DevBuf<unsigned long long> log_nk;
   DevBuf<float> log_ac, log_gr;
   hipError_t e = hipSuccess;
   auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-  A(key.Alloc(gs));
-  A(cost.Alloc(gs));
-  A(arc.Alloc(gs));
+  A(slot.Alloc(4 * gs));
   A(used.Alloc(gs));
   A(wl.Alloc(2 * gs));
   A(log_h.Alloc(2 * gs));
@@ -352,13 +348,11 @@ hipError_t AllocTables(kd_batch *b, int lg) {
   A(log_nk.Alloc(2 * gs));
   if (b->lattice || b->simple) A(log_ac.Alloc(2 * gs));
   if (b->lattice) A(log_gr.Alloc(2 * gs));
-  if (e == hipSuccess) e = hipMemsetAsync(key.p, 0xFF, key.bytes(), b->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(cost.p, 0xFF, cost.bytes(), b->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(arc.p, 0xFF, arc.bytes(), b->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(slot.p, 0xFF, slot.bytes(), b->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
   if (e != hipSuccess) return e;  // (the locals free what was allocated)
   auto S = [](auto &dst, auto &src) { std::swap(dst.p, src.p); std::swap(dst.n, src.n); };
-  S(b->g_key, key); S(b->g_cost, cost); S(b->g_arc, arc); S(b->g_used, used); S(b->g_wl, wl);
+  S(b->g_slot, slot); S(b->g_used, used); S(b->g_wl, wl);
   S(b->g_log_h, log_h); S(b->g_log_arc, log_arc); S(b->g_log_src, log_src); S(b->g_log_nk, log_nk);
   S(b->g_log_ac, log_ac); S(b->g_log_gr, log_gr);
   b->g_log2_slots = lg;
@@ -857,8 +851,8 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
     KD_D(link_delta); KD_D(frame_base); KD_D(link_emit_base); KD_D(link_eps_base); KD_D(frame_count);
     KD_D(link_emit_count); KD_D(link_eps_count); KD_D(frame_state_off); KD_D(frame_arc_off);
     KD_D(frames_decoded); KD_D(status); KD_D(mem); KD_D(stats); KD_D(lat_fbc); KD_D(lat_frel);
-    KD_D(lat_any_final); KD_D(lat_finalized); KD_D(g_key); KD_D(g_arc); KD_D(g_used); KD_D(g_wl);
-    KD_D(g_log_h); KD_D(g_log_arc); KD_D(g_log_src); KD_D(g_cost); KD_D(g_log_nk); KD_D(g_log_ac);
+    KD_D(lat_any_final); KD_D(lat_finalized); KD_D(g_slot); KD_D(g_used); KD_D(g_wl);
+    KD_D(g_log_h); KD_D(g_log_arc); KD_D(g_log_src); KD_D(g_log_nk); KD_D(g_log_ac);
     KD_D(g_log_gr); KD_D(bctl);
 #undef KD_D
     D("out_pool", b->out_pool, b->out_cap * 8);

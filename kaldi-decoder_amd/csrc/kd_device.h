@@ -172,9 +172,7 @@ struct SearchParams {
   UttMem *mem;
   long long *stats;  // [batch][kStatStride]
   // per-WORKGROUP spill table (global memory) and scratch, g_slots entries each
-  uint32_t *g_key;
-  unsigned long long *g_cost;
-  uint32_t *g_arc;
+  uint32_t *g_slot;  // 16-byte slots {cost key lo, hi, state key, winning arc}
   uint32_t *g_used;
   uint32_t *g_wl;    // two worklists
   // per-workgroup candidate log, 2 * g_slots entries (both table modes)

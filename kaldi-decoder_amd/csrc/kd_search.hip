@@ -90,6 +90,9 @@ constexpr int kWaves = kBlock / 64;
 #ifndef KD_VMAX
 #define KD_VMAX 2048
 #endif
+#ifndef KD_GT_SIZE_X4
+#define KD_GT_SIZE_X4 8  // global table: at least this many quarter slots per emitting candidate
+#endif
 #ifndef KD_WG_PER_CU
 #define KD_WG_PER_CU 1
 #endif
@@ -546,33 +549,37 @@ __device__ __forceinline__ uint32_t TakeChunks(CParams &p, Shared &s, int utt, i
 }
 
 // ---- table access: LDS (ds_* ops) or global memory (L2 atomics) --------------
+// The LDS table is three arrays (bank-friendly).  The global table is an array of 16-byte
+// slots {cost key u64, state key u32, winning arc u32}: a frame scatters its tokens over
+// the table, and with one array per word every token dirtied three 64-byte sectors per
+// phase (claim + relax, resolve, clear) that the L2 wrote back in between -- 2.3 MB of
+// HBM writes per global-table frame of 7.5 k tokens, 60 % of all the kernel wrote
+// (tools/write_breakdown.sh, round 3).  One sector per token now.
 template <bool LDS>
 struct Table {
   Shared &s;
-  KD_G uint32_t *gkey;
-  KD_G unsigned long long *gcost;
-  KD_G uint32_t *garc;
+  KD_G uint32_t *gslot;  // 4 words per slot: cost (lo, hi), key, arc
   uint32_t *bitmask;
   int log2_slots;
   uint32_t mask;
 
-  __device__ __forceinline__ uint32_t *KeyP(uint32_t h) const { if constexpr (LDS) return &s.key[h]; else return ToFlat(&gkey[h]); }
-  __device__ __forceinline__ unsigned long long *CostP(uint32_t h) const { if constexpr (LDS) return &s.cost[h]; else return ToFlat(&gcost[h]); }
-  __device__ __forceinline__ uint32_t *ArcP(uint32_t h) const { if constexpr (LDS) return &s.arc[h]; else return ToFlat(&garc[h]); }
+  __device__ __forceinline__ uint32_t *KeyP(uint32_t h) const { if constexpr (LDS) return &s.key[h]; else return ToFlat(&gslot[4ull * h + 2]); }
+  __device__ __forceinline__ unsigned long long *CostP(uint32_t h) const { if constexpr (LDS) return &s.cost[h]; else return reinterpret_cast<unsigned long long *>(ToFlat(&gslot[4ull * h])); }
+  __device__ __forceinline__ uint32_t *ArcP(uint32_t h) const { if constexpr (LDS) return &s.arc[h]; else return ToFlat(&gslot[4ull * h + 3]); }
 
   // Global-table words are updated by L2 atomics, which do not refresh this
   // CU's L1: read and write them with agent-scope (sc1) accesses.
   __device__ __forceinline__ uint32_t LoadKey(uint32_t h) const {
     if constexpr (LDS) return s.key[h];
-    else return __hip_atomic_load(ToFlat(&gkey[h]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return __hip_atomic_load(KeyP(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ void StoreKey(uint32_t h, uint32_t v) const {
     if constexpr (LDS) s.key[h] = v;
-    else __hip_atomic_store(ToFlat(&gkey[h]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(KeyP(h), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ unsigned long long LoadCost(uint32_t h) const {
     if constexpr (LDS) return s.cost[h];
-    else return __hip_atomic_load(ToFlat(&gcost[h]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return __hip_atomic_load(CostP(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // The cost word as decoder M keys it.  The lattice decoders' keys live in the high
   // word (the low word is zero): the global table is asked for that word only.  (Also
@@ -583,22 +590,35 @@ struct Table {
     if constexpr (LDS || M != 1) {
       return LoadCost(h);
     } else {
-      const uint32_t hi = __hip_atomic_load(reinterpret_cast<uint32_t *>(ToFlat(&gcost[h])) + 1,
+      const uint32_t hi = __hip_atomic_load(reinterpret_cast<uint32_t *>(CostP(h)) + 1,
                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return static_cast<unsigned long long>(hi) << 32;
     }
   }
   __device__ __forceinline__ void StoreCost(uint32_t h, unsigned long long v) const {
     if constexpr (LDS) s.cost[h] = v;
-    else __hip_atomic_store(ToFlat(&gcost[h]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(CostP(h), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ uint32_t LoadArc(uint32_t h) const {
     if constexpr (LDS) return s.arc[h];
-    else return __hip_atomic_load(ToFlat(&garc[h]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return __hip_atomic_load(ArcP(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ void StoreArc(uint32_t h, uint32_t v) const {
     if constexpr (LDS) s.arc[h] = v;
-    else __hip_atomic_store(ToFlat(&garc[h]), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(ArcP(h), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // An empty slot.  (Global: one 16-byte store; stores go through to the L2, where the
+  // table's atomics and agent-scope loads see them.)
+  __device__ __forceinline__ void ClearSlot(uint32_t h) const {
+    if constexpr (LDS) {
+      s.key[h] = kKeyEmpty;
+      s.cost[h] = kCostDead;
+      s.arc[h] = kArcNone;
+    } else {
+      static_assert(kKeyEmpty == 0xFFFFFFFFu && kArcNone == 0xFFFFFFFFu && kCostDead == ~0ull, "all ones");
+      typedef uint32_t V4 __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<KD_G V4 *>(&gslot[4ull * h]) = V4{~0u, ~0u, ~0u, ~0u};
+    }
   }
   __device__ __forceinline__ uint32_t Hash(uint32_t state) const {
     return (state * 2654435761u) >> (32 - log2_slots);
@@ -1236,7 +1256,7 @@ __device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
     if ((tid & 63) == 0 && mk != kCostInf<M>) atomicMin(&s.min_new, mk);
   }
   KD_LAP(s, 2);
-  Table<true> none{s, nullptr, nullptr, nullptr, nullptr, 0, 0};
+  Table<true> none{s, nullptr, nullptr, 0, 0};
   // SimpleDecoder: a first pass only finds min total cost, the second queues what
   // is below min + beam (simple-decoder.cc:170-176 at the cutoff's final value)
 #pragma unroll 1
@@ -1282,10 +1302,7 @@ __device__ __forceinline__ void FullClear(const Table<LDS> &t, Shared &s) {
 template <bool LDS, int M>
 __device__ __forceinline__ void ClearLive(const FrameCtx<M> &c, const Table<LDS> &t, int n_live) {
   for (int i = threadIdx.x; i < n_live; i += kBlock) {
-    const uint32_t h = c.live[i];
-    t.StoreKey(h, kKeyEmpty);
-    t.StoreCost(h, kCostDead);
-    t.StoreArc(h, kArcNone);
+    t.ClearSlot(c.live[i]);
   }
 }
 
@@ -2369,11 +2386,10 @@ __device__ __noinline__ uint32_t FrameBackSpill(CParams *pp, int utt, long long 
   // the epsilon closure may add more: a frame that outgrows the guess runs again in the
   // whole table.
   int lg = 14;
-  while ((1 << lg) < 2 * q_emit && lg < p.g_log2_slots) ++lg;
+  while ((1ll << lg) * 4 < static_cast<long long>(KD_GT_SIZE_X4) * q_emit && lg < p.g_log2_slots) ++lg;
   uint32_t r;
   while (true) {
-    Table<false> tg{s, ToG(p.g_key) + wg * gslots, ToG(p.g_cost) + wg * gslots,
-                    ToG(p.g_arc) + wg * gslots, reinterpret_cast<uint32_t *>(s.cost),
+    Table<false> tg{s, ToG(p.g_slot) + 4 * wg * gslots, reinterpret_cast<uint32_t *>(s.cost),
                     lg, (1u << lg) - 1u};
     r = FrameBack<false>(c, tg, frame, q_emit, cnt);
     if (r == 0) break;
@@ -2383,11 +2399,7 @@ __device__ __noinline__ uint32_t FrameBackSpill(CParams *pp, int utt, long long 
     // the table itself has claimed slots that are on no list, so all of it is wiped.
     __syncthreads();
     if (r == kRetry) {
-      for (long long h = threadIdx.x; h < (1ll << lg); h += kBlock) {
-        tg.StoreKey(static_cast<uint32_t>(h), kKeyEmpty);
-        tg.StoreCost(static_cast<uint32_t>(h), kCostDead);
-        tg.StoreArc(static_cast<uint32_t>(h), kArcNone);
-      }
+      for (long long h = threadIdx.x; h < (1ll << lg); h += kBlock) tg.ClearSlot(static_cast<uint32_t>(h));
     } else {
       const int used = s.n_live < static_cast<int>(tg.FillLimit()) ? s.n_live
                                                                    : static_cast<int>(tg.FillLimit());
@@ -2431,7 +2443,7 @@ __device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long 
   Shared &s = Lds();
   const int tid = threadIdx.x;
   const bool filtered = flags & 1, upper_dirty = flags & 2, best_stale = flags & 4;
-  Table<true> tl{s, nullptr, nullptr, nullptr, s.bitmask, kLog2Slots, kSlots - 1};
+  Table<true> tl{s, nullptr, s.bitmask, kLog2Slots, kSlots - 1};
   FrameCtx<M> c{p, s, utt};
   InitCtx(c, p);
   c.base_in = base_in;
@@ -2548,7 +2560,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   constexpr int KD_BUCKET = kBucketBig;
   (void)KD_BUCKET;
 
-  Table<true> tl{s, nullptr, nullptr, nullptr, s.bitmask, kLog2Slots, kSlots - 1};
+  Table<true> tl{s, nullptr, s.bitmask, kLog2Slots, kSlots - 1};
   FrameCtx<M> c{p, s, utt};
   InitCtx(c, p);
 
@@ -2606,7 +2618,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   // Tier bookkeeping (all workgroup-uniform): is the frontier in LDS (left there by
   // a tier-1 frame), do the upper table halves hold tier-1 data, and is the best
   // token's arc range (the tier-2 prepass input) out of date.
-  Table<true> t1{s, nullptr, nullptr, nullptr, s.bitmask, kT1Log2, kT1Slots - 1};
+  Table<true> t1{s, nullptr, s.bitmask, kT1Log2, kT1Slots - 1};
   bool front_lds = false, upper_dirty = false, best_stale = false;
   int gen = 0;  // team barriers this wave has passed
   auto row_of = [&](int f) {
