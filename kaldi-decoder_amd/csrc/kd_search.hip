@@ -607,6 +607,19 @@ struct Table {
     if constexpr (LDS) s.arc[h] = v;
     else __hip_atomic_store(ArcP(h), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // The whole slot of the global table in one 16-byte agent-scope load (cost lo, hi, key,
+  // arc): the passes that need two or three of its words issue one L2 request, not three
+  // (8-byte and narrower sc1 accesses run at about half the 16-byte rate per access).
+  typedef uint32_t SlotV __attribute__((ext_vector_type(4)));
+  __device__ __forceinline__ SlotV LoadSlot(uint32_t h) const {
+    static_assert(!LDS, "global table only");
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+        ToFlat(gslot), 0, static_cast<int>(16u << log2_slots), 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(h << 4), 0, 16 /* sc1 */);
+  }
+  static __device__ __forceinline__ unsigned long long SlotCost(const SlotV &v) {
+    return static_cast<unsigned long long>(v.y) << 32 | v.x;
+  }
   // An empty slot.  (Global: one 16-byte store; stores go through to the L2, where the
   // table's atomics and agent-scope loads see them.)
   __device__ __forceinline__ void ClearSlot(uint32_t h) const {
@@ -974,8 +987,14 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
         ok = cst < c.weight_cutoff;  // faster-decoder.cc:202
       } else {
         const uint32_t hs = wl_in[i];
-        st = t.LoadKey(hs) & kStateMask;
-        cst = KC<M>(t.template LoadCostM<M>(hs));
+        if constexpr (LDS) {
+          st = t.LoadKey(hs) & kStateMask;
+          cst = KC<M>(t.template LoadCostM<M>(hs));
+        } else {
+          const auto sv = t.LoadSlot(hs);
+          st = sv.z & kStateMask;
+          cst = KC<M>(t.SlotCost(sv));
+        }
         srcid = hs | kSrcEps;
         ok = !(cst > c.cutoff);  // faster-decoder.cc:74
       }
@@ -1063,6 +1082,11 @@ __device__ __forceinline__ void Insert(const FrameCtx<M> &c, const Table<LDS> &t
           const int pos = AggInc(&s.n_live);
           if (static_cast<uint32_t>(pos) < t.FillLimit()) c.live[pos] = h;
           else s.overflow = 1;
+          // Global table, lattice decoders (no back-pointers: the arc word is free): the
+          // token's place in the frame's block is its place on the live list -- noted in
+          // the slot now, next to the words this insert just touched, instead of by a
+          // scattered agent-scope store per token in the compaction pass.
+          if constexpr (!LDS && M == 1) *t.ArcP(h) = static_cast<uint32_t>(pos);
           push = (k & kHasEps) != 0;  // every new token is expanded once (:63-65)
           if constexpr (EPS) {
             // a concurrent improver of this brand-new slot may already have queued it:
@@ -1329,6 +1353,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
       const uint32_t h = t.Hash(static_cast<uint32_t>(p.start));
       t.StoreKey(h, static_cast<uint32_t>(p.start) | (eps ? kHasEps : 0u));
       t.StoreCost(h, CK<M>(0.0));
+      if constexpr (!LDS && M == 1) t.StoreArc(h, 0u);  // its place in the block (see Insert)
       c.live[0] = h;
       s.n_live = 1;
       if (eps) { c.wl0[0] = h; s.wl_count[0] = 1; }
@@ -1440,9 +1465,16 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
       for (int u = 0; u < U; ++u) h[u] = c.live[i0 + u * kBlock < n_out ? i0 + u * kBlock : 0];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        ckv[u] = t.template LoadCostM<M>(h[u]);
-        kw[u] = t.LoadKey(h[u]);
-        aw[u] = M != 1 ? t.LoadArc(h[u]) : 0u;  // (lattice tokens have no back-pointers)
+        if constexpr (LDS) {
+          ckv[u] = t.template LoadCostM<M>(h[u]);
+          kw[u] = t.LoadKey(h[u]);
+          aw[u] = M != 1 ? t.LoadArc(h[u]) : 0u;  // (lattice tokens have no back-pointers)
+        } else {
+          const auto sv = t.LoadSlot(h[u]);
+          ckv[u] = t.SlotCost(sv);
+          kw[u] = sv.z;
+          aw[u] = sv.w;
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1460,7 +1492,8 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
           ToG(p.tok_prev)[g] = -1;
           ToG(p.tok_arc)[g] = -1;
         }
-        t.StoreKey(h[u], static_cast<uint32_t>(i));
+        // (global table, lattice: the slot's arc word holds i since the insert)
+        if constexpr (LDS || M != 1) t.StoreKey(h[u], static_cast<uint32_t>(i));
         if (ck < my_min) { my_min = ck; my_min_state = st_of_tok; }
       }
     }
@@ -1556,10 +1589,11 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
           const int i = i0 + u * kBlock;
           ok[u] = i < n_q && h[u] != kKeyEmpty;
           const uint32_t hd = ok[u] ? h[u] : 0u, hs = ok[u] && i >= q_emit ? sr[u] & ~kSrcEps : 0u;
-          kd[u] = t.LoadKey(hd);
-          cd[u] = t.template LoadCostM<M>(hd);
-          ks[u] = t.LoadKey(hs);
-          cs[u] = t.template LoadCostM<M>(hs);
+          const auto vd = t.LoadSlot(hd), vs = t.LoadSlot(hs);
+          kd[u] = vd.w;  // (the token's place in the block: Insert)
+          cd[u] = t.SlotCost(vd);
+          ks[u] = vs.w;
+          cs[u] = t.SlotCost(vs);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
