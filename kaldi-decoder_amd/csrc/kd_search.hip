@@ -973,18 +973,51 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
   // others from the back (two per row).  Counters and cursors of the second list,
   // by chunk parity: (it_n32, it_next32) and (it_n16, it_next16).
   if (tid == 0) { s.it_count[0] = 0; s.it_next[0] = 0; s.it_n32 = 0; s.it_next32 = 0; }
+  // The emitting filter's chain per chunk of tokens is token fields -> state record -> arcs,
+  // three dependent round trips with the workgroup's barriers between chunks.  It is
+  // software-pipelined: a chunk's arcs are requested while the NEXT chunk's state records
+  // and the one after's token fields are already in flight (loads return in order: the wait
+  // for the arcs covers them), so a chunk costs one round trip, not three.  (An index past
+  // the frontier reads record 0, which exists.)
+  [[maybe_unused]] uint32_t pf_st = 0, pf_st2 = 0;
+  [[maybe_unused]] double pf_cst = 0.0, pf_cst2 = 0.0;
+  [[maybe_unused]] bool pf_ok = false;
+  [[maybe_unused]] StateRec pf_r{};
+  if constexpr (!EPS) {
+    const long long i0 = tid < n_items ? c.base_in + tid : 0ll;
+    const long long i1 = tid + kBlock < n_items ? c.base_in + tid + kBlock : 0ll;
+    pf_st = static_cast<uint32_t>(ToG(p.tok_state)[i0]);
+    pf_cst = ToG(p.tok_cost)[i0];
+    pf_st2 = static_cast<uint32_t>(ToG(p.tok_state)[i1]);
+    pf_cst2 = ToG(p.tok_cost)[i1];
+    pf_ok = tid < n_items && pf_cst < c.weight_cutoff;  // faster-decoder.cc:202
+    pf_r = LoadState(p.states, pf_ok ? pf_st : 0u);
+  }
   LdsBarrier();
   for (int chunk = 0; chunk < n_items; chunk += kBlock, par ^= 1) {
     const int i = chunk + tid;
+    [[maybe_unused]] uint32_t cur_st = 0;
+    [[maybe_unused]] double cur_cst = 0.0;
+    [[maybe_unused]] bool cur_ok = false;
+    [[maybe_unused]] StateRec cur_r{};
+    if constexpr (!EPS) {
+      cur_st = pf_st; cur_cst = pf_cst; cur_ok = pf_ok; cur_r = pf_r;
+      pf_st = pf_st2; pf_cst = pf_cst2;
+      pf_ok = i + kBlock < n_items && pf_cst < c.weight_cutoff;
+      pf_r = LoadState(p.states, pf_ok ? pf_st : 0u);
+      const long long i2 = i + 2 * kBlock < n_items ? c.base_in + i + 2 * kBlock : 0ll;
+      pf_st2 = static_cast<uint32_t>(ToG(p.tok_state)[i2]);
+      pf_cst2 = ToG(p.tok_cost)[i2];
+    }
     if (i < n_items) {
       uint32_t st, srcid;
       double cst;
       bool ok;
       if constexpr (!EPS) {
-        st = static_cast<uint32_t>(ToG(p.tok_state)[c.base_in + i]);
-        cst = ToG(p.tok_cost)[c.base_in + i];
+        st = cur_st;
+        cst = cur_cst;
         srcid = static_cast<uint32_t>(i);
-        ok = cst < c.weight_cutoff;  // faster-decoder.cc:202
+        ok = cur_ok;
       } else {
         const uint32_t hs = wl_in[i];
         if constexpr (LDS) {
@@ -999,7 +1032,9 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
         ok = !(cst > c.cutoff);  // faster-decoder.cc:74
       }
       if (ok) {
-        const StateRec r = LoadState(p.states, st);
+        StateRec r;
+        if constexpr (!EPS) r = cur_r;
+        else r = LoadState(p.states, st);
         const int abeg = EPS ? r.emit_end : r.arc_begin;
         const int deg = EPS ? r.arc_end - r.emit_end : r.emit_end - r.arc_begin;
         if (EPS) { cnt.eps_exp += 1; cnt.eps_arcs += deg; }
