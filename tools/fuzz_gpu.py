@@ -21,7 +21,7 @@ INT_MAX = 2**31 - 1
 
 
 def graph(rng):
-    if rng.random() < 0.04:
+    if rng.random() < float(os.environ.get("KD_FUZZ_HEAVY", "0.04")):  # (share of heavy cases)
         # heavy: tens of thousands of states under flat posteriors -- frontiers far beyond
         # the LDS tiers (the global-table tier, table growth, oversized pool blocks)
         V = int(rng.integers(8, 24))
