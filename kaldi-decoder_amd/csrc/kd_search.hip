@@ -617,8 +617,51 @@ struct Table {
         ToFlat(gslot), 0, static_cast<int>(16u << log2_slots), 0x00020000);
     return __builtin_amdgcn_raw_buffer_load_b128(r, static_cast<int>(h << 4), 0, 16 /* sc1 */);
   }
+  // The slot's words by decoder.  FasterDecoder / SimpleDecoder (64-bit cost keys):
+  // {cost lo, cost hi, state key, winning arc}.  Lattice decoders (32-bit cost keys, no
+  // back-pointer): {place in the frame's block, -, cost key, state key} -- state key and
+  // cost key form ONE 64-bit word, so that a single compare-and-swap claims an empty slot
+  // AND gives it its first cost (ClaimRelaxLattice).
+  template <int M>
   static __device__ __forceinline__ unsigned long long SlotCost(const SlotV &v) {
-    return static_cast<unsigned long long>(v.y) << 32 | v.x;
+    if constexpr (M == 1) return static_cast<unsigned long long>(v.z) << 32;
+    else return static_cast<unsigned long long>(v.y) << 32 | v.x;
+  }
+  template <int M>
+  static __device__ __forceinline__ uint32_t SlotKey(const SlotV &v) { return M == 1 ? v.w : v.z; }
+  static __device__ __forceinline__ uint32_t SlotPlace(const SlotV &v) { return v.x; }  // (lattice)
+  __device__ __forceinline__ void StorePlace(uint32_t h, uint32_t place) const {
+    static_assert(!LDS, "global table only");
+    gslot[4ull * h] = place;
+  }
+  // Lattice decoders, global table: claim + relax.  The pass runs at the rate one CU issues
+  // L2 atomics, and nineteen of twenty entries that reach it are their state's first token
+  // of the frame (every entry below the cutoff is a forward link; links = 1.05 x tokens): the
+  // compare-and-swap of {state key, cost key} against "empty" settles those with ONE atomic
+  // instead of two.  A slot that already holds the state answers with its cost: only an
+  // entry that lowers it follows up with the 64-bit min (equal state keys: ordered by cost).
+  // `old`: the slot's cost key before (kCostDead: the state's first token).
+  __device__ __forceinline__ uint32_t ClaimRelaxLattice(uint32_t k, unsigned long long nk,
+                                                        unsigned long long &old) const {
+    static_assert(!LDS, "global table only");
+    const unsigned long long want = static_cast<unsigned long long>(k) << 32 | nk >> 32;
+    uint32_t h = Hash(k & kStateMask);
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+      unsigned long long *w = reinterpret_cast<unsigned long long *>(ToFlat(&gslot[4ull * h + 2]));
+      unsigned long long was = atomicCAS(w, ~0ull, want);
+      if (was == ~0ull) {
+        old = kCostDead;
+        return h;
+      }
+      if (static_cast<uint32_t>(was >> 32) == k) {
+        if (static_cast<uint32_t>(was) > static_cast<uint32_t>(want)) was = atomicMin(w, want);
+        old = (was & 0xFFFFFFFFull) << 32;
+        return h;
+      }
+      h = (h + 1) & mask;
+    }
+    old = 0;
+    return kKeyEmpty;
   }
   // An empty slot.  (Global: one 16-byte store; stores go through to the L2, where the
   // table's atomics and agent-scope loads see them.)
@@ -1025,8 +1068,8 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
           cst = KC<M>(t.template LoadCostM<M>(hs));
         } else {
           const auto sv = t.LoadSlot(hs);
-          st = sv.z & kStateMask;
-          cst = KC<M>(t.SlotCost(sv));
+          st = t.template SlotKey<M>(sv) & kStateMask;
+          cst = KC<M>(t.template SlotCost<M>(sv));
         }
         srcid = hs | kSrcEps;
         ok = !(cst > c.cutoff);  // faster-decoder.cc:74
@@ -1106,11 +1149,13 @@ __device__ __forceinline__ void Insert(const FrameCtx<M> &c, const Table<LDS> &t
     // emitting entries were queued under the running cutoff: apply the final one (:211);
     // once the frame is known not to fit, stop probing a full table
     if ((EPS || nk < cutkey) && !s.overflow) {
-      h = t.Claim(k);
+      unsigned long long old = 0;
+      if constexpr (!LDS && M == 1) h = t.ClaimRelaxLattice(k, nk, old);
+      else h = t.Claim(k);
       if (h == kKeyEmpty) {
         s.overflow = 1;
       } else {
-        const unsigned long long old = atomicMin(t.CostP(h), nk);
+        if constexpr (LDS || M != 1) old = atomicMin(t.CostP(h), nk);
         if (!EPS && c.simple && nk < s.min_stored) atomicMin(&s.min_stored, nk);
         bool push = false;
         if (old == kCostDead) {  // the state's first token this frame
@@ -1121,7 +1166,7 @@ __device__ __forceinline__ void Insert(const FrameCtx<M> &c, const Table<LDS> &t
           // token's place in the frame's block is its place on the live list -- noted in
           // the slot now, next to the words this insert just touched, instead of by a
           // scattered agent-scope store per token in the compaction pass.
-          if constexpr (!LDS && M == 1) *t.ArcP(h) = static_cast<uint32_t>(pos);
+          if constexpr (!LDS && M == 1) t.StorePlace(h, static_cast<uint32_t>(pos));
           push = (k & kHasEps) != 0;  // every new token is expanded once (:63-65)
           if constexpr (EPS) {
             // a concurrent improver of this brand-new slot may already have queued it:
@@ -1386,9 +1431,14 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
       const StateRec r = LoadState(p.states, p.start);
       const bool eps = r.arc_end > r.emit_end;
       const uint32_t h = t.Hash(static_cast<uint32_t>(p.start));
-      t.StoreKey(h, static_cast<uint32_t>(p.start) | (eps ? kHasEps : 0u));
-      t.StoreCost(h, CK<M>(0.0));
-      if constexpr (!LDS && M == 1) t.StoreArc(h, 0u);  // its place in the block (see Insert)
+      if constexpr (!LDS && M == 1) {
+        unsigned long long was;
+        t.ClaimRelaxLattice(static_cast<uint32_t>(p.start) | (eps ? kHasEps : 0u), CK<M>(0.0), was);
+        t.StorePlace(h, 0u);  // its place in the block (see Insert)
+      } else {
+        t.StoreKey(h, static_cast<uint32_t>(p.start) | (eps ? kHasEps : 0u));
+        t.StoreCost(h, CK<M>(0.0));
+      }
       c.live[0] = h;
       s.n_live = 1;
       if (eps) { c.wl0[0] = h; s.wl_count[0] = 1; }
@@ -1506,9 +1556,9 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
           aw[u] = M != 1 ? t.LoadArc(h[u]) : 0u;  // (lattice tokens have no back-pointers)
         } else {
           const auto sv = t.LoadSlot(h[u]);
-          ckv[u] = t.SlotCost(sv);
-          kw[u] = sv.z;
-          aw[u] = sv.w;
+          ckv[u] = t.template SlotCost<M>(sv);
+          kw[u] = t.template SlotKey<M>(sv);
+          aw[u] = sv.w;  // (read where M != 1)
         }
       }
 #pragma unroll
@@ -1625,10 +1675,10 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
           ok[u] = i < n_q && h[u] != kKeyEmpty;
           const uint32_t hd = ok[u] ? h[u] : 0u, hs = ok[u] && i >= q_emit ? sr[u] & ~kSrcEps : 0u;
           const auto vd = t.LoadSlot(hd), vs = t.LoadSlot(hs);
-          kd[u] = vd.w;  // (the token's place in the block: Insert)
-          cd[u] = t.SlotCost(vd);
-          ks[u] = vs.w;
-          cs[u] = t.SlotCost(vs);
+          kd[u] = t.SlotPlace(vd);  // (the token's place in the block: Insert)
+          cd[u] = t.template SlotCost<M>(vd);
+          ks[u] = t.SlotPlace(vs);
+          cs[u] = t.template SlotCost<M>(vs);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
