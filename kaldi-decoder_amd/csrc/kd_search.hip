@@ -483,9 +483,10 @@ __device__ __forceinline__ unsigned long long BlockMinU64(Shared &s, unsigned lo
 // moves, for a moment, the base of every allocation that succeeds in between, and its
 // subtraction then pulls the cursor back UNDER them (two utterances end up with the same
 // records -- seen as rare wrong lattices when a pool ran out mid-launch).
-__device__ __forceinline__ long long PoolTake(unsigned long long *top, unsigned long long base,
-                                              unsigned long long cap, unsigned long long want) {
-  unsigned long long old = atomicAdd(top, 0ull);
+__device__ __forceinline__ long long PoolTake(unsigned long long *top, unsigned long long seen_top,
+                                              unsigned long long base, unsigned long long cap,
+                                              unsigned long long want) {
+  unsigned long long old = seen_top;  // (a value the caller read a moment ago: usually still right)
   while (true) {
     if (old - base + want > cap) return -1;
     const unsigned long long seen = atomicCAS(top, old, old + want);
@@ -494,52 +495,95 @@ __device__ __forceinline__ long long PoolTake(unsigned long long *top, unsigned 
   }
 }
 
+__device__ __forceinline__ long long PoolTake(unsigned long long *top, unsigned long long base,
+                                              unsigned long long cap, unsigned long long want) {
+  return PoolTake(top, __hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), base, cap, want);
+}
+
+// What the slow path of TakeChunks reads of one pool, requested TOGETHER before any of it is
+// used: every one of these was a dependent round trip to memory of ONE lane with the whole
+// workgroup waiting at the frame's barrier -- eight of them per new chunk, 21 k cycles, 3.6 %
+// of the kernel on the bench workload (round 3, a diagnostic build that timed this function).
+struct PoolView {
+  int32_t chunk, chunk_len, n_free, n_retired;
+  unsigned long long top;
+};
+__device__ __forceinline__ PoolView LoadPoolView(CParams &p, KD_G UttMem *m, bool links) {
+  KD_G ChunkRing *ring = links ? &m->link : &m->tok;
+  PoolView v;
+  v.chunk = links ? m->link_chunk : m->arena_chunk;
+  v.chunk_len = links ? m->link_chunk_len : m->arena_chunk_len;
+  v.n_free = ring->n_free;
+  v.n_retired = ring->n_retired;
+  v.top = __hip_atomic_load(links ? &p.ctl->link_top : &p.ctl->tok_top, __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+
 // A chunk of `want` records of pool `links ? link : token`: one of the utterance's own
 // freed chunks if the request is of standard size, else the next of the pool.  -1: the
 // pool is exhausted.
-__device__ __forceinline__ long long PoolChunk(CParams &p, KD_G ChunkRing *ring, bool links,
-                                               unsigned long long want) {
+__device__ __forceinline__ long long PoolChunk(CParams &p, KD_G ChunkRing *ring, const PoolView &v,
+                                               bool links, unsigned long long want) {
   const unsigned long long standard = links ? p.link_chunk : p.tok_chunk;
-  if (want == standard && ring->n_free > 0) return ring->free_start[--ring->n_free];
+  if (want == standard && v.n_free > 0) {
+    ring->n_free = v.n_free - 1;
+    return ring->free_start[v.n_free - 1];
+  }
   unsigned long long *top = links ? &p.ctl->link_top : &p.ctl->tok_top;
   const unsigned long long base = links ? p.link_base : p.tok_base, cap = links ? p.link_cap : p.tok_cap;
-  return PoolTake(top, base, cap, want);
+  return PoolTake(top, v.top, base, cap, want);
+}
+
+__device__ __forceinline__ long long PoolChunk(CParams &p, KD_G ChunkRing *ring, bool links,
+                                               unsigned long long want) {  // (the collector's)
+  PoolView v;
+  v.chunk = -1; v.chunk_len = 0; v.n_retired = 0;
+  v.n_free = ring->n_free;
+  v.top = __hip_atomic_load(links ? &p.ctl->link_top : &p.ctl->tok_top, __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT);
+  return PoolChunk(p, ring, v, links, want);
 }
 
 // Notes a nursery chunk that is full (`last` = the last frame plus one with a block in
 // it) so that the collector can free it once that frame is archived.  A chunk taken for
 // one oversized frame is noted as the standard-size pieces it can be cut into.
-__device__ __forceinline__ void RetireChunk(KD_G ChunkRing *ring, int32_t start, int32_t len,
-                                            int32_t standard, int32_t last) {
-  if (start < 0) return;
-  for (int32_t off = 0; off + standard <= len && ring->n_retired < kChunkRing; off += standard) {
-    ring->retired_start[ring->n_retired] = start + off;
-    ring->retired_last[ring->n_retired] = last;
-    ring->n_retired++;
+__device__ __forceinline__ void RetireChunk(KD_G ChunkRing *ring, const PoolView &v, int32_t standard,
+                                            int32_t last) {
+  if (v.chunk < 0) return;
+  int32_t n = v.n_retired;
+  for (int32_t off = 0; off + standard <= v.chunk_len && n < kChunkRing; off += standard, ++n) {
+    ring->retired_start[n] = v.chunk + off;
+    ring->retired_last[n] = last;
   }  // (what does not fit the ring is not recycled: lost until InitDecoding)
+  ring->n_retired = n;
 }
 
 __device__ __forceinline__ uint32_t TakeChunks(CParams &p, Shared &s, int utt, int frame_plus_one,
                                                long long need_tokens, long long need_links) {
+  const bool new_tok = s.arena_next + need_tokens > s.arena_end;
+  const bool new_link = need_links > 0 && s.link_next + need_links > s.link_end;
+  if (!new_tok && !new_link) return 0;
   KD_G UttMem *m = ToG(p.mem) + utt;
-  if (s.arena_next + need_tokens > s.arena_end) {
+  const PoolView tv = LoadPoolView(p, m, false), lv = LoadPoolView(p, m, true);
+  if (new_tok) {
     const unsigned long long want =
         static_cast<unsigned long long>(need_tokens > p.tok_chunk ? need_tokens : p.tok_chunk);
-    const long long b = PoolChunk(p, &m->tok, false, want);
+    const long long b = PoolChunk(p, &m->tok, tv, false, want);
     if (b < 0) return KD_UTT_ARENA_FULL;
-    RetireChunk(&m->tok, m->arena_chunk, m->arena_chunk_len, p.tok_chunk, frame_plus_one - 1);
+    RetireChunk(&m->tok, tv, p.tok_chunk, frame_plus_one - 1);
     m->arena_chunk = static_cast<int32_t>(b);
     m->arena_chunk_len = static_cast<int32_t>(want);
     s.arena_next = b;
     s.arena_end = b + static_cast<long long>(want);
   }
-  if (need_links > 0 && s.link_next + need_links > s.link_end) {
+  if (new_link) {
     const unsigned long long want =
         static_cast<unsigned long long>(need_links > p.link_chunk ? need_links : p.link_chunk);
-    const long long b = PoolChunk(p, &m->link, true, want);
+    const long long b = PoolChunk(p, &m->link, lv, true, want);
     if (b < 0) return KD_UTT_LINKS_FULL;
     // (the links of frame_plus_one - 1's tokens are being written: the old chunk's last are older)
-    RetireChunk(&m->link, m->link_chunk, m->link_chunk_len, p.link_chunk, frame_plus_one - 1);
+    RetireChunk(&m->link, lv, p.link_chunk, frame_plus_one - 1);
     m->link_chunk = static_cast<int32_t>(b);
     m->link_chunk_len = static_cast<int32_t>(want);
     s.link_next = b;
@@ -550,7 +594,7 @@ __device__ __forceinline__ uint32_t TakeChunks(CParams &p, Shared &s, int utt, i
 
 // ---- table access: LDS (ds_* ops) or global memory (L2 atomics) --------------
 // The LDS table is three arrays (bank-friendly).  The global table is an array of 16-byte
-// slots {cost key u64, state key u32, winning arc u32}: a frame scatters its tokens over
+// slots (the words by decoder: SlotCost / SlotKey below): a frame scatters its tokens over
 // the table, and with one array per word every token dirtied three 64-byte sectors per
 // phase (claim + relax, resolve, clear) that the L2 wrote back in between -- 2.3 MB of
 // HBM writes per global-table frame of 7.5 k tokens, 60 % of all the kernel wrote
@@ -558,7 +602,8 @@ __device__ __forceinline__ uint32_t TakeChunks(CParams &p, Shared &s, int utt, i
 template <bool LDS>
 struct Table {
   Shared &s;
-  KD_G uint32_t *gslot;  // 4 words per slot: cost (lo, hi), key, arc
+  KD_G uint32_t *gslot;  // 4 words per slot; KeyP / CostP / ArcP and the word-wise loads and
+                         // stores below are the FasterDecoder / SimpleDecoder layout
   uint32_t *bitmask;
   int log2_slots;
   uint32_t mask;
@@ -581,17 +626,16 @@ struct Table {
     if constexpr (LDS) return s.cost[h];
     else return __hip_atomic_load(CostP(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // The cost word as decoder M keys it.  The lattice decoders' keys live in the high
-  // word (the low word is zero): the global table is asked for that word only.  (Also
-  // a necessity: this hipcc's instruction selection crashes when it narrows the 64-bit
-  // atomic load to its high half by itself.)
+  // The cost word as decoder M keys it.  The lattice decoders' keys are 32 bits wide (the
+  // high word of the LDS table's 64-bit word; a word of its own in the global table).
   template <int M>
   __device__ __forceinline__ unsigned long long LoadCostM(uint32_t h) const {
     if constexpr (LDS || M != 1) {
       return LoadCost(h);
     } else {
-      const uint32_t hi = __hip_atomic_load(reinterpret_cast<uint32_t *>(CostP(h)) + 1,
-                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (lattice layout: the cost key is the slot's third word)
+      const uint32_t hi = __hip_atomic_load(ToFlat(&gslot[4ull * h + 2]), __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
       return static_cast<unsigned long long>(hi) << 32;
     }
   }
