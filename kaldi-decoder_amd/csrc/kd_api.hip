@@ -1422,8 +1422,9 @@ int kd_batch_capacity(const kd_batch *b, int64_t *out) {
   out[1] = static_cast<int64_t>(b->link_cap);
   out[2] = 1ll << b->g_log2_slots;
   out[3] = b->o.max_frames;
-  out[4] = static_cast<int64_t>(b->h_tok_top);
-  out[5] = static_cast<int64_t>(b->h_link_top);
+  // (a take that did not fit leaves the cursor beyond the capacity: kd_search.hip PoolChunk)
+  out[4] = static_cast<int64_t>(std::min<uint64_t>(b->h_tok_top, b->tok_cap));
+  out[5] = static_cast<int64_t>(std::min<uint64_t>(b->h_link_top, b->link_cap));
   out[6] = b->grow_events;
   out[7] = b->workgroups;
   return KD_OK;

@@ -532,7 +532,19 @@ __device__ __forceinline__ long long PoolChunk(CParams &p, KD_G ChunkRing *ring,
   }
   unsigned long long *top = links ? &p.ctl->link_top : &p.ctl->tok_top;
   const unsigned long long base = links ? p.link_base : p.tok_base, cap = links ? p.link_cap : p.tok_cap;
-  return PoolTake(top, v.top, base, cap, want);
+  // ONE atomic add, no compare-and-swap loop: a thousand utterances take a chunk every few
+  // microseconds between them, a round trip to the cursor takes a few microseconds under
+  // load, and a compare-and-swap from a value that old mostly fails -- a take cost 5-10 round
+  // trips of one lane with its workgroup waiting at the frame's barrier (30 k cycles; 8 % of
+  // the kernel in a diagnostic build that timed it, round 3).  The cursor is never taken back
+  // (PoolTake says why it must not be): a take that does not fit leaves it beyond `cap`, where
+  // every later take fails its check -- which is what an exhausted pool means -- and the few
+  // records between the last block handed out and `cap` stay unused until the host has grown
+  // the pool (kd_api.hip clamps the cursor it reads to the capacity).
+  if (v.top - base + want > cap) return -1;  // (already exhausted: do not push the cursor further)
+  const unsigned long long old = atomicAdd(top, want);
+  if (old - base + want > cap) return -1;
+  return static_cast<long long>(old - base);
 }
 
 __device__ __forceinline__ long long PoolChunk(CParams &p, KD_G ChunkRing *ring, bool links,
