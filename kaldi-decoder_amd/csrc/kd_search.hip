@@ -112,6 +112,10 @@ constexpr int kPfRegs = (kVmax + KD_BLOCK - 1) / KD_BLOCK;
 #endif
 constexpr int kSmallDeg = KD_SMALL_DEG;  // tokens with at most this many arcs stay on their lane
 constexpr int kGroup = KD_GROUP;  // queued tokens a wave scores at a time
+#ifndef KD_BIG_GROUP
+#define KD_BIG_GROUP KD_GROUP
+#endif
+constexpr int kBigGroup = KD_BIG_GROUP;  // ... in the big tiers' filter (BigLoop)
 // Tier 1 (frames whose frontier is at most one token per lane -- 97% of the frames
 // of an HLG decode): the lower half of the table arrays is a 4096-slot table, the
 // upper half holds the first kQL entries of the candidate queue, and the frontier
@@ -978,27 +982,27 @@ __device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int32_t *next, int
   const int lane = threadIdx.x & 63;
   while (true) {
     int q0 = 0;
-    if (lane == 0) q0 = atomicAdd(next, kGroup * kPer);
+    if (lane == 0) q0 = atomicAdd(next, kBigGroup * kPer);
     q0 = __builtin_amdgcn_readfirstlane(q0);
     if (q0 >= nq) break;
-    ArcRec ar[kGroup];
-    int abeg[kGroup], deg[kGroup], item[kGroup];
+    ArcRec ar[kBigGroup];
+    int abeg[kBigGroup], deg[kBigGroup], item[kBigGroup];
 #pragma unroll
-    for (int g = 0; g < kGroup; ++g) {
+    for (int g = 0; g < kBigGroup; ++g) {
       const int q = q0 + g * kPer + lane / W;
       item[g] = q < nq ? q : q0;  // (entry q0 exists: a slot past the end reads it)
       range(item[g], abeg[g], deg[g]);
       if (q >= nq) deg[g] = 0;
     }
 #pragma unroll
-    for (int g = 0; g < kGroup; ++g)
+    for (int g = 0; g < kBigGroup; ++g)
       ar[g] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg[g] + lane % W), lane % W < deg[g], 0u);
     if constexpr (!T1 && (EPS || M != 2)) {
-      uint32_t aidx[kGroup], src[kGroup];
-      bool on[kGroup];
-      double cst[kGroup];
+      uint32_t aidx[kBigGroup], src[kBigGroup];
+      bool on[kBigGroup];
+      double cst[kBigGroup];
 #pragma unroll
-      for (int g = 0; g < kGroup; ++g) {
+      for (int g = 0; g < kBigGroup; ++g) {
         on[g] = lane % W < deg[g];
         aidx[g] = static_cast<uint32_t>(abeg[g] + lane % W);
         source(item[g], cst[g], src[g]);
@@ -1006,7 +1010,7 @@ __device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int32_t *next, int
       ScoreBatchBig<EPS>(c, ar, aidx, on, cst, src);
     } else {
 #pragma unroll
-      for (int g = 0; g < kGroup; ++g)
+      for (int g = 0; g < kBigGroup; ++g)
         if (lane % W < deg[g]) {
           double cst;
           uint32_t srcid;
@@ -1018,7 +1022,7 @@ __device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int32_t *next, int
     if constexpr (W == 64) {
       // tails of tokens with more than 64 arcs, four wave-rows in flight
 #pragma unroll 1
-      for (int g = 0; g < kGroup; ++g) {
+      for (int g = 0; g < kBigGroup; ++g) {
         if (deg[g] <= 64) continue;
         double cst;
         uint32_t srcid;
