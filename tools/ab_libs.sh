@@ -14,7 +14,7 @@ for rep in 1 2; do
 import json, sys
 d = json.loads(open("/tmp/ab.json").read().strip().splitlines()[-1])
 print("%-22s %.2f M  ms/step %.3f  launch %.1f ms" % (sys.argv[1], d["value"] / 1e6, d["ms_per_step"],
-      d["roofline"].get("launch_ms", 0) or 0))
+      d["roofline"].get("kernel_ms", 0) or 0))
 PY
     else echo "$lib rc=$rc"; tail -3 /tmp/ab.err; fi
   done
