@@ -122,6 +122,49 @@ def test_lattice_frames_that_spill_to_the_global_table(oracle):
     assert len(gl.src) == len(cl.src)  # no duplicate arcs
 
 
+def _fan_graph(n, V):
+    """Start state with `n` epsilon arcs (distinct weights) into states that each have two
+    emitting arcs into a chain of final states: InitDecoding's epsilon closure alone holds
+    n + 1 tokens."""
+    arcs = []
+    for i in range(n):
+        arcs.append((0, 1 + i, 0, 0, 0.25 * (i % 7)))
+        arcs.append((1 + i, n + 1 + (i % 5), 1 + i % V, 1 + i % 3, 0.5 * (i % 3)))
+        arcs.append((1 + i, n + 1 + ((i + 2) % 5), 1 + (i + 1) % V, 0, 0.125))
+    for j in range(5):
+        arcs.append((n + 1 + j, n + 1 + (j + 1) % 5, 1 + j % V, 0, 0.25))
+    return synth.graph_from_arcs(n + 6, 0, arcs, {n + 1 + j: 0.5 * j for j in range(5)})
+
+
+@pytest.mark.parametrize("n", [3000, 7000])
+def test_init_decoding_closure_beyond_the_lds_tables(oracle, n):
+    # the start state's epsilon closure does not fit the LDS-resident tier (n = 3000: the
+    # big LDS table) nor the LDS table at all (n = 7000: the global table, where a lattice
+    # token's slot is claimed and given its cost by ONE compare-and-swap and its place in the
+    # block is noted at insert -- InitDecoding takes that path through code of its own)
+    V = 8
+    g = _fan_graph(n, V)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lp = synth.make_logprobs(4, V, 3, peak=1.0)
+    opts = dict(beam=1000.0, lattice_beam=1000.0, min_active=0)
+    lb = cabi.LatticeBatch(G, max_batch=1, **opts)
+    lb.decode_host([lp])
+    can = oracle.CanonLatticeDecoder(OG, **opts)
+    can.decode(lp)
+    _assert_same_lattice(lb.raw_lattices()[0], can.get_raw_lattice(), f"fan {n}")
+    assert len(lb.raw_lattices()[0].src) > n  # the closure's links are all there
+    st = dict(zip(cabi.STAT_NAMES, lb.stats()[0].tolist()))
+    assert (st["spill_frames"] > 0) == (n > 6144), st  # (the global table: InitDecoding included)
+    # FasterDecoder through the same tiers (its slots keep the 64-bit cost key layout)
+    bt = cabi.Batch(G, max_batch=1, beam=1000.0, min_active=0)
+    bt.init_decoding()
+    s0, c0 = bt.frame_tokens(0, 0)
+    d = oracle.FasterDecoder(OG, policy=1, beam=1000.0, min_active=0)
+    d.init_decoding()
+    so, co = d.tokens()
+    assert len(so) == n + 1 and s0.tolist() == so.tolist() and c0.tolist() == co.tolist()
+
+
 def test_bench_size_workload_matches_canonical_oracle(oracle):
     # BASELINE configs[2] at full size (4.9 M states, beam 15, lattice beam 8, T = 250), a few
     # utterances: every tier of the search runs here (frontiers from 1 to > 20 000 tokens)
