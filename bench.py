@@ -94,6 +94,8 @@ def profiled_traffic(workload_desc, utt_frames_per_launch, prune_interval):
         cfg = line.get("config", {})
         if cfg.get("workload") != workload_desc or cfg.get("prune_interval") != prune_interval:
             continue
+        if "hbm_bytes_per_launch" not in d:  # (a trace-only summary: no counter passes)
+            continue
         theirs = line.get("roofline", {}).get("utterance_frames_per_launch")
         src = os.path.basename(path)
         if theirs and theirs != utt_frames_per_launch:

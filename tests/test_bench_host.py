@@ -34,6 +34,14 @@ def test_traffic_comes_from_a_summary_of_the_same_workload_and_options(tmp_path,
     # other options or another workload: no figure rather than a wrong one
     assert bench.profiled_traffic("W", 256000, 1 << 20) is None
     assert bench.profiled_traffic("other", 256000, 25) is None
+    # a trace-only summary of the workload (no counter passes, e.g. r03_hlg_large_summary.json)
+    # is passed over, whichever way the file names sort
+    line2 = {"config": {"workload": "L", "prune_interval": 25},
+             "roofline": {"utterance_frames_per_launch": 256000}}
+    (prof / "r07_large_summary.json").write_text(json.dumps({"bench_line_under_profiler": line2}))
+    (prof / "r08_w_trace_summary.json").write_text(json.dumps({"bench_line_under_profiler": line}))
+    assert bench.profiled_traffic("L", 256000, 25) is None
+    assert bench.profiled_traffic("W", 256000, 25) == (64e9, "r07_summary.json")
 
 
 def test_committed_summary_matches_the_bench_line_next_to_it():
