@@ -261,6 +261,74 @@ def test_oracle_prune_active_tokens_stops_early(oracle):
     assert c.get_raw_lattice().arc_set() == AFTER_F
 
 
+# ---------------------------------------------------------------------------------------
+# Graph H: PruneForwardLinksFinal's "iterate until nothing changes" loop (ref:
+# lattice-simple-decoder.cc:425-520) -- a link that is excised only in the SECOND pass,
+# because the first pass read its destination's extra cost before that was computed (the
+# frame's token list is not in topological order, :437-440).  One frame, V = 3,
+# log-likelihoods -0.5 / -0.25 / -0.125 (acoustic costs 0.5 / 0.25 / 0.125), beam 16.
+#   state 0 (start)  a0 1:1/1.0 -> 1 (B)   a1 2:2/0.5 -> 2 (A)   a2 3:3/0.375 -> 3 (C)
+#   state 2 (A)      a3 eps:4/0.25 -> 1 (B)
+#   final: B 0, A 2.0, C 0
+# ProcessEmitting (:364-402) walks a0, a1, a2: tokens B 1.5, A 0.75, C 0.5, each PREPENDED to
+# the frame's list (:95-96): the list is C, A, B.  ProcessNonemitting (:122-191): only state 2
+# has an epsilon arc; A -> B costs 0.75 + 0.25 = 1.0 < 1.5: B's tot_cost becomes 1.0 (:104-107)
+# and the link A -> B (graph 0.25, ac 0) is kept.  Links of the start token: ->B (1.0, 0.5),
+# ->A (0.5, 0.25), ->C (0.375, 0.125).
+# ComputeFinalCosts (:522-560): B 1.0, A 2.75, C 0.5: final_best_cost 0.5, best_cost 0.5,
+# FinalRelativeCost 0.  Every token's extra_cost is still the 0 it was created with.
+#  lattice_beam 0.5:
+#   pass 1  C: 0.5 + 0 - 0.5 = 0, unchanged.   A: starts at 0.75 + 2 - 0.5 = 2.25; link A->B:
+#           B.extra (STALE 0) + ((0.75 + 0 + 0.25) - 1.0) = 0: kept, extra 0, unchanged.
+#           B: 1.0 + 0 - 0.5 = 0.5, not > 0.5: extra 0.5, changed.
+#   pass 2  A: link A->B: 0.5 + 0 = 0.5, not > 0.5: kept; extra min(2.25, 0.5) = 0.5, changed.
+#   pass 3  nothing changes.
+#   PruneForwardLinks(0) (:228-305): ->B: 0.5 + ((0 + 0.5 + 1.0) - 1.0) = 1.0 > 0.5 EXCISED (B
+#   is reached 0.5 cheaper through A);  ->A: 0.5 + 0 = 0.5 kept;  ->C: 0 kept.  No token has
+#   extra +inf: four states, THREE arcs, finals B 0 / A 2 / C 0.
+#  lattice_beam 0.375:
+#   pass 1  A: link A->B at the stale 0: kept, extra 0.   B: 0.5 > 0.375: extra +inf, changed.
+#   pass 2  A: link A->B: +inf > 0.375: EXCISED NOW; extra 2.25 > 0.375: +inf, changed.
+#   pass 3  nothing changes.
+#   PruneForwardLinks(0): ->B and ->A excised (+inf), ->C kept; PruneTokensForFrame(1)
+#   (:310-334) deletes A and B: two states, ONE arc, final C 0.
+def graph_h():
+    arcs = [(0, 1, 1, 1, 1.0), (0, 2, 2, 2, 0.5), (0, 3, 3, 3, 0.375), (2, 1, 0, 4, 0.25)]
+    return synth.graph_from_arcs(4, 0, arcs, {1: 0.0, 2: 2.0, 3: 0.0})
+
+
+LP_H = np.array([[-0.5, -0.25, -0.125]], np.float32)
+ARCS_H = {
+    "0B": (0, 0, 1, 1, 1, 1, 1.0, 0.5), "0A": (0, 0, 1, 2, 2, 2, 0.5, 0.25),
+    "0C": (0, 0, 1, 3, 3, 3, 0.375, 0.125), "AB": (1, 2, 1, 1, 0, 4, 0.25, 0.0),
+}
+# lattice_beam -> (arcs, finals) after FinalizeDecoding
+AFTER_H = {
+    0.5: ({ARCS_H[k] for k in ("0A", "0C", "AB")}, {(1, 0.0), (2, 2.0), (3, 0.0)}),
+    0.375: ({ARCS_H["0C"]}, {(3, 0.0)}),
+}
+
+
+@pytest.mark.parametrize("lattice_beam", [0.5, 0.375])
+def test_oracle_final_pruning_needs_a_second_pass(oracle, lattice_beam):
+    G = oracle.Graph(graph_h())
+    arcs, finals = AFTER_H[lattice_beam]
+    d = oracle.LatticeSimpleDecoder(G, beam=16.0, lattice_beam=lattice_beam)
+    d.decode_nofinal(LP_H)
+    lat = d.get_raw_lattice(True)
+    assert lat.arc_set() == set(ARCS_H.values())  # nothing pruned before FinalizeDecoding
+    assert lat.final_set() == {(1, 0.0), (2, 2.0), (3, 0.0)}
+    assert d.final_relative_cost() == 0.0
+    d.finalize_decoding()
+    lat = d.get_raw_lattice(True)
+    assert lat.arc_set() == arcs and lat.final_set() == finals
+    assert lat.num_states == 1 + len(finals)
+    c = oracle.CanonLatticeDecoder(G, beam=16.0, lattice_beam=lattice_beam)
+    c.decode(LP_H)
+    lat = c.get_raw_lattice()
+    assert lat.arc_set() == arcs and lat.final_set() == finals
+
+
 # ---- the same cases through the C ABI on the GPU ---------------------------------------
 @pytest.mark.gpu
 def test_gpu_hashlist_order_extra(oracle):
@@ -334,3 +402,27 @@ def test_gpu_prune_active_tokens_stops_early(chunk):
     lb.init_decoding()
     lb.advance_host([LP_F])
     assert lb.raw_lattices()[0].arc_set() == AFTER_F
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lattice_beam", [0.5, 0.375])
+def test_gpu_final_pruning_needs_a_second_pass(lattice_beam):
+    from kaldi_decoder import cabi
+    arcs, finals = AFTER_H[lattice_beam]
+    G = cabi.Graph(graph_h())
+    lb = cabi.LatticeBatch(G, max_batch=1, beam=16.0, lattice_beam=lattice_beam, min_active=0)
+    lb.init_decoding()
+    lb.advance_host([LP_H])
+    lat = lb.raw_lattices()[0]
+    assert lat.arc_set() == set(ARCS_H.values())
+    assert lat.final_set() == {(1, 0.0), (2, 2.0), (3, 0.0)}
+    assert lb.final_relative_cost().tolist() == [0.0]
+    lb.finalize_decoding()
+    lat = lb.raw_lattices()[0]
+    assert lat.arc_set() == arcs and lat.final_set() == finals
+    assert lat.num_states == 1 + len(finals)
+    # Decode(): the same in one launch
+    lb = cabi.LatticeBatch(G, max_batch=1, beam=16.0, lattice_beam=lattice_beam, min_active=0)
+    lb.decode_host([LP_H])
+    lat = lb.raw_lattices()[0]
+    assert lat.arc_set() == arcs and lat.final_set() == finals
