@@ -251,6 +251,25 @@ def _cpu_worker(idx):
     return frames, t0, time.perf_counter()
 
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): start the N
+    ranks as a CHILD `python -m torch.distributed.run` of this same command line and exit with
+    its code.  Nothing here has imported torch or made a HIP call -- a process that has touched
+    the GPU must never be replaced by another (no exec), and this one has not and does not."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this host driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    # stdout is inherited: rank 0's JSON line is this process's JSON line
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -278,7 +297,21 @@ def main():
                          "workload's setting)")
     ap.add_argument("--search-only", action="store_true",
                     help="diagnostic: time InitDecoding + AdvanceDecoding only (not a bench line)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the result gather: nccl (= RCCL, the product) "
+                         "or gloo (tests: the exchange crosses host memory)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="test only: every rank uses GPU 0 (needs --backend gloo: RCCL refuses two "
+                         "ranks on one device) -- the world > 1 code path on a one-GPU box")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="after the timed region every rank sends one more call's lattices through "
+                         "the gather; rank 0 decodes the other ranks' utterances itself and compares "
+                         "what arrived with that, array for array (`gather_verified` in the line)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
+    if args.one_device and args.backend != "gloo":
+        raise SystemExit("--one-device needs --backend gloo")
 
     from kaldi_decoder import synth
     rank = int(os.environ.get("RANK", "0"))
@@ -288,7 +321,7 @@ def main():
     # The CPU leg's worker processes are forked HERE, before this process loads the HIP
     # runtime: they inherit the graph and the sample's log-probs and never touch the GPU.
     cpu_pool = None
-    if rank == 0 and not args.no_cpu and not args.search_only and args.gpus == 1:
+    if rank == 0 and not args.no_cpu and not args.search_only:
         import multiprocessing
         B0, T0, V0 = args.batch or wl["batch"], wl["frames"], wl["V"]
         n_sample = max(1, args.steps_per_call) * B0
@@ -308,10 +341,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)  # (before any other HIP call of this process)
-    if world > 1:
+    if world > 1 and args.backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif world > 1:
+        dist.init_process_group("gloo")
+    # the few control words the ranks exchange (repeat count, times) live where the backend
+    # wants them: device memory for RCCL, host memory for gloo
+    ctl_dev = "cuda" if args.backend == "nccl" else "cpu"
 
     B = args.batch or wl["batch"]
     T, V = wl["frames"], wl["V"]
@@ -430,6 +470,45 @@ def main():
         gatherer.flush()  # (the exchange of every call of this run has completed)
         return res
 
+    def verify_gather():
+        """One more call per rank through the gather, kept on rank 0, which then decodes every
+        other rank's utterances of that call ITSELF and compares what arrived with its own
+        export, array for array: the exchange hands over the right bytes of the right rank."""
+        if out_bufs is None:
+            return None
+        vg = sharded.ResultGatherer(dst=0, group=gather_group, keep=True)
+        call(0, G)
+        used, table = bts[0].raw_lattice_table()
+        with torch.cuda.stream(streams[0]):
+            payload = sharded.pool_payload(out_bufs[0], used, table)
+            ready = torch.cuda.Event()
+            ready.record(streams[0])
+        vg.submit(payload, ready)
+        got = vg.close()
+        if rank != 0:
+            return None
+        fields = ("src", "dst", "ilabel", "olabel", "graph_cost", "ac_cost", "state_frame",
+                  "state_graph", "final_state", "final_graph")
+        bad = n_utts = 0
+        for r in range(world):
+            theirs = sharded.unpack_pool(got[0][r])
+            if r == 0:
+                mine = bts[0].raw_lattices()
+            else:
+                lps_r = [synth.make_logprobs(T, V, u, peak=12.0, lexicon=g["lexicon"])
+                         for u in range(r * n_fly * per_slot, r * n_fly * per_slot + per_slot)]
+                dev_r = torch.from_numpy(np.stack(lps_r)).cuda()
+                bts[0].decode_device([dev_r[i].data_ptr() for i in range(per_slot)], [T] * per_slot, V)
+                mine = bts[0].raw_lattices()
+            assert len(theirs) == len(mine) == per_slot
+            for i in range(per_slot):
+                a, b = theirs[i], mine[i]
+                n_utts += 1
+                if a.num_states != b.num_states or a.start != b.start or not all(
+                        np.array_equal(getattr(a, f), getattr(b, f)) for f in fields):
+                    bad += 1
+        return dict(ranks=world, utterances=n_utts, mismatches=bad)
+
     # every slot's batch gets at least one untimed full call when warmup is requested
     # (first launches fault in the pools and size the read-back buffers)
     run_steps(max(args.warmup, 2 * n_fly * G if args.warmup else 0))
@@ -444,7 +523,7 @@ def main():
     t_probe = time.perf_counter() - t_probe
     repeats = max(1, int(np.ceil(args.min_seconds / max(t_probe, 1e-6))))
     if world > 1:  # every rank must run the same number of collectives
-        tr = torch.tensor([repeats], dtype=torch.int64, device="cuda")
+        tr = torch.tensor([repeats], dtype=torch.int64, device=ctl_dev)
         dist.all_reduce(tr, op=dist.ReduceOp.MAX)
         repeats = int(tr.item())
     steps_timed = args.steps * repeats
@@ -543,10 +622,15 @@ def main():
         single.append(((time.perf_counter() - t1) * 1e3, k1))
     single_batch_ms = float(np.median([a for a, _ in single]))
     single_kernel_ms = float(np.median([b for _, b in single]))
+    per_rank_elapsed = [elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
+        ts_all = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts_all, t)
+        per_rank_elapsed = [float(x.item()) for x in ts_all]
+        elapsed = max(per_rank_elapsed)  # (the job is as slow as its slowest rank)
+    gather_ms = gatherer.mean_ms()
+    verified = verify_gather() if args.verify_gather else None
 
     if rank == 0 and args.search_only:
         print(json.dumps({"diagnostic": "search only", "ms_per_step": elapsed / steps_timed * 1e3,
@@ -565,6 +649,12 @@ def main():
             "value": frames_total * SUBSAMPLING / elapsed,
             "unit": "audio_frames/s",
             "n_gpus": world,
+            # every rank's own figure (its utterances over its own time); `value` is all
+            # ranks' utterances over the slowest rank's time
+            "per_rank_value": [B * T * steps_timed * SUBSAMPLING / e for e in per_rank_elapsed],
+            "gather_ms_per_call": gather_ms,
+            "gather_backend": (args.backend if world > 1 else None),
+            "gather_verified": verified,
             # `steps` is what --steps asked for; the timed region repeats them `repeats` times
             # (until it lasts --min-seconds): `steps_timed` steps went into `value`
             "steps": args.steps,
@@ -633,4 +723,18 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # one rank of several failing must end the job, not leave the others waiting in a
+        # collective until its timeout: torch.distributed.run tears the group down when a
+        # rank exits non-zero -- so exit now, without the interpreter's orderly shutdown
+        # (which would join the gather thread and the process group first)
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            os._exit(1)
+        raise

@@ -203,6 +203,8 @@ def gather_exact(payload, dst=0, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return [payload]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if payload.is_cuda and dist.get_backend(group) == "gloo":
+        payload = payload.cpu()  # (gloo's wire is host memory; RCCL takes the device tensor as it is)
     n = torch.tensor([payload.numel()], dtype=torch.int64, device=payload.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
@@ -241,6 +243,7 @@ class ResultGatherer:
         self.results = []
         self.error = None
         self.n = 0
+        self.seconds = []  # (per call: the exchange as the worker saw it, waits included)
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
 
@@ -253,6 +256,8 @@ class ResultGatherer:
                 if item is None:
                     return
                 seq, payload, ready = item
+                import time
+                t0 = time.perf_counter()
                 if payload.is_cuda:
                     if stream is None:
                         torch.cuda.set_device(payload.device)
@@ -264,6 +269,7 @@ class ResultGatherer:
                     stream.synchronize()
                 else:
                     got = gather_exact(payload, self.dst, self.group)
+                self.seconds.append(time.perf_counter() - t0)
                 if self.keep and got is not None:
                     self.results.append(got)
                 if self.on_done is not None:
@@ -277,6 +283,10 @@ class ResultGatherer:
         self.n += 1
         self.q.put((seq, payload, ready))
         return seq
+
+    def mean_ms(self):
+        """Mean duration of an exchange on the worker thread, in ms (None before the first)."""
+        return 1e3 * sum(self.seconds) / len(self.seconds) if self.seconds else None
 
     def flush(self):
         """Waits until everything submitted so far has been gathered."""

@@ -80,3 +80,36 @@ def test_the_barrier_that_the_spill_option_depends_on_is_in_place():
     # (comment lines out: the barrier call itself must precede the builder)
     code = "\n".join(ln for ln in body.splitlines() if not ln.strip().startswith("//"))
     assert "LdsBarrier();" in code and code.index("LdsBarrier();") < code.index("if (tid < 64) {")
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 8` as the driver may run it (no torchrun around it, WORLD_SIZE
+    unset): bench.py starts `python -m torch.distributed.run` on its own command line as a child
+    process -- before torch is imported or any HIP call is made -- and exits with its code."""
+    import subprocess
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "16", "--warmup", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    had_torch = "torch" in sys.modules
+    try:
+        bench.main()
+        raise AssertionError("main() should have exited with the child's code")
+    except SystemExit as e:
+        assert e.code == 7
+    assert had_torch or "torch" not in sys.modules  # (nothing was imported on the way)
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "8", "--steps", "16", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
