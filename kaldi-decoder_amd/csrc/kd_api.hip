@@ -132,6 +132,7 @@ struct kd_batch {
   bool initialized = false, path_valid = false, pending = false;
   int32_t path_use_final = -1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev_staged = nullptr;  // behind the last host-to-device copy of a staged call
   bool timed = false;
   int grow_events = 0;
 
@@ -140,6 +141,7 @@ struct kd_batch {
     if (ctl_host) (void)hipHostFree(ctl_host);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev_staged) (void)hipEventDestroy(ev_staged);
   }
 
   size_t DeviceBytes() const {
@@ -808,6 +810,7 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   b->h_lat_arena.assign(max_batch, 0);
   if (e == hipSuccess) e = hipEventCreate(&b->ev0);
   if (e == hipSuccess) e = hipEventCreate(&b->ev1);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming);
   if (e == hipSuccess && lopts) {
     uint64_t links = lopts->arena_links > 0 ? static_cast<uint64_t>(lopts->arena_links) : 2 * b->tok_cap;
     b->link_cap = std::min<uint64_t>(links, kIndexLimit);
@@ -1010,6 +1013,16 @@ static int StageHost(kd_batch *b, const float *const *loglikes, int32_t num_cols
     }
     uc[i].ll = b->staging.p + pos - first[i] * static_cast<size_t>(num_cols);
     pos += count[i] * num_cols;
+  }
+  // The contract of every staged call: when it returns, the rows have LEFT the caller's
+  // memory (ref: DecodableCtc copies its matrix, csrc/decodable-ctc.h:15-16).  From pageable
+  // memory HIP's copy blocks the host anyway; from pinned memory (hipHostMalloc,
+  // hipHostRegister, torch pin_memory) it is truly asynchronous, and a caller that refills its
+  // buffer for the next call would overwrite rows still on their way.  Wait for the last copy
+  // -- not for the launch, which is enqueued behind it.
+  if (total > 0) {
+    KD_HIP_TRY(hipEventRecord(b->ev_staged, b->stream));
+    KD_HIP_TRY(hipEventSynchronize(b->ev_staged));
   }
   return KD_OK;
 }

@@ -56,18 +56,6 @@
 namespace kd {
 namespace {
 
-// The wave tier (kd_wave_tier.h: a frame of at most 64 tokens run by ONE wave, without
-// workgroup barriers) is an experiment of round 3 that is NOT in the shipped build.  With the
-// first wave running such frames alone the bench lost 6 % (31.5 M against 33.7 M audio
-// frames/s): one wave's frame is as long a chain of dependent memory and LDS round trips
-// (~40 k cycles) as the workgroup's.  With one utterance per wave, twelve per workgroup
-// (tools/experiments/wave_slots_stage2.patch), a launch of 768 utterances took 35 ms against
-// 30 ms: everything beyond the wave tier -- larger frames, PruneActiveTokens, the tails: 9 of
-// the 16 M cycles of an utterance -- still needs the whole workgroup and serialises the slots.
-// DESIGN.md section 5.  `make knob NAME=wave KNOBS=-DKD_WAVE_TIER` builds the first variant.
-#ifndef KD_WAVE_TIER
-#define KD_NO_WAVE_TIER
-#endif
 #ifndef KD_BLOCK
 #define KD_BLOCK 768
 #endif
@@ -2694,7 +2682,6 @@ __device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long 
 
 #include "kd_lattice_tail.h"
 #include "kd_path_tail.h"
-#include "kd_wave_tier.h"
 
 // Fused log-softmax (kd_batch_set_log_softmax): the caller's matrices hold
 // logits, and the row a frame reads is normalised where it already sits -- in LDS -- by the
@@ -2819,10 +2806,6 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   __syncthreads();
   Counters tot;  // per-lane work counters of the small frames, folded when the launch ends
   int visited = do_init ? -1 : Uni(ToG(p.mem)[utt].visited);
-  // wave tier (kd_wave_tier.h): frames of at most 64 tokens are run by the first wave alone
-  WaveFront wfr{0u, 0.0f, 0, 0};
-  WaveStats wst;
-  bool wv_front = false, wv_clean = false;  // the frontier is in wave 0's lanes / its table is empty
 
   while (err == 0 && frame < target) {
     if constexpr (M == 1) {
@@ -2849,8 +2832,6 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
         FullClear<true>(tl, s);
         front_lds = false;
         upper_dirty = false;
-        wv_front = false;
-        wv_clean = false;
         KD_LAP(s, 23);
         if (pe) { err |= pe; break; }
       }
@@ -2862,49 +2843,6 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     uint32_t r = kRetry;
     int q_emit = 0;
     bool filtered = false;  // the emitting filter already ran (tier 1 did not fit)
-#ifndef KD_NO_WAVE_TIER
-    if constexpr (M == 1) {
-      if (frame >= 0 && c.n_in <= kWvFront && c.ll_in_lds && WaveCutoffOk(p, c.n_in)) {
-        // (the wave's LDS: the upper half of the cost array -- tier-1's queue region)
-        WaveLds &w = *reinterpret_cast<WaveLds *>(&s.cost[kT1Slots]);
-        static_assert(sizeof(WaveLds) <= sizeof(unsigned long long) * kT1Slots, "wave region");
-        if (tid < 64) {
-          if (!wv_clean) WaveClearTable(w);
-          if (!wv_front) WaveLoadFront<M>(p, c.base_in, c.n_in, wfr);
-          int n = c.n_in;
-          long long b = c.base_in;
-          uint32_t bk = kFInfKey;
-          const uint32_t rr = WaveFrame(c, w, s.ll, frame, wfr, n, b, bk, wst);
-          if (tid == 0) {
-            s.ctl[frame & 1].r = rr;
-            s.ctl[frame & 1].n_in = n;
-            s.ctl[frame & 1].base_out = b;
-            if (rr == 0) s.f_best = static_cast<unsigned long long>(bk) << 32;
-          }
-        }
-        __syncthreads();
-        wv_clean = true;
-        const uint32_t rr = Uni(s.ctl[frame & 1].r);
-        if (rr == 0) {
-          c.base_in = Uni(s.ctl[frame & 1].base_out);
-          c.n_in = Uni(s.ctl[frame & 1].n_in);
-          wv_front = c.n_in <= kWvFront;
-          front_lds = false;
-          upper_dirty = true;
-          best_stale = true;
-          row_to_lds(frame + 1);
-          __syncthreads();
-          KD_LAP(s, 19);
-          frame++;
-          continue;
-        }
-        if (rr != kRedo) { err |= rr; break; }
-        wv_front = false;  // does not fit the wave's table or queue: the workgroup-wide tiers
-      }
-    }
-#endif
-    wv_front = false;
-    wv_clean = false;
     if (small) {
       // a small frame of few tokens is run by the first four waves alone
       const Team tm{kT1Narrow > 0 && c.n_in <= kT1Narrow ? 256 : kBlock, gen};
@@ -3004,20 +2942,6 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     frame++;
   }
 
-  if (tid == 0 && wst.frames) {  // the wave tier's counters
-    s.ustat[KD_STAT_FRAMES] += wst.frames;
-    s.ustat[KD_STAT_SMALL_FRAMES] += wst.frames;
-    s.ustat[KD_STAT_TOKENS_IN] += wst.tokens_in;
-    s.ustat[KD_STAT_TOKENS_EXPANDED] += wst.expanded;
-    s.ustat[KD_STAT_ARCS_SCANNED] += wst.arcs;
-    s.ustat[KD_STAT_ARCS_KEPT] += wst.kept;
-    s.ustat[KD_STAT_TOKENS_OUT] += wst.tokens_out;
-    s.ustat[KD_STAT_EPS_ARCS_SCANNED] += wst.eps_arcs;
-    s.ustat[KD_STAT_EPS_EXPANSIONS] += wst.eps_exp;
-    if (static_cast<unsigned long long>(wst.max_tokens) > s.ustat[KD_STAT_MAX_TOKENS])
-      s.ustat[KD_STAT_MAX_TOKENS] = wst.max_tokens;
-    s.ustat[KD_STAT_LINKS] += wst.links;
-  }
   __syncthreads();
   // fold the small frames' per-lane work counters into the launch totals
   {

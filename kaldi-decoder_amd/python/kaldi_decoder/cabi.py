@@ -352,7 +352,9 @@ class Batch:
 
     def decode_host(self, mats, offsets=None, finalize=True, lattice=True, best_path=True, sync=True):
         """Decode() over host matrices (staged to the device first), one launch; with
-        sync=False the call returns once the rows are on their way (kd_batch_decode_host_async)."""
+        sync=False the call returns once the rows have LEFT the caller's memory -- pinned or
+        pageable: the arrays may be refilled at once -- with the launch enqueued behind them
+        (kd_batch_decode_host_async)."""
         mats = [np.ascontiguousarray(m, np.float32) for m in mats]
         self.batch = len(mats)
         V = mats[0].shape[1]

@@ -306,3 +306,34 @@ def test_one_call_decode_and_growing_pools_faster_decoder(oracle):
         _assert_same_path(paths[i], d.get_best_path(), i)
     with pytest.raises(RuntimeError, match="largest ilabel"):
         bt.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V - 1, row_stride=V)
+
+
+def test_host_async_from_pinned_rows_that_are_refilled_at_once(oracle):
+    """kd_batch_decode_host_async promises that the rows have left the caller's memory when it
+    returns (ref: DecodableCtc copies its matrix, csrc/decodable-ctc.h:15-16).  From PINNED
+    memory HIP's host-to-device copies are truly asynchronous, so the promise needs the
+    library's own wait behind the last staging copy: a pipelined caller refills its buffer for
+    the next call the moment this one returns.  Here the pinned rows are overwritten with
+    garbage right after the call; the decode must still be that of the original rows."""
+    import torch
+    g = synth.hl_graph(V=40, n_words=400, seed=3)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T, V = 16, 400, 40
+    lps = [synth.make_logprobs(T, V, 90 + i, peak=6.0, lexicon=g["lexicon"]) for i in range(B)]
+    pinned = torch.from_numpy(np.stack(lps)).pin_memory()
+    assert pinned.is_pinned()
+    views = [pinned[i].numpy() for i in range(B)]  # (no copy: the library reads the pinned pages)
+    bt = cabi.Batch(G, max_batch=B, beam=8.0)
+    want = []
+    for lp in lps:
+        d = oracle.FasterDecoder(OG, beam=8.0, policy=1)
+        d.decode(lp)
+        want.append(d.get_best_path())
+    for _ in range(3):
+        pinned.copy_(torch.from_numpy(np.stack(lps)))
+        bt.decode_host(views, sync=False)
+        pinned.fill_(-1e30)  # the caller's next batch, as far as the library may care
+        bt.sync()
+        paths = bt.best_paths()
+        for i in range(B):
+            _assert_same_path(paths[i], want[i], i)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Probe: one LatticeBatch call of N utterances (distinct or repeated) with chosen pool sizes.
-   python tools/slots_probe.py N [arena_shift] [no_grow] [repeat_of]"""
+   python tools/call_probe.py N [arena_shift] [no_grow] [repeat_of]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "kaldi-decoder_amd", "python"))
