@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "kd_device.h"
+#include "kd_graph_check.h"
 #include "kd_hip.h"
 
 using namespace kd;
@@ -688,6 +689,13 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
       if (ilabel[a] == 0) has_eps[s] = 1;
       max_ilabel = std::max(max_ilabel, ilabel[a]);
     }
+  }
+  {
+    // epsilon cycles: positive ones decode like the reference; a zero- or negative-weight one
+    // is refused here (kd_graph_check.h says why)
+    std::string why;
+    if (!EpsilonCyclesArePositive(num_states, row_ptr, ilabel, weight, nextstate, &why))
+      return Fail(KD_E_INVALID, why);
   }
   std::vector<StateRec> st(num_states);
   std::vector<ArcRec> ar(std::max<int64_t>(na, 1));

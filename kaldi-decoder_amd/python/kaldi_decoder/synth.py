@@ -68,11 +68,15 @@ def ctc_topo(V: int):
 
 
 def random_graph(num_states, avg_degree, V, eps_frac, seed, n_olabels=50,
-                 final_frac=0.3, max_weight=3.0):
+                 final_frac=0.3, max_weight=3.0, eps_back=0.0, eps_back_min_weight=0.25):
     """Unstructured sparse graph with epsilon arcs and final weights.
 
-    Epsilon arcs only go from a lower to a higher state id, so the graph has
-    no epsilon cycles.  Every state gets at least one emitting arc.
+    Epsilon arcs go from a lower to a higher state id -- no epsilon cycles -- except the
+    fraction `eps_back` of them, which lead to ANY state and weigh at least
+    `eps_back_min_weight`: every epsilon cycle then holds such an arc and (weights being
+    non-negative) has a positive total weight, the kind of cycle the reference's
+    ProcessNonemitting terminates on by strict improvement (faster-decoder.cc:97-113).
+    Every state gets at least one emitting arc.
     """
     rng = np.random.default_rng(seed)
     S = num_states
@@ -83,10 +87,15 @@ def random_graph(num_states, avg_degree, V, eps_frac, seed, n_olabels=50,
     is_eps = rng.random(n_arcs) < eps_frac
     is_eps[:S] = False
     is_eps &= src < S - 1
-    dst = np.where(is_eps, src + 1 + (dst % np.maximum(S - 1 - src, 1)), dst)
+    fwd = src + 1 + (dst % np.maximum(S - 1 - src, 1))
+    back = np.zeros(n_arcs, bool)
+    if eps_back > 0.0:  # (drawn only when asked for: graphs of earlier seeds stay what they were)
+        back = is_eps & (rng.random(n_arcs) < eps_back)
+    dst = np.where(is_eps & ~back, fwd, dst)
     il = np.where(is_eps, 0, il)
     ol = np.where(rng.random(n_arcs) < 0.4, rng.integers(1, n_olabels + 1, n_arcs), 0)
     w = (rng.random(n_arcs) * max_weight).astype(np.float32)
+    w = np.where(back, np.maximum(w, np.float32(eps_back_min_weight)), w).astype(np.float32)
     perm = rng.permutation(n_arcs)
     final = np.where(rng.random(S) < final_frac,
                      (rng.random(S) * 2.0).astype(np.float32), INF).astype(np.float32)

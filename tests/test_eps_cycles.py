@@ -1,0 +1,212 @@
+"""Epsilon cycles.
+
+The reference decodes any epsilon topology: ProcessNonemitting re-queues a token on STRICT
+improvement (ref faster-decoder.cc:97-113, lattice-simple-decoder.cc:122-191), so it ends on a
+cycle whose total weight is positive, ends on a ZERO-weight one only because an equal cost is no
+improvement, and never ends on a negative one.
+
+* Positive cycles: decoded here like there.  The search relaxes to the same fixpoint; for the
+  lattice, PruneForwardLinks' extra costs have one fixpoint only, which the reference reaches from
+  below (:246-304, from the zeros new tokens are created with) and the GPU sweep from above.
+  Checked: both oracle decoders against the order-free definition of the lattice
+  (tests/lattice_ref.py, in tests/test_lattice_ref.py), a hand-derived case below, and the GPU
+  against the canonical oracle on random cyclic graphs (here and in tools/fuzz_gpu.py).
+* Zero-weight cycles: the two fixpoints DIFFER (hand-derived case below: the reference keeps
+  the cycle's tokens at extra cost 0 although every way out of the cycle is beyond the lattice
+  beam), and the canonical tie rule could make two tokens of the cycle each other's
+  back-pointer.  kd_graph_create refuses such a graph, and a negative arc on an epsilon cycle,
+  with a message (csrc/kd_graph_check.h).
+"""
+import numpy as np
+import pytest
+
+from kaldi_decoder import cabi, synth
+import lattice_ref
+
+INF = float("inf")
+
+# ---------------------------------------------------------------------------------------
+# Graph Z: two tokens on an epsilon cycle whose only exit is expensive.
+#   state 0 (start)   a0: 1:0 /0 -> 1       a1: 2:0 /0 -> 3
+#   state 1           a2: 0:0 /0 -> 2                        (epsilon)
+#   state 2           a3: 0:0 /w -> 1  (epsilon, closes the cycle)     a4: 1:0 /5 -> 4
+#   state 3           a5: 1:0 /0 -> 4
+#   state 4 (final 0)
+# log-likelihoods all 0 (two frames, V = 2): every acoustic cost is 0.  beam 16, lattice_beam 2.
+#
+# LatticeSimpleDecoder (lattice-simple-decoder.cc):
+#  InitDecoding: token (0: 0).
+#  frame 0 (ProcessEmitting :364-402): a0 -> 1: 0, a1 -> 3: 0; cutoff 0 + 16.  ProcessNonemitting
+#   (:122-191): token 1 -> a2 -> token 2 at 0 (new, queued); token 2 -> a3 -> state 1 at 0 + w: not
+#   below token 1's cost, so not "changed" -- but the LINK is made all the same (:175-181: the link
+#   is appended whatever FindOrAddToken says).  Frame 1: tokens {1: 0, 2: 0, 3: 0}, epsilon links
+#   1->2 (0), 2->1 (w).
+#  frame 1: a4 from 2 -> 4: 5, a5 from 3 -> 4: 0.  Frame 2: token {4: 0}; links 2->4 (graph 5),
+#   3->4 (graph 0), both below 0 + 16.
+#  FinalizeDecoding: frame 2: token 4 final, extra 0.  Frame 1, PruneForwardLinks (:228-305), every
+#   token's extra_cost starting at the 0 it was created with (:91-95):
+#     3->4: 0 + (0 + 0 - 0) = 0 kept.     2->4: 0 + (0 + 5 - 0) = 5 > 2: deleted (:264).
+#     2->1: extra(1) + (0 + w - 0)        1->2: extra(2) + (0 + 0 - 0)
+#   w = 0:    2->1 = 0 + 0 = 0, 1->2 = 0 + 0 = 0: nothing changes, the loop ends (:286-290) --
+#             tokens 1 and 2 keep extra cost 0 and their two links, FOR EVER, although the only
+#             way from either of them to the end costs 5 more than the best path.  Frame 0: link
+#             0->1 = 0 + 0 kept.  Lattice: 5 arcs (a0, a1, a2, a3, a5), 5 states.
+#   w = 0.5:  first pass 2->1 = 0 + 0.5, extra(2) = 0.5; 1->2 = 0.5, extra(1) = 0.5 (or, in the
+#             other token order, the same one pass later); each pass adds 0.5 until 2->1 reaches
+#             2.5 > 2 and is deleted, token 2 has no link left (extra +inf, :294-295), 1->2 goes
+#             with it.  Frame 0: 0->1 = +inf: deleted.  Lattice: 2 arcs (a1, a5), 3 states -- what
+#             the distance to the best path says for both values of w.
+
+
+def graph_z(w):
+    arcs = [(0, 1, 1, 0, 0.0), (0, 3, 2, 0, 0.0), (1, 2, 0, 0, 0.0), (2, 1, 0, 0, w),
+            (2, 4, 1, 0, 5.0), (3, 4, 1, 0, 0.0)]
+    return synth.graph_from_arcs(5, 0, arcs, {4: 0.0})
+
+
+LP_Z = np.zeros((2, 2), np.float32)
+ARCS_Z_TRUE = {(0, 0, 1, 3, 2, 0, 0.0, 0.0), (1, 3, 2, 4, 1, 0, 0.0, 0.0)}
+ARCS_Z_PHANTOM = ARCS_Z_TRUE | {(0, 0, 1, 1, 1, 0, 0.0, 0.0), (1, 1, 1, 2, 0, 0, 0.0, 0.0),
+                                (1, 2, 1, 1, 0, 0, 0.0, 0.0)}
+
+
+def test_zero_weight_cycle_the_reference_order_keeps_tokens_the_distance_does_not(oracle):
+    g = graph_z(0.0)
+    og = oracle.Graph(g)
+    d = oracle.LatticeSimpleDecoder(og, beam=16.0, lattice_beam=2.0)
+    d.decode(LP_Z)
+    lat = d.get_raw_lattice()
+    assert lat.arc_set() == ARCS_Z_PHANTOM and lat.num_states == 5
+    # ... while the definition by distance (alpha + w + beta - best <= lattice_beam) has two arcs
+    links, _, best = lattice_ref.lattice_by_viterbi(g, LP_Z, 2.0)
+    assert best == 0.0
+    assert {k for k, x in links.items() if x <= 2.0} == {(0, 0, 1, 3, 2, 0), (1, 3, 2, 4, 1, 0)}
+    assert links[(1, 2, 1, 1, 0, 0)] == 5.0 and links[(1, 1, 1, 2, 0, 0)] == 5.0
+
+
+def test_positive_cycle_every_decoder_agrees_with_the_distance(oracle):
+    g = graph_z(0.5)
+    og = oracle.Graph(g)
+    for d in (oracle.LatticeSimpleDecoder(og, beam=16.0, lattice_beam=2.0),
+              oracle.CanonLatticeDecoder(og, beam=16.0, lattice_beam=2.0)):
+        d.decode(LP_Z)
+        lat = d.get_raw_lattice()
+        assert lat.arc_set() == ARCS_Z_TRUE and lat.num_states == 3
+        assert lattice_ref.check_lattice(lat, g, LP_Z, 2.0, 1e-6) == 0
+    # a lattice beam that keeps the cycle: 2->4 at 5 stays out, the cycle's links carry
+    # 5 -> no: with lattice_beam 6 everything is within reach (2->4: 5, 2->1: 5.5, 1->2: 5)
+    d = oracle.CanonLatticeDecoder(og, beam=16.0, lattice_beam=6.0)
+    d.decode(LP_Z)
+    assert len(d.get_raw_lattice().src) == 6
+    # FasterDecoder: the cycle costs nothing to decode through (strict improvement only)
+    for pol in (0, 1):
+        f = oracle.FasterDecoder(og, beam=16.0, min_active=0, policy=pol)
+        f.decode(LP_Z)
+        p = f.get_best_path()
+        assert p.ok and p.state.tolist() == [3, 4]
+
+
+def _expect_refused(g, what):
+    with pytest.raises(RuntimeError, match=what):
+        cabi.Graph(g)
+
+
+def test_graphs_with_zero_or_negative_epsilon_cycles_are_refused_at_the_boundary():
+    """kd_graph_create runs the check before it touches the GPU: this needs none."""
+    _expect_refused(graph_z(0.0), "epsilon cycle of total weight zero")
+    _expect_refused(graph_z(-0.25), "negative-weight arc")
+    # a zero-weight epsilon self-loop
+    g = synth.graph_from_arcs(2, 0, [(0, 1, 1, 0, 0.0), (1, 1, 0, 0, 0.0)], {1: 0.0})
+    _expect_refused(g, "epsilon cycle of total weight zero")
+    # a cycle of three, zero arcs only; hung off a chain of epsilon arcs
+    arcs = [(0, 1, 1, 0, 0.0), (1, 2, 0, 0, 1.0), (2, 3, 0, 0, 0.0), (3, 4, 0, 0, 0.0), (4, 2, 0, 0, 0.0)]
+    _expect_refused(synth.graph_from_arcs(5, 0, arcs, {4: 0.0}), "epsilon cycle of total weight zero")
+    # a negative epsilon arc that is on NO cycle is fine, and so is a positive cycle that has
+    # zero-weight arcs on it: these pass the check (and then need a GPU)
+    ok1 = synth.graph_from_arcs(3, 0, [(0, 1, 1, 0, 0.0), (1, 2, 0, 0, -1.0)], {2: 0.0})
+    ok2 = graph_z(0.5)
+    ok3 = synth.random_graph(300, 3.5, 10, 0.45, 7, eps_back=0.6)
+    for g in (ok1, ok2, ok3):
+        try:
+            cabi.Graph(g)
+        except RuntimeError as e:
+            assert "epsilon" not in str(e), e
+            assert cabi.device_count() == 0, e  # (only the missing GPU may stop it)
+
+
+# ---- GPU ---------------------------------------------------------------------------------
+
+
+@pytest.mark.gpu
+def test_gpu_positive_cycle_kat(oracle):
+    g = graph_z(0.5)
+    G = cabi.Graph(g)
+    for lbeam, n_arcs in ((2.0, 2), (6.0, 6)):
+        lb = cabi.LatticeBatch(G, max_batch=1, beam=16.0, lattice_beam=lbeam, min_active=0)
+        lb.decode_host([LP_Z])
+        lat = lb.raw_lattices()[0]
+        assert len(lat.src) == n_arcs
+        if lbeam == 2.0:
+            assert lat.arc_set() == ARCS_Z_TRUE and lat.num_states == 3
+    bt = cabi.Batch(G, max_batch=1, beam=16.0, min_active=0)
+    bt.decode_host([LP_Z])
+    assert bt.best_paths()[0].state.tolist() == [3, 4]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_gpu_random_graphs_with_positive_epsilon_cycles(oracle, seed):
+    """Search and lattice sweep on epsilon cycles: per-frame frontiers, 1-best, raw lattices
+    before and after FinalizeDecoding at two prune intervals -- all equal to the canonical
+    oracle's, whose extras are iterated from below like the reference's."""
+    rng = np.random.default_rng(seed)
+    S = int(rng.integers(60, 1500))
+    V = 12
+    g = synth.random_graph(S, float(rng.uniform(3, 5)), V, 0.45, 400 + seed, eps_back=0.6,
+                           eps_back_min_weight=float(rng.choice([0.25, 1.0])))
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T = 4, 25
+    lps = [synth.make_logprobs(T, V, 500 + 10 * seed + i, peak=float(rng.uniform(1, 5))) for i in range(B)]
+    beam, lbeam = float(rng.uniform(4, 9)), float(rng.uniform(1.5, 5))
+    for pi in (3, 1 << 20):
+        lb = cabi.LatticeBatch(G, max_batch=B, beam=beam, lattice_beam=lbeam, min_active=0, prune_interval=pi)
+        lb.decode_host(lps)
+        lats = lb.raw_lattices()
+        frc = lb.final_relative_cost()
+        for i, lp in enumerate(lps):
+            can = oracle.CanonLatticeDecoder(OG, beam=beam, lattice_beam=lbeam)
+            can.decode(lp)
+            cl = can.get_raw_lattice()
+            assert lats[i].arc_set() == cl.arc_set() and lats[i].state_set() == cl.state_set(), (pi, i)
+            assert lats[i].final_set() == cl.final_set()
+            assert frc[i] == can.final_relative_cost() or (np.isinf(frc[i]) and np.isinf(can.final_relative_cost()))
+    bt = cabi.Batch(G, max_batch=B, beam=beam, min_active=0)
+    bt.decode_host(lps)
+    paths = bt.best_paths()
+    for i, lp in enumerate(lps):
+        d = oracle.FasterDecoder(OG, beam=beam, min_active=0, policy=1)
+        d.decode(lp)
+        p = d.get_best_path()
+        assert paths[i].ok == p.ok and paths[i].state.tolist() == p.state.tolist()
+        assert paths[i].ac_cost.tolist() == p.ac_cost.tolist()
+        assert paths[i].graph_cost.tolist() == p.graph_cost.tolist()
+
+
+@pytest.mark.gpu
+def test_gpu_lattice_is_the_links_within_lattice_beam_of_the_best_path():
+    """The GPU's finalized lattices against the INDEPENDENT definition (tests/lattice_ref.py):
+    with a search beam that prunes nothing, exactly the links and tokens with
+    alpha + w + ac + beta - best <= lattice_beam, on the cases of tests/test_lattice_ref.py
+    (acyclic, positive epsilon cycles, HLG, HL)."""
+    import test_lattice_ref as tl
+    for name, g, lex, V, T, lbeams in tl.CASES:
+        G = cabi.Graph(g)
+        lps = [synth.make_logprobs(T, V, 300 + utt, peak=2.0, lexicon=lex) for utt in range(3)]
+        for lbeam in lbeams:
+            for pi in (4, 25):
+                lb = cabi.LatticeBatch(G, max_batch=3, beam=tl.WIDE, lattice_beam=lbeam, min_active=0,
+                                       prune_interval=pi)
+                lb.decode_host(lps)
+                for lat, lp in zip(lb.raw_lattices(), lps):
+                    n_margin = lattice_ref.check_lattice(lat, g, lp, lbeam, 1e-4 * (T + 1))
+                    assert n_margin <= max(2, len(lat.src) // 50), (name, n_margin)

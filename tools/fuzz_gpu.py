@@ -33,8 +33,14 @@ def graph(rng):
         return synth.ctc_topo(V), None, V
     if k == 1:
         V = int(rng.integers(8, 24))
+        # a third of them with epsilon cycles of positive weight (kd_graph_create refuses the
+        # others: csrc/kd_graph_check.h): the closure's re-queueing and the lattice sweep's
+        # fixpoint on cyclic links
+        cyc = rng.random() < 0.33
         return synth.random_graph(int(rng.integers(50, 3000)), float(rng.uniform(2, 5)), V,
-                                  float(rng.uniform(0, 0.35)), int(rng.integers(0, 10**6))), None, V
+                                  float(rng.uniform(0.2, 0.5) if cyc else rng.uniform(0, 0.35)),
+                                  int(rng.integers(0, 10**6)), eps_back=0.5 if cyc else 0.0,
+                                  eps_back_min_weight=float(rng.choice([0.125, 0.5, 2.0]))), None, V
     V = int(rng.integers(20, 60))
     if k == 2:
         g = synth.hl_graph(V=V, n_words=int(rng.integers(30, 600)), seed=int(rng.integers(0, 10**6)))
