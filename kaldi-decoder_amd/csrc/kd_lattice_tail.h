@@ -281,7 +281,9 @@ __device__ __forceinline__ int SweepWindow(CParams &p, TailShared &s, const Stag
   // global loads come first), and sensitive to anything that shifts the waves' timing: the
   // stall / memory fault of round 2's hlg-large runs with another register allocation, and
   // one bench run in six of round 3 after an unrelated edit of this function.)
+#ifndef KD_TEST_DROP_SWEEP_BARRIER  // (tools only: the jitter build must FIND the race this barrier closes)
   LdsBarrier();
+#endif
   if (tid < 64) {  // the descriptors of frames f, f - 1, ...; how many fit
     const int k = f - lane;
     const bool in = lane < kWinMax && k >= 0;

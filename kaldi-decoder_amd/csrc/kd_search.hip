@@ -53,6 +53,37 @@
 #include "kd_device.h"
 #include "kd_hip.h"
 
+// Timing-perturbation build (make jitter; -DKD_JITTER=<unit>): behind EVERY workgroup barrier
+// -- __syncthreads, LdsBarrier, Team::Sync -- each wave sleeps a pseudo-random time of its own
+// (seeded by the clock and the wave's id: another draw at every barrier of every call), mostly
+// up to 31 units of <unit> x 64 cycles, one time in sixteen sixteen times that.  Results must
+// not change: a kernel whose waves may only differ in WHEN they pass a barrier gives the same
+// answer however late any of them is.  What it shakes out is an LDS region that one phase reads
+// and the next overwrites with no barrier in between: in the shipped build the reader is
+// rarely late enough to see it (round 3's SweepWindow race bit one bench run in six and was
+// found by reading); here a wave lags by thousands of cycles at every barrier.  Never shipped,
+// never timed: tools/fuzz_gpu.py, the bench-scale tests and tools/soak.sh run against it.
+#ifdef KD_JITTER
+__device__ __forceinline__ void KdJitter() {
+  uint32_t x = static_cast<uint32_t>(__builtin_amdgcn_s_memtime()) * 2654435761u;
+  x ^= (threadIdx.x >> 6) * 0x9E3779B9u + blockIdx.x * 0x85EBCA6Bu;
+  x ^= x >> 15;
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 12;
+  x = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(x)));
+  int n = static_cast<int>(x & 31u);
+  if (((x >> 5) & 15u) == 0u) n *= 16;
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(KD_JITTER);
+}
+#define __syncthreads()  \
+  do {                   \
+    ::__syncthreads();   \
+    KdJitter();          \
+  } while (0)
+#else
+__device__ __forceinline__ void KdJitter() {}
+#endif
+
 namespace kd {
 namespace {
 
@@ -337,6 +368,7 @@ constexpr int kBucketSmall = 19, kBucketBig = -1, kBucketSpill = 14;
 // needs the other waves' LDS writes, this lets the stores keep draining.
 __device__ __forceinline__ void LdsBarrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  KdJitter();
 }
 
 // Barrier for phases whose cross-wave traffic is the token table: LDS in the LDS
@@ -366,6 +398,7 @@ struct Team {
     // (each team wave has a SIMD to itself: spinning costs nobody an issue slot)
     while (__hip_atomic_load(&s.soft_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - gen < 0) {}
     asm volatile("" ::: "memory");
+    KdJitter();
   }
 };
 

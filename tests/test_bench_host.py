@@ -65,23 +65,6 @@ def test_committed_summary_matches_the_bench_line_next_to_it():
         assert lo <= s["avg_launch_ms"] <= 1.05 * b["roofline"]["kernel_ms"]
 
 
-def test_the_barrier_that_the_spill_option_depends_on_is_in_place():
-    """DESIGN section 4, "A barrier that was missing": -amdgpu-prealloc-sgpr-spill-vgprs (+ 3 % on
-    the bench) made round 2's large-LM workload stall 2 runs in 3 -- by shifting the waves'
-    timing onto a race in the lattice sweep, not by itself.  The option is on again since the
-    race is fixed; this keeps the two together: SweepWindow must synchronise BEFORE its first
-    wave rewrites the window descriptors that the other waves may still be reading."""
-    mk = open(os.path.join(ROOT, "kaldi-decoder_amd", "Makefile")).read()
-    flags = [ln for ln in mk.splitlines() if ln.startswith("HIPFLAGS")]
-    assert flags
-    src = open(os.path.join(ROOT, "kaldi-decoder_amd", "csrc", "kd_lattice_tail.h")).read()
-    body = src[src.index("__device__ __forceinline__ int SweepWindow("):]
-    body = body[:body.index("__syncthreads();")]
-    # (comment lines out: the barrier call itself must precede the builder)
-    code = "\n".join(ln for ln in body.splitlines() if not ln.strip().startswith("//"))
-    assert "LdsBarrier();" in code and code.index("LdsBarrier();") < code.index("if (tid < 64) {")
-
-
 def test_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
     """`python bench.py --gpus 8` as the driver may run it (no torchrun around it, WORLD_SIZE
     unset): bench.py starts `python -m torch.distributed.run` on its own command line as a child

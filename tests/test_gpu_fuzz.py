@@ -35,3 +35,20 @@ def test_randomised_parity_with_shrunk_capacities(seed):
                        capture_output=True, text=True, timeout=300,
                        env={**os.environ, "KD_HIP_LIB": "libkd_hip_stress.so"})
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("seed", [31])
+def test_randomised_parity_under_timing_perturbation(seed):
+    """The same runs against `libkd_hip_jitter.so` (make jitter; part of `make all`): behind every
+    workgroup barrier each wave sleeps a pseudo-random time of its own, up to thousands of
+    cycles (kd_search.hip, KdJitter), with the stress build's shrunk tail capacities.  A phase
+    that reads an LDS region which the next phase overwrites without a barrier in between
+    -- round 3's SweepWindow race, found by reading after it had bitten one bench run in six --
+    gives wrong lattices or faults here.  (Replaces a test that grepped the source for that
+    one barrier.)"""
+    lib = os.path.join(ROOT, "kaldi-decoder_amd", "python", "kaldi_decoder", "lib", "libkd_hip_jitter.so")
+    assert os.path.exists(lib), "make -C kaldi-decoder_amd jitter"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), "30", str(seed)],
+                       capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "KD_HIP_LIB": "libkd_hip_jitter.so"})
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
