@@ -40,6 +40,7 @@ extern "C" {
 #define KD_UTT_FRAMES_FULL 4u
 #define KD_UTT_LINKS_FULL 8u
 #define KD_UTT_OUT_FULL 16u
+#define KD_UTT_PATH_QUEUE_FULL 32u /* a best path longer than the workgroup's staging queue (2 x table_slots arcs) */
 
 typedef struct kd_graph kd_graph;
 typedef struct kd_batch kd_batch;
@@ -326,7 +327,11 @@ int kd_batch_set_output_buffer(kd_batch *b, void *device_words, int64_t cap_word
  * the output pool / buffer are in use, and per utterance {first word, states, arcs, finals,
  * start state}.  An utterance's region: states {frame, graph state} x ns | finals {state,
  * weight} x nf | arcs {src, dst | ilabel, olabel | graph, ac} x na, ordered as
- * kd_batch_raw_lattice_copy delivers them. */
+ * kd_batch_raw_lattice_copy delivers them.  With a lent buffer the regions are complete in it
+ * whichever export ran: the one fused into a decode writes both copies; an export that the
+ * host has to put in order first (an un-finalized lattice, kd_batch_raw_lattice_prepare apart
+ * from the decode, a lattice that outgrew the staging lists) is ordered in the pinned pool
+ * and copied into the buffer by this call. */
 int kd_batch_raw_lattice_table(kd_batch *b, int64_t *used_words, int64_t *table /* [batch][5] */);
 
 

@@ -57,7 +57,8 @@ struct kd_graph {
   int64_t num_arcs = 0;
   int32_t max_ilabel = 0;  // a log-likelihood matrix needs at least this many columns
   DevBuf<StateRec> states;
-  DevBuf<ArcRec> arcs;
+  DevBuf<ArcPacked> arcs;
+  DevBuf<int32_t> olabels;  // [arcs], in the arcs' device order (emitting first per state)
 };
 
 struct kd_batch {
@@ -162,6 +163,7 @@ struct kd_batch {
     SearchParams p{};
     p.states = g->states.p;
     p.arcs = g->arcs.p;
+    p.arc_olabel = g->olabels.p;
     p.start = g->start;
     p.beam = o.beam;
     p.max_active = o.max_active;
@@ -242,7 +244,7 @@ struct kd_batch {
 namespace {
 
 constexpr uint32_t kRecoverable =
-    KD_UTT_ARENA_FULL | KD_UTT_LINKS_FULL | KD_UTT_TABLE_FULL | KD_UTT_OUT_FULL;
+    KD_UTT_ARENA_FULL | KD_UTT_LINKS_FULL | KD_UTT_TABLE_FULL | KD_UTT_OUT_FULL | KD_UTT_PATH_QUEUE_FULL;
 constexpr uint64_t kIndexLimit = (1ull << 31) - 1;  // tokens and links are indexed with int32
 constexpr int kMaxLog2Slots = 19;  // the spill table's worklist bitmask lives in 64 KiB of LDS
 
@@ -362,10 +364,13 @@ hipError_t AllocTables(kd_batch *b, int lg) {
   return hipSuccess;
 }
 
-int GrowTables(kd_batch *b) {
+int GrowTables(kd_batch *b, bool for_path = false) {
   if (b->g_log2_slots >= kMaxLog2Slots)
-    return Fail(KD_E_CAPACITY, "token table full at 2^19 slots per utterance: a frame holds more "
-                               "than 393216 tokens (tighten beam / max_active)");
+    return Fail(KD_E_CAPACITY, for_path
+                    ? "a best path of more than 2^20 arcs does not fit the staging queue at its "
+                      "largest (2 x 2^19 entries): decode the utterance in pieces"
+                    : "token table full at 2^19 slots per utterance: a frame holds more "
+                      "than 393216 tokens (tighten beam / max_active)");
   // the tables are empty between frames: nothing to carry over
   if (hipError_t e = AllocTables(b, b->g_log2_slots + 1); e != hipSuccess)
     return Fail(KD_E_CAPACITY, std::string("token table full and cannot grow: ") + hipGetErrorString(e));
@@ -458,6 +463,8 @@ std::string StatusMessage(const kd_batch *b, int i) {
   if (st & KD_UTT_TABLE_FULL) m += " token table full (raise table_slots)";
   if (st & KD_UTT_FRAMES_FULL) m += " frame index full (raise max_frames)";
   if (st & KD_UTT_OUT_FULL) m += " lattice output pool full";
+  if (st & KD_UTT_PATH_QUEUE_FULL)
+    m += " best path longer than the staging queue of 2 x table_slots arcs (raise table_slots)";
   return m;
 }
 
@@ -571,12 +578,31 @@ int ReadBack(kd_batch *b) {
     }
     if (!any) return KD_OK;
     if (b->o.no_grow || (any & ~kRecoverable)) return Fail(KD_E_CAPACITY, StatusMessage(b, first_bad));
+    // A pool's cursor only moves forward (kd_search.hip, PoolChunk): the take that did not fit,
+    // and every take after it, left it BEYOND the capacity.  Nothing was handed out past the
+    // first failed take, which started below the capacity: pull the cursor back to the
+    // capacity before the launch resumes, or the overshoot -- one chunk per workgroup that ran
+    // into the end together -- is lost for the rest of the decode and may force a doubling more.
+    auto pull_back = [&](uint64_t *raw, uint64_t base, uint64_t cap, size_t word) -> int {
+      if (*raw - base <= cap) return KD_OK;
+      const unsigned long long v = base + cap;
+      KD_HIP_TRY(hipMemcpy(reinterpret_cast<char *>(b->bctl.p) + word, &v, sizeof(v), hipMemcpyHostToDevice));
+      *raw = v;
+      return KD_OK;
+    };
+    if (int r = pull_back(&b->tok_raw, b->tok_base, b->tok_cap, offsetof(BatchCtl, tok_top))) return r;
+    if (int r = pull_back(&b->link_raw, b->link_base, b->link_cap, offsetof(BatchCtl, link_top))) return r;
+    b->h_tok_top = b->tok_raw - b->tok_base;
+    b->h_link_top = b->link_raw - b->link_base;
     if (any & KD_UTT_ARENA_FULL)
       if (int r = GrowTokens(b)) return r;
     if (any & KD_UTT_LINKS_FULL)
       if (int r = GrowLinks(b)) return r;
-    if (any & KD_UTT_TABLE_FULL)
+    if (any & KD_UTT_TABLE_FULL) {
       if (int r = GrowTables(b)) return r;
+    } else if (any & KD_UTT_PATH_QUEUE_FULL) {
+      if (int r = GrowTables(b, true)) return r;
+    }
     if (any & KD_UTT_OUT_FULL) {
       if (int r = GrowOut(b)) return r;
       b->out_base = b->out_raw;  // every utterance exports again, into the larger pool
@@ -697,19 +723,32 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
     if (!EpsilonCyclesArePositive(num_states, row_ptr, ilabel, weight, nextstate, &why))
       return Fail(KD_E_INVALID, why);
   }
+  if (max_ilabel > kMaxIlabel)
+    return Fail(KD_E_INVALID, "ilabel " + std::to_string(max_ilabel) + " exceeds the largest supported (" +
+                              std::to_string(kMaxIlabel) + ": 20 bits of the arc record)");
   std::vector<StateRec> st(num_states);
-  std::vector<ArcRec> ar(std::max<int64_t>(na, 1));
+  std::vector<ArcPacked> ar(std::max<int64_t>(na, 1));
+  std::vector<int32_t> ol(std::max<int64_t>(na, 1), 0);
   for (int32_t s = 0; s < num_states; ++s) {
     const int32_t b = row_ptr[s], e = row_ptr[s + 1];
     int32_t pe = b;
     for (int32_t a = b; a < e; ++a)
       if (ilabel[a] != 0) ++pe;
     st[s] = StateRec{b, pe, e, final_cost[s]};
-    int32_t we = b, wn = pe;
+  }
+  for (int32_t s = 0; s < num_states; ++s) {
+    const int32_t b = row_ptr[s], e = row_ptr[s + 1];
+    int32_t we = b, wn = st[s].emit_end;
     for (int32_t a = b; a < e; ++a) {
-      ArcRec r{ilabel[a], olabel[a], weight[a],
-               static_cast<uint32_t>(nextstate[a]) | (has_eps[nextstate[a]] ? kHasEps : 0u)};
-      ar[ilabel[a] != 0 ? we++ : wn++] = r;
+      // the arc carries its destination's arc range (first arc, emitting and epsilon degrees:
+      // what the search would otherwise fetch from the destination's state record)
+      const StateRec &d = st[nextstate[a]];
+      const uint32_t degs = PackDegs(d.emit_end - d.arc_begin, d.arc_end - d.emit_end);
+      ArcPacked r{static_cast<uint32_t>(ilabel[a]) | degs << kIlabelBits, static_cast<uint32_t>(d.arc_begin),
+                  weight[a], static_cast<uint32_t>(nextstate[a]) | (has_eps[nextstate[a]] ? kHasEps : 0u)};
+      const int32_t at = ilabel[a] != 0 ? we++ : wn++;
+      ar[at] = r;
+      ol[at] = olabel[a];
     }
   }
   KD_HIP_TRY(hipSetDevice(device));
@@ -722,8 +761,10 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
   g->max_ilabel = max_ilabel;
   hipError_t e = g->states.Alloc(num_states);
   if (e == hipSuccess) e = g->arcs.Alloc(ar.size());
+  if (e == hipSuccess) e = g->olabels.Alloc(ol.size());
   if (e == hipSuccess) e = hipMemcpy(g->states.p, st.data(), st.size() * sizeof(StateRec), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(g->arcs.p, ar.data(), ar.size() * sizeof(ArcRec), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(g->arcs.p, ar.data(), ar.size() * sizeof(ArcPacked), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(g->olabels.p, ol.data(), ol.size() * sizeof(int32_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     delete g;
     return Fail(KD_E_HIP, std::string("graph upload: ") + hipGetErrorString(e));
@@ -735,7 +776,9 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
 void kd_graph_destroy(kd_graph *g) { delete g; }
 int32_t kd_graph_num_states(const kd_graph *g) { return g ? g->num_states : 0; }
 int64_t kd_graph_num_arcs(const kd_graph *g) { return g ? g->num_arcs : 0; }
-size_t kd_graph_device_bytes(const kd_graph *g) { return g ? g->states.bytes() + g->arcs.bytes() : 0; }
+size_t kd_graph_device_bytes(const kd_graph *g) {
+  return g ? g->states.bytes() + g->arcs.bytes() + g->olabels.bytes() : 0;
+}
 
 void kd_faster_options_default(kd_faster_options *o) {
   // faster-decoder.h:41-49
@@ -1386,11 +1429,25 @@ int kd_batch_raw_lattice_table(kd_batch *b, int64_t *used_words, int64_t *table)
     if (int r = ReadBack(b)) return r;
   if (b->exported_use_final < 0)
     return Fail(KD_E_STATE, "nothing exported: decode with KD_DECODE_LATTICE or call kd_batch_raw_lattice_prepare");
-  for (int i = 0; i < b->batch; ++i)
-    if (b->h_lat_arena[i])
-      return Fail(KD_E_STATE, "utterance " + std::to_string(i) + "'s export is in arena order (an un-finalized "
-                              "lattice, or one exported apart from the decode): only the host arrays of "
-                              "kd_batch_raw_lattice_copy are ordered; the lent buffer holds the staged export");
+  // An export in arena order (an un-finalized lattice, one exported apart from the decode, one
+  // that outgrew the staging lists) is written to the pinned pool only and put in order by the
+  // host: mirror those utterances' ordered regions into the lent buffer, so that buffer prefix +
+  // table are complete whichever export ran.  (Rare; the staged export of a decode call writes
+  // both copies itself.)
+  if (b->out_ext) {
+    bool any = false;
+    for (int i = 0; i < b->batch; ++i) any |= b->h_lat_arena[i] && b->h_lat_off[i] >= 0;
+    if (any) {
+      if (int r = HostResults(b)) return r;
+      for (int i = 0; i < b->batch; ++i) {
+        if (!b->h_lat_arena[i] || b->h_lat_off[i] < 0) continue;
+        const int32_t *sz = &b->h_lat_sizes[4 * i];
+        const size_t words = static_cast<size_t>(sz[0]) + sz[2] + 3 * static_cast<size_t>(sz[1]);
+        KD_HIP_TRY(hipMemcpy(b->out_ext + b->h_lat_off[i], b->out_pool + b->h_lat_off[i], words * 8,
+                             hipMemcpyHostToDevice));
+      }
+    }
+  }
   *used_words = static_cast<int64_t>(b->h_out_top);
   for (int i = 0; i < b->batch; ++i) {
     table[5 * i] = b->h_lat_off[i];

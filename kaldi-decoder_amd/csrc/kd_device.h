@@ -2,9 +2,11 @@
 // search kernel, the traceback kernels and the host C-ABI implementation.
 //
 // HBM layout (DESIGN.md "Data layout"):
-//   graph    StateRec[S] (16 B)  + ArcRec[A] (16 B), arcs of a state contiguous,
-//            emitting arcs first (stable) so the emitting and epsilon passes
-//            each read one contiguous, 16-byte-aligned range per token.
+//   graph    StateRec[S] (16 B)  + ArcPacked[A] (16 B) + olabel[A] (4 B, output side only),
+//            arcs of a state contiguous, emitting arcs first (stable) so the emitting and
+//            epsilon passes each read one contiguous, 16-byte-aligned range per token; an
+//            arc names its destination's arc range, so a token knows its arcs from the
+//            arc that created it.
 //   tokens   append-only records of the whole batch as parallel arrays (state,
 //            cost, prev, arc / extra): one pool shared by the utterances; an
 //            utterance takes a chunk at a time (one atomic) and cuts one contiguous
@@ -25,11 +27,36 @@ struct __attribute__((aligned(16))) StateRec {
   float final_cost;   // +inf == not final
 };
 
-struct __attribute__((aligned(16))) ArcRec {
-  int32_t ilabel;
-  int32_t olabel;
+// An arc as the search reads it: 16 bytes, one global_load_dwordx4.  Besides what the
+// reference's ArcIterator yields (ilabel, weight, nextstate; the olabel, which only the export
+// and the traceback read, lives in a side array) it carries what the search would otherwise
+// fetch from the DESTINATION's state record -- a dependent round trip per epsilon round and one
+// for the new frontier: the destination's first arc and its emitting / epsilon degrees.
+struct __attribute__((aligned(16))) ArcPacked {
+  uint32_t lab;       // bits 0..19 ilabel | 20..27 destination's emitting degree | 28..31 its epsilon degree
+  uint32_t dst_arcs;  // the destination's first arc (StateRec::arc_begin)
   float weight;
-  uint32_t next;  // bits 0..30 next state, bit 31: that state has epsilon arcs
+  uint32_t next;      // bits 0..30 next state, bit 31: that state has epsilon arcs
+};
+constexpr int kIlabelBits = 20;
+constexpr int32_t kMaxIlabel = (1 << kIlabelBits) - 1;
+// degrees that do not fit are stored as these, and looked up in the state record as before
+constexpr uint32_t kEmitDegEscape = 255u, kEpsDegEscape = 15u;
+// the 12 degree bits as one field ("degs": emitting degree | epsilon degree << 8)
+__host__ __device__ inline uint32_t PackDegs(int64_t emit_deg, int64_t eps_deg) {
+  const uint32_t e = emit_deg < kEmitDegEscape ? static_cast<uint32_t>(emit_deg) : kEmitDegEscape;
+  const uint32_t n = eps_deg < kEpsDegEscape ? static_cast<uint32_t>(eps_deg) : kEpsDegEscape;
+  return e | n << 8;
+}
+__host__ __device__ inline uint32_t DegsEmit(uint32_t degs) { return degs & 255u; }
+__host__ __device__ inline uint32_t DegsEps(uint32_t degs) { return (degs >> 8) & 15u; }
+// ... and in registers
+struct ArcRec {
+  int32_t ilabel;
+  uint32_t dst_arcs;
+  uint32_t dst_degs;
+  float weight;
+  uint32_t next;
 };
 
 constexpr uint32_t kStateMask = 0x7FFFFFFFu;
@@ -148,7 +175,8 @@ struct LatticeParams {
 struct SearchParams {
   // graph
   const StateRec *states;
-  const ArcRec *arcs;
+  const ArcPacked *arcs;
+  const int32_t *arc_olabel;  // [arcs] read by GetRawLattice / GetBestPath only
   int32_t start;
   // FasterDecoderOptions
   float beam;

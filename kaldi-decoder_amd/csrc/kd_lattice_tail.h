@@ -991,7 +991,7 @@ __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &
     const ArcRec ar = LoadArcRec(p.arcs, static_cast<uint32_t>(arc));
     KD_G unsigned long long *w = o_arc + 3ll * (lo + rank);
     w[0] = pack(static_cast<uint32_t>(sid), static_cast<uint32_t>(ToG(p.lat.tok_newid)[dst]));
-    w[1] = pack(static_cast<uint32_t>(ar.ilabel), static_cast<uint32_t>(ar.olabel));
+    w[1] = pack(static_cast<uint32_t>(ar.ilabel), static_cast<uint32_t>(ToG(p.arc_olabel)[arc]));
     w[2] = pack(__float_as_uint(gr), __float_as_uint(ac));
     if (two) {
       KD_G unsigned long long *d = d_arc + 3ll * (lo + rank);
@@ -1168,7 +1168,7 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
             w[3] = pack(static_cast<uint32_t>(arc), 0u);  // (what the host orders a source's arcs by)
             w[0] = pack(static_cast<uint32_t>(ToG(p.lat.tok_newid)[ToG(p.link_src)[at]]),
                         static_cast<uint32_t>(ToG(p.lat.tok_newid)[dst[u]]));
-            w[1] = pack(static_cast<uint32_t>(ar.ilabel), static_cast<uint32_t>(ar.olabel));
+            w[1] = pack(static_cast<uint32_t>(ar.ilabel), static_cast<uint32_t>(ToG(p.arc_olabel)[arc]));
             w[2] = pack(__float_as_uint(ToG(p.link_graph)[at]), __float_as_uint(ToG(p.link_ac)[at]));
           }
           before += __popcll(m);

@@ -141,9 +141,10 @@ __device__ __noinline__ uint32_t PathTail(CParams *pp, int utt, int F, uint32_t 
   }
   if (len <= 0) { __syncthreads(); return 0; }
   // a path longer than the workgroup's staging queue (2 * table slots: 262 k arcs at the
-  // default): the limit that was hit is the queue, not the output pool, so the host must
-  // enlarge the tables (GrowTables) -- growing the pool would fail the same way for ever
-  if (len >= st.cap) { __syncthreads(); return KD_UTT_TABLE_FULL; }
+  // default): the limit that was hit is the queue, not the output pool and not the token
+  // table -- a status of its own, so that the host enlarges the queue (it grows with the
+  // tables: GrowTables) and, where it cannot, says which limit this was
+  if (len >= st.cap) { __syncthreads(); return KD_UTT_PATH_QUEUE_FULL; }
   if (tid == 0) {
     const unsigned long long words = 3ull * len;
     s.out_off = PoolTake(&p.ctl->out_top, p.out_base, p.lat.out_cap, words);
@@ -166,7 +167,7 @@ __device__ __noinline__ uint32_t PathTail(CParams *pp, int utt, int F, uint32_t 
     const float graph_cost = arc.weight;
     const float ac_cost = p.simple ? __uint_as_float(st.tok_f[k]) : tot_cost - graph_cost;
     KD_G unsigned long long *w = o + 3ll * j;
-    w[0] = pack(static_cast<uint32_t>(arc.ilabel), static_cast<uint32_t>(arc.olabel));
+    w[0] = pack(static_cast<uint32_t>(arc.ilabel), static_cast<uint32_t>(ToG(p.arc_olabel)[st.tok_g[k]]));
     w[1] = pack(arc.next & kStateMask, __float_as_uint(graph_cost));
     w[2] = pack(__float_as_uint(ac_cost), 0u);
   }

@@ -315,10 +315,15 @@ __device__ __forceinline__ ArcRange LoadArcRange(const StateRec *base, uint32_t 
   r.arc_begin = v.x; r.emit_end = v.y;
   return r;
 }
-__device__ __forceinline__ ArcRec LoadArcRec(const ArcRec *base, uint32_t i) {
+__device__ __forceinline__ ArcRec LoadArcRec(const ArcPacked *base, uint32_t i) {
   const v4i v = reinterpret_cast<const KD_G v4i *>(ToG(base))[i];
   ArcRec r;
-  r.ilabel = v.x; r.olabel = v.y; r.weight = __int_as_float(v.z); r.next = static_cast<uint32_t>(v.w);
+  const uint32_t lab = static_cast<uint32_t>(v.x);
+  r.ilabel = static_cast<int32_t>(lab & static_cast<uint32_t>(kMaxIlabel));
+  r.dst_degs = lab >> kIlabelBits;
+  r.dst_arcs = static_cast<uint32_t>(v.y);
+  r.weight = __int_as_float(v.z);
+  r.next = static_cast<uint32_t>(v.w);
   return r;
 }
 
@@ -327,7 +332,7 @@ __device__ __forceinline__ ArcRec LoadArcRec(const ArcRec *base, uint32_t i) {
 // branch of its own and waits for it there, so loads written as
 // "if (on) x = load" complete one after the other; written this way a group of them
 // is in flight together.
-__device__ __forceinline__ ArcRec LoadArcRecIf(const ArcRec *base, uint32_t i, bool on, uint32_t safe) {
+__device__ __forceinline__ ArcRec LoadArcRecIf(const ArcPacked *base, uint32_t i, bool on, uint32_t safe) {
   return LoadArcRec(base, on ? i : safe);
 }
 
@@ -856,10 +861,26 @@ __device__ __forceinline__ bool ScoreArc(const FrameCtx<M> &c, const ArcRec &a, 
 }
 
 // Candidate-queue entry `pos` of a tier-1 frame: the first kQL entries are in LDS.
+//
+// Lattice decoders: the entry also carries the DESTINATION's arc range, which the arc record
+// names (ArcPacked) -- its first arc in the low word of the cost key (a lattice key is the float's
+// 32-bit key in the HIGH word; all candidates of one state carry the same low word, so the
+// 64-bit ds_min orders them by cost as before, and the slot ends up holding the word), its
+// degrees in bits 16..27 of the source word (a tier-1 source is a frontier index or a slot:
+// 13 bits and the epsilon flag).  The token a candidate creates thus knows its arcs: neither
+// the epsilon rounds nor the next frame's frontier fetch a state record (two dependent round
+// trips of a frame that consists of little else).
+constexpr uint32_t kT1SrcMask = kSrcEps | 0xFFFFu;
+constexpr int kT1SrcDegShift = 16;
+static_assert(kT1Slots <= 0x10000 && kT1Front <= 0x10000, "a tier-1 source fits 16 bits");
 template <int M>
 __device__ __forceinline__ void T1Put(const FrameCtx<M> &c, int pos, const ArcRec &a, uint32_t aidx,
                                       uint32_t srcid, unsigned long long nk, float aux) {
   Shared &s = c.s;
+  if constexpr (M == 1) {
+    nk |= a.dst_arcs;
+    srcid |= a.dst_degs << kT1SrcDegShift;
+  }
   if (pos < kQL) {
     T1QH(s)[pos] = a.next;
     T1QArc(s)[pos] = aidx;
@@ -2204,6 +2225,8 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       for (int i = lo + tid; i < hi; i += nt) {
         const uint32_t k = q_h(w, i);
         const unsigned long long nk = q_nk(w, i);
+        [[maybe_unused]] uint32_t degs = 0;
+        if constexpr (M == 1) degs = (q_src(w, i) & ~kSrcEps) >> kT1SrcDegShift;
         uint32_t h = kKeyEmpty;
         if ((EPS || nk < cutkey) && !s.overflow) {
           h = t.Claim(k);
@@ -2216,6 +2239,9 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
               const int pos = AggInc(&s.n_live);
               if (pos < static_cast<int>(t.FillLimit())) T1Live(s)[pos] = static_cast<uint16_t>(h);
               else s.overflow = 1;
+              // (lattice decoders: the slot's cost word holds the state's first arc in its low
+              // half -- it came with the key -- and its free arc word takes the degrees)
+              if constexpr (M == 1) s.arc[h] = degs;
               push = (k & kHasEps) != 0;  // every new token is expanded once (:63-65)
             } else if (EPS && old > nk && (k & kHasEps)) {  // re-queue on improvement, :97-113
               push = true;
@@ -2269,11 +2295,36 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
         bool ok[2], own[2];
         StateRec r[2];
         int abeg[2], deg[2];
+        if constexpr (M == 1) {
+          // the token's epsilon arcs are known from the arc that created it (T1Put): the
+          // slot's cost word holds the state's first arc, its arc word the degrees
+          uint32_t dg[2], first[2];
+          bool lookup = false;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          cst[j] = KC<M>(s.cost[h[j]]);
-          ok[j] = (j == 0 || two) && !(cst[j] > c.cutoff);  // :74
-          r[j] = LoadState(p.states, s.key[h[j]] & kStateMask);
+          for (int j = 0; j < 2; ++j) {
+            const unsigned long long cw = s.cost[h[j]];
+            cst[j] = KC<M>(cw);
+            first[j] = static_cast<uint32_t>(cw);
+            dg[j] = s.arc[h[j]];
+            ok[j] = (j == 0 || two) && !(cst[j] > c.cutoff);  // :74
+            lookup |= ok[j] && (DegsEmit(dg[j]) == kEmitDegEscape || DegsEps(dg[j]) == kEpsDegEscape);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            r[j].emit_end = static_cast<int32_t>(first[j] + DegsEmit(dg[j]));
+            r[j].arc_end = r[j].emit_end + static_cast<int32_t>(DegsEps(dg[j]));
+          }
+          if (lookup) {  // (a degree that does not fit its field: the state record, as ever)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) r[j] = LoadState(p.states, s.key[h[j]] & kStateMask);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            cst[j] = KC<M>(s.cost[h[j]]);
+            ok[j] = (j == 0 || two) && !(cst[j] > c.cutoff);  // :74
+            r[j] = LoadState(p.states, s.key[h[j]] & kStateMask);
+          }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -2368,16 +2419,27 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   ArcRange next_rec[kNextRecs];
   bool next_on[kNextRecs];
   {
+    // (lattice decoders: a token's arc range came with the arc that created it -- its slot
+    // holds it -- and only a degree that does not fit its field is looked up here)
     uint32_t st_next[kNextRecs];
 #pragma unroll
     for (int j = 0; j < kNextRecs; ++j) {
       const int i = tid + j * nt;
       next_on[j] = next_small && i < n_out;
       const int h = T1Live(s)[next_on[j] ? i : 0];
+      if constexpr (M == 1) next_on[j] = next_on[j] && DegsEmit(s.arc[h]) == kEmitDegEscape;
       st_next[j] = next_on[j] ? s.key[h] & kStateMask : 0u;  // (before the key words become indices)
     }
+    bool any_on = false;
 #pragma unroll
-    for (int j = 0; j < kNextRecs; ++j) next_rec[j] = LoadArcRange(p.states, st_next[j]);
+    for (int j = 0; j < kNextRecs; ++j) any_on |= next_on[j];
+    if (M != 1 || __ballot(any_on)) {
+#pragma unroll
+      for (int j = 0; j < kNextRecs; ++j) next_rec[j] = LoadArcRange(p.states, st_next[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kNextRecs; ++j) next_rec[j] = ArcRange{0, 0};
+    }
   }
   for (int i = tid; i < n_out; i += nt) {
     const int h = T1Live(s)[i];
@@ -2387,11 +2449,21 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     ToG(p.tok_state)[g] = static_cast<int32_t>(st);
     ToG(p.tok_cost)[g] = KC<M>(ck);
     if (c.lattice) ToG(p.tok_extra)[g] = 0.0f;  // lattice-simple-decoder.cc:91-95
-    my_min = ck < my_min ? ck : my_min;
+    // (lattice: the key without the arc index that rides in its low word -- the next frame
+    // looks for its best token by this value)
+    const unsigned long long ckc = M == 1 ? ck & 0xFFFFFFFF00000000ull : ck;
+    my_min = ckc < my_min ? ckc : my_min;
     s.key[h] = static_cast<uint32_t>(i);
     if (next_small) {
       s.it_cost[i] = KC<M>(ck);
       s.it_src[i] = st;
+      if constexpr (M == 1) {
+        const uint32_t emit = DegsEmit(s.arc[h]);
+        if (emit != kEmitDegEscape) {
+          s.it_abeg[i] = static_cast<int32_t>(static_cast<uint32_t>(ck));
+          s.it_deg[i] = static_cast<int32_t>(emit);
+        }
+      }
     }
   }
   if (my_min != kCostDead && my_min < s.f_best_next) atomicMin(&s.f_best_next, my_min);
@@ -2428,7 +2500,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       for (int i = lo + tid; i < hi; i += nt) {
         // the entry's queue words together, then its table words together (read one
         // by one behind the tests below, each waits for the one before it)
-        const uint32_t h = q_h(w, i), sr = q_src(w, i), aidx = q_arc(w, i);
+        const uint32_t h = q_h(w, i), sr = q_src(w, i) & (M == 1 ? kT1SrcMask : ~0u), aidx = q_arc(w, i);
         const float qa = q_ac(w, i), qg = q_gr(w, i);
         const unsigned long long nk = q_nk(w, i);
         const bool ok = h != kKeyEmpty, eps = i >= q_emit;
@@ -2487,10 +2559,17 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       s.it_deg[tid + j * nt] = next_rec[j].emit_end - next_rec[j].arc_begin;
     }
   }
-  if (tid == 64) {
-    // launch counters, by a thread of another wave than the one that prepares the next
-    // frame (fire-and-forget LDS adds; the per-lane work counters are folded once, when
-    // the launch ends)
+  // Everything below that READS the frame's counters (n_emit_fin, n_eps_fin, best_next) and
+  // the reset of those counters for the next frame are done by lanes of ONE wave, the first:
+  // within a wave LDS operations execute in program order, between waves only a barrier
+  // orders them.  (Until round 4 the third wave did the reset while the first wrote the frame
+  // index: had the first wave ever fallen behind the third by the length of the table-clearing
+  // loop above, it would have read zeros -- a frame with no links, a next frame without a best
+  // cost.  Never seen in the shipped build; the timing-perturbation build (make jitter) fails
+  // nine cases in ten on it.)
+  if (tid == 32) {
+    // launch counters (fire-and-forget LDS adds; the per-lane work counters are folded once,
+    // when the launch ends)
     atomicAdd(&s.ustat[KD_STAT_ARCS_KEPT], static_cast<unsigned long long>(q_emit));
     atomicAdd(&s.ustat[KD_STAT_TOKENS_OUT], static_cast<unsigned long long>(n_out));
     atomicMax(&s.ustat[KD_STAT_MAX_TOKENS], static_cast<unsigned long long>(n_out));
@@ -2518,7 +2597,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     s.ctl[frame & 1].n_in = n_out;
     s.ctl[frame & 1].base_out = base_out;
   }
-  ResetFrame<M>(s, 128);  // (the third wave: the first two write the frame index and the counters)
+  ResetFrame<M>(s, 0);  // (the first wave, behind its own reads above)
   return 0;
 }
 
@@ -2938,12 +3017,22 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
         q_emit = Uni(s.ctl[frame & 1].q_emit);
         c.cutoff = Uni(s.ctl[frame & 1].cutoff);
         const int nl = q_emit < kQL ? q_emit : kQL;
+        // (lattice: without the destination's arc range that tier-1 entries carry in the low
+        // word of the key and the upper bits of the source: T1Put)
+        constexpr unsigned long long kNkMask = M == 1 ? 0xFFFFFFFF00000000ull : ~0ull;
+        constexpr uint32_t kSrMask = M == 1 ? kT1SrcMask : ~0u;
         for (int i = tid; i < nl; i += kBlock) {
           c.q_arc[i] = T1QArc(s)[i];
-          c.q_src[i] = T1QSrc(s)[i];
-          c.q_nk[i] = T1QNk(s)[i];
+          c.q_src[i] = T1QSrc(s)[i] & kSrMask;
+          c.q_nk[i] = T1QNk(s)[i] & kNkMask;
           if (c.lattice) c.q_ac[i] = T1QAc(s)[i];  // (allocated for the lattice decoders only)
           if (c.lattice) c.q_gr[i] = T1QGr(s)[i];
+        }
+        if constexpr (M == 1) {
+          for (int i = kQL + tid; i < q_emit; i += kBlock) {
+            c.q_src[i] &= kSrMask;
+            c.q_nk[i] &= kNkMask;
+          }
         }
         filtered = true;
         cnt.eps_exp = 0;

@@ -62,6 +62,47 @@ def test_cfg2_full_size_hl_max_active_3000(oracle):
         assert paths[i].osyms.tolist() == pr.osyms.tolist(), i
 
 
+def test_cfg2_hl_batch_64_one_launch(oracle):
+    """configs[1] at its real batch: FasterDecoder over the HL graph, B = 64 utterances of
+    T = 250 in ONE launch, beam 16, max_active = 3000 (binding on the flat-posterior quarter of
+    the batch).  Every utterance decodes all its frames; 8 sampled utterances against the
+    canonical oracle (arcs, states, costs, last frontier) and the reference-order decoder
+    (labels)."""
+    import torch
+    import bench
+    wl = bench.WORKLOADS["hl"]
+    g = synth.hl_graph(**wl["graph"])
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T, V = wl["batch"], wl["frames"], wl["V"]
+    assert B == 64
+    lps = [synth.make_logprobs(T, V, 700 + i, peak=4.0 if i % 4 == 3 else 12.0, lexicon=g["lexicon"])
+           for i in range(B)]
+    dev = torch.from_numpy(np.stack(lps)).cuda()
+    bt = cabi.Batch(G, max_batch=B, **wl["opts"])
+    bt.decode_tensor(dev)
+    assert bt.num_frames_decoded().tolist() == [T] * B
+    assert not bt.status().any()
+    paths, rf = bt.best_paths(), bt.reached_final()
+    st = bt.stats()
+    assert st[3::4, 8].min() > wl["opts"]["max_active"]  # (the flat ones exceed it before the cut)
+    for i in (0, 3, 7, 21, 22, 35, 50, 63):
+        can = oracle.FasterDecoder(OG, policy=1, **wl["opts"])
+        can.decode(lps[i])
+        p = can.get_best_path()
+        for k in ("ilabel", "olabel", "state", "graph_cost", "ac_cost"):
+            assert getattr(paths[i], k).tolist() == getattr(p, k).tolist(), (i, k)
+        assert tuple(paths[i].final_weight) == tuple(p.final_weight)
+        assert bool(rf[i]) == can.reached_final()
+        s, c = bt.frame_tokens(i, T)
+        so, co = can.tokens()
+        assert s.tolist() == so.tolist() and c.tolist() == co.tolist(), i
+        ref = oracle.FasterDecoder(OG, policy=0, **wl["opts"])
+        ref.decode(lps[i])
+        pr = ref.get_best_path()
+        assert paths[i].isyms.tolist() == pr.isyms.tolist(), i
+        assert paths[i].osyms.tolist() == pr.osyms.tolist(), i
+
+
 def test_cfg5_large_lm_hlg_beam17_default_capacities(oracle):
     """configs[4]: LatticeFasterDecoder over a large-LM HLG (200 k words: 52.8 M states,
     141 M arcs = 2.26 GB of arc records), beam 17, lattice beam 8, T = 250, library DEFAULT

@@ -337,3 +337,29 @@ def test_host_async_from_pinned_rows_that_are_refilled_at_once(oracle):
         paths = bt.best_paths()
         for i in range(B):
             _assert_same_path(paths[i], want[i], i)
+
+
+def test_best_path_longer_than_the_staging_queue_grows_the_queue(oracle):
+    """GetBestPath stages the path in the workgroup's candidate queue (2 x table_slots entries).
+    A path of 40 x 1001 arcs -- a chain of a thousand epsilon arcs walked once per frame --
+    against a queue of 2 x 2^14: the utterance stops with KD_UTT_PATH_QUEUE_FULL (a status of
+    its own: neither the token table nor the output pool is what ran out), the host grows the
+    per-workgroup tables and asks again; with no_grow the message names the limit."""
+    L, T = 1000, 40
+    arcs = [(i, i + 1, 0, 0, 0.0) for i in range(L)] + [(L, 0, 1, 7, 0.5), (L, L, 2, 0, 3.0)]
+    g = synth.graph_from_arcs(L + 1, 0, arcs, {L: 0.0})
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    lp = np.zeros((T, 2), np.float32)
+    bt = cabi.Batch(G, max_batch=1, beam=8.0, min_active=0, table_slots=1 << 14)
+    slots0 = bt.capacity()["table_slots"]
+    bt.decode_host([lp])
+    p = bt.best_paths()[0]
+    d = oracle.FasterDecoder(OG, beam=8.0, min_active=0, policy=1)
+    d.decode(lp)
+    _assert_same_path(p, d.get_best_path(), "long")
+    assert len(p.ilabel) == T * (L + 1) > 2 * slots0
+    assert bt.capacity()["table_slots"] > slots0
+    fixed = cabi.Batch(G, max_batch=1, beam=8.0, min_active=0, table_slots=1 << 14, no_grow=1)
+    with pytest.raises(RuntimeError, match="best path longer than the staging queue"):
+        fixed.decode_host([lp])
+        fixed.best_paths()

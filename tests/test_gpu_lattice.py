@@ -295,6 +295,36 @@ def test_pools_and_tables_grow_on_demand(oracle):
         fixed.decode_device([d.data_ptr() for d in dev], [T] * B, V)
 
 
+def test_pool_cursor_is_pulled_back_after_an_overshoot(oracle):
+    """A take that does not fit pushes the pool's cursor past the capacity (one atomic add, never
+    taken back: kd_search.hip PoolChunk), and every workgroup that runs into the end in the same
+    launch pushes it further -- here by a frame's worth of tokens each (oversized requests: a
+    frame of some ten thousand tokens against a pool of 1024).  The host pulls the cursor back
+    to the capacity before it resumes (kd_api.hip ReadBack), so what the failed takes skipped is
+    not lost: the pools end within a doubling of what the decode wrote, where they would
+    otherwise have to outgrow the accumulated overshoot of a dozen relaunches."""
+    import torch
+    g = synth.random_graph(20000, 4.0, 16, 0.1, 77)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T, V = 8, 6, 16
+    opts = dict(beam=20.0, lattice_beam=3.0, min_active=0, prune_interval=1 << 20)
+    lps = [synth.make_logprobs(T, V, 60 + i, peak=0.5) for i in range(B)]
+    dev = torch.from_numpy(np.stack(lps)).cuda()
+    lb = cabi.LatticeBatch(G, max_batch=B, arena_tokens=1024, arena_links=1024, **opts)
+    lb.decode_tensor(dev)
+    cap, st = lb.capacity(), lb.stats()
+    wrote_tokens = int(st[:, 5].sum()) + B  # tokens_out of every frame + the start tokens
+    wrote_links = int(st[:, 10].sum())
+    assert cap["grow_events"] >= 8 and wrote_tokens > 100 * 1024
+    assert cap["arena_tokens"] <= 2.5 * wrote_tokens, (cap, wrote_tokens)
+    assert cap["arena_links"] <= 2.5 * wrote_links, (cap, wrote_links)
+    lats = lb.raw_lattices()
+    for i in (0, B - 1):
+        can = oracle.CanonLatticeDecoder(OG, beam=20.0, lattice_beam=3.0)
+        can.decode(lps[i])
+        _assert_same_lattice(lats[i], can.get_raw_lattice(), i)
+
+
 def test_more_utterances_than_workgroups_and_table_growth_mid_launch(oracle):
     """A launch has at most one workgroup per CU (256) and 300 utterances here: workgroups
     take second utterances from the work queue.  The frontier (tens of thousands of tokens
@@ -569,6 +599,19 @@ def test_lattices_exported_into_a_lent_device_buffer(oracle):
         for i in range(B):
             assert _same_arrays(got[i], want[i]), i
             assert _same_arrays(mine[i], want[i]), i
+    # an export that runs APART from the decode (step-wise API: advance, finalize, then
+    # GetRawLattice) goes through the general, arena-ordered export, which the host puts in
+    # order: raw_lattice_table mirrors the ordered regions into the lent buffer
+    buf.zero_()
+    lb.init_decoding(B)
+    lb.advance_device([dev[i].data_ptr() for i in range(B)], [T] * B, V)
+    lb.finalize_decoding()
+    mine = lb.raw_lattices()
+    used, table = lb.raw_lattice_table()
+    got = sharded.unpack_pool(sharded.pool_payload(buf, used, table))
+    for i in range(B):
+        assert _same_arrays(mine[i], want[i]), i
+        assert _same_arrays(got[i], want[i]), i
     lb.set_output_buffer(torch.zeros(64, dtype=torch.int64, device="cuda"))
     with pytest.raises(RuntimeError, match="output buffer"):
         lb.decode_tensor(dev)

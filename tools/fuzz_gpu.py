@@ -60,7 +60,8 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     t_end = time.time() + budget
-    n_cases = n_lat = n_1b = 0
+    n_cases = n_lat = n_1b = n_bad = 0
+    keep_going = os.environ.get("KD_FUZZ_KEEP_GOING") == "1"  # (diagnosis: count mismatches, do not stop)
     while time.time() < t_end:
         g, lex, V = graph(rng)
         G, OG = cabi.Graph(g), oracle.Graph(g)
@@ -103,7 +104,9 @@ def main():
                         frc[i] == can.final_relative_cost() or
                         (np.isinf(frc[i]) and np.isinf(can.final_relative_cost()))):
                     print("LATTICE MISMATCH", tag, dict(lbeam=lbeam, pi=pi, utt=i), flush=True)
-                    sys.exit(1)
+                    n_bad += 1
+                    if not keep_going:
+                        sys.exit(1)
             n_lat += 1
         else:
             opts = dict(beam=beam, max_active=ma, min_active=mi)
@@ -125,9 +128,14 @@ def main():
                         or q.ac_cost.tolist() != p.ac_cost.tolist() or q.graph_cost.tolist() != p.graph_cost.tolist()
                         or tuple(q.final_weight) != tuple(p.final_weight) or bool(rf[i]) != d.reached_final()):
                     print("PATH MISMATCH", tag, dict(uf=uf, utt=i), flush=True)
-                    sys.exit(1)
+                    n_bad += 1
+                    if not keep_going:
+                        sys.exit(1)
             n_1b += 1
         n_cases += 1
+    if n_bad:
+        print(f"fuzz FAILED: {n_bad} mismatching utterances in {n_cases} cases")
+        sys.exit(1)
     print(f"fuzz ok: {n_cases} cases ({n_lat} lattice, {n_1b} 1-best) in {budget:.0f} s")
 
 

@@ -3,6 +3,7 @@
 committed summaries under profiles/ (per round).
 
     python tools/summarize_profile.py r01
+    python tools/summarize_profile.py r04 large     (tools/profile_large.sh: the large-LM workload)
 
 Expects gpurun_out/prof_<round>_trace (--kernel-trace --stats),
 gpurun_out/prof_<round>_fetch (--pmc FETCH_SIZE) and gpurun_out/prof_<round>_write
@@ -52,11 +53,17 @@ def counter(path, name):
 
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    large = len(sys.argv) > 2 and sys.argv[2] == "large"
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    stats = one(f"prof_{rnd}_trace/*/*_kernel_stats.csv")
-    trace = one(f"prof_{rnd}_trace/*/*_kernel_trace.csv")
-    shutil.copy(stats, os.path.join(out, f"{rnd}_kernel_stats.csv"))
+    # (directory names as tools/profile_round.sh and tools/profile_large.sh make them)
+    d_trace = f"prof_{rnd}_large" if large else f"prof_{rnd}_trace"
+    d_fetch, d_write = (f"prof_{rnd}_large_fetch", f"prof_{rnd}_large_write") if large else (
+        f"prof_{rnd}_fetch", f"prof_{rnd}_write")
+    name = f"{rnd}_hlg_large" if large else rnd
+    stats = one(f"{d_trace}/*/*_kernel_stats.csv")
+    trace = one(f"{d_trace}/*/*_kernel_trace.csv")
+    shutil.copy(stats, os.path.join(out, f"{name}_kernel_stats.csv"))
     rows = [r for r in csv.DictReader(open(trace)) if KERNEL in r["Kernel_Name"]]
     dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6  # noqa: E731
     full = sorted(dur(r) for r in rows if full_launch(r))
@@ -66,10 +73,10 @@ def main():
     for r in csv.DictReader(open(trace)):
         by[r["Kernel_Name"][:60]] = by.get(r["Kernel_Name"][:60], 0.0) + dur(r)
     tot = sum(by.values())
-    fetch_kb, nf = counter(one(f"prof_{rnd}_fetch/*/*_counter_collection.csv"), "FETCH_SIZE")
-    write_kb, nw = counter(one(f"prof_{rnd}_write/*/*_counter_collection.csv"), "WRITE_SIZE")
+    fetch_kb, nf = counter(one(f"{d_fetch}/*/*_counter_collection.csv"), "FETCH_SIZE")
+    write_kb, nw = counter(one(f"{d_write}/*/*_counter_collection.csv"), "WRITE_SIZE")
     bench = {}
-    bj = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}_trace.json")
+    bj = os.path.join(ROOT, "gpurun_out", f"{d_trace}.json")
     if os.path.exists(bj):
         txt = open(bj).read().strip().splitlines()
         if txt:
@@ -77,6 +84,7 @@ def main():
     summary = {
         "round": rnd,
         "command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --headline-only "
+                   + ("--workload hlg-large " if large else "") +
                    "(+ one run each with --pmc FETCH_SIZE / --pmc WRITE_SIZE)",
         "kernel": KERNEL,
         "full_launches": len(full),
@@ -98,7 +106,7 @@ def main():
                 "the launches; the trace pass does not (launches of calls in flight overlap).",
         "bench_line_under_profiler": bench,
     }
-    with open(os.path.join(out, f"{rnd}_summary.json"), "w") as f:
+    with open(os.path.join(out, f"{name}_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps({k: v for k, v in summary.items() if k != "bench_line_under_profiler"}, indent=1))
 
