@@ -1541,7 +1541,7 @@ __device__ __noinline__ uint32_t LatticeTail(CParams *pp, int utt, int F, uint32
     s.r_out_off = -1;
     s.r_arena_order = 0;
   }
-#ifdef KD_PROFILE
+#if defined(KD_PROFILE) && !defined(KD_PROF_SIZE)
   // diagnostic build: cycles of the tail's three parts, buckets 20-22 of the utterance
   long long lap = static_cast<long long>(__builtin_amdgcn_s_memtime());
   auto tail_lap = [&](int bucket) {

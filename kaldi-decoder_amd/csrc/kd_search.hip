@@ -253,6 +253,7 @@ struct Shared {
 #ifdef KD_PROFILE
   long long cyc[kProfSlots];
   long long lap_last;
+  int lap_on, lap_pad;  // (KD_PROF_NMIN / KD_PROF_NMAX: only frames of that frontier size are timed)
 #endif
 };
 static_assert(sizeof(Shared) <= 163840 / KD_WG_PER_CU, "LDS budget");
@@ -354,12 +355,12 @@ constexpr int kBucketSmall = 19, kBucketBig = 19, kBucketSpill = -1;
 #else
 constexpr int kBucketSmall = 19, kBucketBig = -1, kBucketSpill = 14;
 #endif
-#ifdef KD_PROFILE
+#if defined(KD_PROFILE) && !defined(KD_PROF_SIZE)
 #define KD_LAP(s, i)                                                              \
   do {                                                                            \
     if (threadIdx.x == 0) {                                                       \
       const long long now_ = static_cast<long long>(__builtin_amdgcn_s_memtime()); \
-      (s).cyc[KD_BUCKET < 0 ? (i) : KD_BUCKET] += now_ - (s).lap_last;                       \
+      if ((s).lap_on) (s).cyc[KD_BUCKET < 0 ? (i) : KD_BUCKET] += now_ - (s).lap_last;      \
       (s).lap_last = now_;                                                        \
     }                                                                             \
   } while (0)
@@ -2864,7 +2865,10 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   }
 #ifdef KD_PROFILE
   if (tid < kProfSlots) s.cyc[tid] = 0;
-  if (tid == 0) s.lap_last = static_cast<long long>(__builtin_amdgcn_s_memtime());
+  if (tid == 0) {
+    s.lap_last = static_cast<long long>(__builtin_amdgcn_s_memtime());
+    s.lap_on = 1;
+  }
 #endif
   if (search) FullClear<true>(tl, s);
 
@@ -2949,6 +2953,17 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       }
     }
     KD_LAP(s, 13);
+#if defined(KD_PROFILE) && defined(KD_PROF_NMIN)
+    if (tid == 0) s.lap_on = c.n_in >= KD_PROF_NMIN && c.n_in < KD_PROF_NMAX;
+#endif
+#ifdef KD_PROF_SIZE
+    // -DKD_PROFILE -DKD_PROF_SIZE (make knob; tools/prof_sizes.py): the frames' cycles by the
+    // SIZE of their frontier -- classes 0, 1, 2-3, 4-7, ..., 512-1023, >= 1024: sums in buckets
+    // 0..11, counts in 12..23 -- instead of by phase
+    const int prof_n = c.n_in;
+    long long prof_t0 = 0;
+    if (tid == 0) prof_t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
+#endif
     Counters cnt;
     bool small = false;
     if constexpr (!c.simple) small = frame >= 0 && c.n_in <= kT1Front;
@@ -3061,6 +3076,14 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       __syncthreads();
     }
     if (r != 0) { err |= r; break; }
+#ifdef KD_PROF_SIZE
+    if (tid == 0) {
+      int cls = 0;
+      while ((1 << cls) <= prof_n && cls < 11) ++cls;
+      s.cyc[cls] += static_cast<long long>(__builtin_amdgcn_s_memtime()) - prof_t0;
+      s.cyc[12 + cls] += 1;
+    }
+#endif
     frame++;
   }
 

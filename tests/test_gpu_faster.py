@@ -341,7 +341,8 @@ def test_host_async_from_pinned_rows_that_are_refilled_at_once(oracle):
 
 def test_best_path_longer_than_the_staging_queue_grows_the_queue(oracle):
     """GetBestPath stages the path in the workgroup's candidate queue (2 x table_slots entries).
-    A path of 40 x 1001 arcs -- a chain of a thousand epsilon arcs walked once per frame --
+    A path of 1000 + 40 x 1001 arcs -- a chain of a thousand epsilon arcs walked by InitDecoding
+    and once more per frame --
     against a queue of 2 x 2^14: the utterance stops with KD_UTT_PATH_QUEUE_FULL (a status of
     its own: neither the token table nor the output pool is what ran out), the host grows the
     per-workgroup tables and asks again; with no_grow the message names the limit."""
@@ -357,7 +358,7 @@ def test_best_path_longer_than_the_staging_queue_grows_the_queue(oracle):
     d = oracle.FasterDecoder(OG, beam=8.0, min_active=0, policy=1)
     d.decode(lp)
     _assert_same_path(p, d.get_best_path(), "long")
-    assert len(p.ilabel) == T * (L + 1) > 2 * slots0
+    assert len(p.ilabel) == L + T * (L + 1) > 2 * slots0
     assert bt.capacity()["table_slots"] > slots0
     fixed = cabi.Batch(G, max_batch=1, beam=8.0, min_active=0, table_slots=1 << 14, no_grow=1)
     with pytest.raises(RuntimeError, match="best path longer than the staging queue"):
