@@ -1996,19 +1996,61 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     float aux[N];
     bool keep[N];
     int pre[N], total = 0;
+    if constexpr (M == 1 && !EPS) {
+      if (c.ll_in_lds) {
+        // Lattice decoders, emitting arcs, row in LDS (every HLG / HL / H decode): the rows'
+        // log-likelihoods are read TOGETHER and the rows scored without a branch.  Written
+        // row by row under `if (on[g])`, each row waits for its own LDS read behind the
+        // branch (four exposed LDS round trips an iteration, in the kernel's hottest loop:
+        // a quarter of the frames -- frontiers of 512-1023 tokens -- spend 40 % of their
+        // cycles here).  The arithmetic is ScoreArc's (lattice-simple-decoder.cc:383-390).
+        // (A lane without an arc holds arc 0 -- LoadArcRecIf -- whose ilabel may be 0.)
+        float llv[N];
 #pragma unroll
-    for (int g = 0; g < N; ++g) {
-      keep[g] = false;
-      nk[g] = 0;
-      aux[g] = 0.f;
-      if (on[g]) {
-        double nc;
-        keep[g] = ScoreArc<EPS>(c, ar[g], cst[g], seen, nc, aux[g]);
-        nk[g] = CK<M>(nc);
+        for (int g = 0; g < N; ++g) llv[g] = s.ll[on[g] ? ar[g].ilabel - 1 : 0];
+        const float lim = KCf<M>(seen) + c.adaptive_beam;
+#pragma unroll
+        for (int g = 0; g < N; ++g) {
+          const float ac_cost = -llv[g], cur_cost = static_cast<float>(cst[g]),
+                      tot_cost = cur_cost + ac_cost + ar[g].weight;
+          keep[g] = on[g] && tot_cost < lim;
+          nk[g] = CKf<M>(tot_cost);
+          aux[g] = ac_cost;
+          bal[g] = __ballot(keep[g]);
+          pre[g] = total;
+          total += __popcll(bal[g]);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < N; ++g) {
+          keep[g] = false;
+          nk[g] = 0;
+          aux[g] = 0.f;
+          if (on[g]) {
+            double nc;
+            keep[g] = ScoreArc<EPS>(c, ar[g], cst[g], seen, nc, aux[g]);
+            nk[g] = CK<M>(nc);
+          }
+          bal[g] = __ballot(keep[g]);
+          pre[g] = total;
+          total += __popcll(bal[g]);
+        }
       }
-      bal[g] = __ballot(keep[g]);
-      pre[g] = total;
-      total += __popcll(bal[g]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < N; ++g) {
+        keep[g] = false;
+        nk[g] = 0;
+        aux[g] = 0.f;
+        if (on[g]) {
+          double nc;
+          keep[g] = ScoreArc<EPS>(c, ar[g], cst[g], seen, nc, aux[g]);
+          nk[g] = CK<M>(nc);
+        }
+        bal[g] = __ballot(keep[g]);
+        pre[g] = total;
+        total += __popcll(bal[g]);
+      }
     }
     if (total == 0) return;
     int base = 0;
