@@ -57,7 +57,13 @@ int kd_device_count(void);
  * [row_ptr[s], row_ptr[s+1]); ilabel 0 is epsilon; final_cost[s] = +inf means
  * Weight::Zero() (not final).  The arrays are copied; the device copy is laid
  * out as 16-byte state records and 16-byte arcs with every state's emitting
- * arcs first (stable), and lives until kd_graph_destroy.
+ * arcs first (stable) -- an arc record also names its destination's arc range,
+ * the olabels live in a side array -- and lives until kd_graph_destroy.
+ * KD_E_INVALID: ilabels of 2^20 or more (20 bits of the arc record); a graph with an epsilon
+ * cycle of total weight zero, or with a negative arc on an epsilon cycle (the reference ends
+ * on the first only because an equal cost is no improvement -- and prunes its lattice to
+ * another fixpoint than any order-free sweep -- and does not end on the second; cycles of
+ * positive weight decode exactly like the reference: csrc/kd_graph_check.h).
  */
 int kd_graph_create(int device, int32_t num_states, int32_t start,
                     const int32_t *row_ptr, const int32_t *ilabel,

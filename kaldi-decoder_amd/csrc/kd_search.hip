@@ -973,19 +973,41 @@ __device__ __forceinline__ void ScoreBatchBig(const FrameCtx<M> &c, const ArcRec
   float aux[N];
   bool keep[N];
   int pre[N], total = 0;
+  bool grouped = false;
+  if constexpr (M == 1 && !EPS) grouped = c.ll_in_lds;  // (a constant in each copy of the frame)
+  if (grouped) {
+    // lattice decoders, emitting arcs, row in LDS: the rows' log-likelihood reads together,
+    // the rows scored without a branch (see the tier-1 frames' score_batch)
+    float llv[N];
 #pragma unroll
-  for (int g = 0; g < N; ++g) {
-    keep[g] = false;
-    nk[g] = 0;
-    aux[g] = 0.f;
-    if (on[g]) {
-      double nc;
-      keep[g] = ScoreArc<EPS>(c, ar[g], cst[g], seen, nc, aux[g]);
-      nk[g] = CK<M>(nc);
+    for (int g = 0; g < N; ++g) llv[g] = s.ll[on[g] ? ar[g].ilabel - 1 : 0];
+    const float lim = KCf<M>(seen) + c.adaptive_beam;
+#pragma unroll
+    for (int g = 0; g < N; ++g) {
+      const float ac_cost = -llv[g], cur_cost = static_cast<float>(cst[g]),
+                  tot_cost = cur_cost + ac_cost + ar[g].weight;
+      keep[g] = on[g] && tot_cost < lim;
+      nk[g] = CKf<M>(tot_cost);
+      aux[g] = ac_cost;
+      bal[g] = __ballot(keep[g]);
+      pre[g] = total;
+      total += __popcll(bal[g]);
     }
-    bal[g] = __ballot(keep[g]);
-    pre[g] = total;
-    total += __popcll(bal[g]);
+  } else {
+#pragma unroll
+    for (int g = 0; g < N; ++g) {
+      keep[g] = false;
+      nk[g] = 0;
+      aux[g] = 0.f;
+      if (on[g]) {
+        double nc;
+        keep[g] = ScoreArc<EPS>(c, ar[g], cst[g], seen, nc, aux[g]);
+        nk[g] = CK<M>(nc);
+      }
+      bal[g] = __ballot(keep[g]);
+      pre[g] = total;
+      total += __popcll(bal[g]);
+    }
   }
   if (total == 0) return;
   int base = 0;
