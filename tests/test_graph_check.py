@@ -1,0 +1,101 @@
+"""kd_graph_create's epsilon-cycle check (csrc/kd_graph_check.h: in-degree peel, iterative
+Tarjan, a second peel over the zero-weight arcs) against a brute-force statement of the same
+rule on thousands of small random graphs -- compiled on its own with
+-fsanitize=address,undefined, so that an index slip in the iterative SCC code shows as a
+report, not as a wrong answer on some real graph later.
+
+The rule: an epsilon arc s -> d lies on an epsilon cycle iff d reaches s through epsilon arcs
+(or d == s).  Refused: a NEGATIVE arc on a cycle; a cycle made of ZERO-weight arcs only
+(a zero-weight arc s -> d such that d reaches s through zero-weight epsilon arcs, or d == s)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _closure(adj):
+    r = adj.copy()
+    n = len(r)
+    for k in range(n):
+        r |= np.outer(r[:, k], r[k, :])
+    return r
+
+
+def _rule(S, src, dst, il, w):
+    eps = il == 0
+    adj = np.zeros((S, S), bool)
+    adj[src[eps], dst[eps]] = True
+    reach = _closure(adj)
+    z = eps & (w == 0.0)
+    zadj = np.zeros((S, S), bool)
+    zadj[src[z], dst[z]] = True
+    zreach = _closure(zadj)
+    for a in np.nonzero(eps)[0]:
+        s, d = src[a], dst[a]
+        on_cycle = d == s or reach[d, s]
+        if on_cycle and w[a] < 0:
+            return False
+        if w[a] == 0.0 and (d == s or zreach[d, s]):
+            return False
+    return True
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("gc") / "graph_check_driver")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I", os.path.join(ROOT, "kaldi-decoder_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "native", "graph_check_driver.cc"), "-o", exe], check=True)
+    return exe
+
+
+def test_epsilon_cycle_check_matches_the_rule_on_random_graphs(driver):
+    rng = np.random.default_rng(7)
+    blobs, want = [], []
+    for case in range(3000):
+        S = int(rng.integers(1, 14))
+        A = int(rng.integers(0, 40))
+        src = np.sort(rng.integers(0, S, A)).astype(np.int32)
+        dst = rng.integers(0, S, A).astype(np.int32)
+        il = np.where(rng.random(A) < 0.6, 0, rng.integers(1, 5, A)).astype(np.int32)
+        # weights from a small set so that zero and negative arcs, and zero CYCLES, are common
+        w = rng.choice(np.asarray([0.0, 0.0, 0.5, 1.0, -0.5], np.float32), A).astype(np.float32)
+        if case % 3 == 0:
+            w = np.abs(w)
+        row_ptr = np.zeros(S + 1, np.int32)
+        np.add.at(row_ptr, src + 1, 1)
+        row_ptr = np.cumsum(row_ptr).astype(np.int32)
+        blobs.append(np.asarray([S, A], np.int32).tobytes() + row_ptr.tobytes() + il.tobytes() +
+                     dst.tobytes() + w.tobytes())
+        want.append(_rule(S, src, dst, il, w))
+    r = subprocess.run([driver], input=b"".join(blobs), capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    got = [ln.split(" ", 1) for ln in r.stdout.decode().splitlines()]
+    assert len(got) == len(want)
+    assert [g[0] == "1" for g in got] == want
+    assert 0.2 < np.mean(want) < 0.8  # (both answers are common: the test has teeth)
+    msgs = {g[1].split(" through")[0].split(" of")[0] for g in got if g[0] == "0"}
+    assert len(msgs) >= 1
+
+
+def test_epsilon_cycle_check_on_a_long_chain_and_a_big_cycle(driver):
+    """Depth: a chain of 200 000 epsilon arcs (no recursion to overflow) closed into one cycle by
+    a last arc -- positive (accepted), zero (refused), negative (refused)."""
+    S = 200000
+    row_ptr = np.arange(S + 1, dtype=np.int32)
+    il = np.zeros(S, np.int32)
+    dst = ((np.arange(S) + 1) % S).astype(np.int32)
+    blobs = []
+    for last in (0.25, 0.0, -1.0):
+        w = np.zeros(S, np.float32)
+        w[-1] = last
+        blobs.append(np.asarray([S, S], np.int32).tobytes() + row_ptr.tobytes() + il.tobytes() +
+                     dst.tobytes() + w.tobytes())
+    r = subprocess.run([driver], input=b"".join(blobs), capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = r.stdout.decode().splitlines()
+    assert out[0].startswith("1") and out[1].startswith("0") and "total weight zero" in out[1]
+    assert out[2].startswith("0") and "negative-weight arc" in out[2]
