@@ -135,6 +135,9 @@ constexpr int kGroup = KD_GROUP;  // queued tokens a wave scores at a time
 #define KD_BIG_GROUP KD_GROUP
 #endif
 constexpr int kBigGroup = KD_BIG_GROUP;  // ... in the big tiers' filter (BigLoop)
+#ifndef KD_BIG_LANE_BATCH
+#define KD_BIG_LANE_BATCH 0
+#endif
 // Tier 1 (frames whose frontier is at most one token per lane -- 97% of the frames
 // of an HLG decode): the lower half of the table arrays is a 4096-slot table, the
 // upper half holds the first kQL entries of the candidate queue, and the frontier
@@ -1177,6 +1180,12 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
       pf_st2 = static_cast<uint32_t>(ToG(p.tok_state)[i2]);
       pf_cst2 = ToG(p.tok_cost)[i2];
     }
+    // (SimpleDecoder's emitting arcs are scored in two passes: FilterArc, not the batch)
+    constexpr bool kBatchLane = KD_BIG_LANE_BATCH != 0 && (EPS || M != 2);
+    [[maybe_unused]] bool lane_on = false;
+    [[maybe_unused]] int lane_abeg = 0, lane_deg = 0;
+    [[maybe_unused]] double lane_cst = 0.0;
+    [[maybe_unused]] uint32_t lane_src = 0;
     if (i < n_items) {
       uint32_t st, srcid;
       double cst;
@@ -1214,6 +1223,12 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
           s.it_deg[q] = deg;
           s.it_cost[q] = cst;
           s.it_src[q] = srcid;
+        } else if (kBatchLane) {
+          lane_on = true;
+          lane_abeg = abeg;
+          lane_deg = deg;
+          lane_cst = cst;
+          lane_src = srcid;
         } else {
           // all of this token's arcs in flight before the first is scored
           ArcRec ar[kSmallDeg];
@@ -1224,6 +1239,26 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
           for (int a = 0; a < kSmallDeg; ++a)
             if (a < deg) FilterArc<EPS>(c, ar[a], static_cast<uint32_t>(abeg + a), cst, srcid);
         }
+      }
+    }
+    if constexpr (kBatchLane) {
+      // Tokens of at most kSmallDeg arcs (nine states in ten of an HLG): their arcs are scored
+      // where the wave is converged, as one batch -- log-likelihood reads grouped, ONE queue
+      // allocation for the wave instead of one wave-aggregated allocation per kept arc.
+      if (__ballot(lane_on)) {
+        ArcRec ar[kSmallDeg];
+        uint32_t aidx[kSmallDeg], sr[kSmallDeg];
+        bool on[kSmallDeg];
+        double cs[kSmallDeg];
+#pragma unroll
+        for (int a = 0; a < kSmallDeg; ++a) {
+          on[a] = lane_on && a < lane_deg;
+          aidx[a] = static_cast<uint32_t>(lane_abeg + a);
+          ar[a] = LoadArcRecIf(p.arcs, aidx[a], on[a], 0u);
+          cs[a] = lane_cst;
+          sr[a] = lane_src;
+        }
+        ScoreBatchBig<EPS>(c, ar, aidx, on, cs, sr);
       }
     }
     if constexpr (!EPS) PublishMin(c);

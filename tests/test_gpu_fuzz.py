@@ -52,3 +52,23 @@ def test_randomised_parity_under_timing_perturbation(seed):
                        capture_output=True, text=True, timeout=600,
                        env={**os.environ, "KD_HIP_LIB": "libkd_hip_jitter.so"})
     assert r.returncode == 0 and "fuzz ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_exports_are_byte_identical_under_timing_perturbation():
+    """What a batch exports -- lattice arrays in their exported ORDER (finalized, at two prune
+    intervals, and un-finalized from a stepwise decode), FinalRelativeCost, 1-best paths -- is
+    the same bytes from the shipped library and from the timing-perturbation build, in which
+    every wave passes every barrier at another time than in the shipped one and than in its own
+    previous run: results, order included, do not depend on wave scheduling."""
+    digests = []
+    for lib in ("libkd_hip.so", "libkd_hip_jitter_full.so" if os.path.exists(os.path.join(
+            ROOT, "kaldi-decoder_amd", "python", "kaldi_decoder", "lib", "libkd_hip_jitter_full.so"))
+            else "libkd_hip_jitter.so", "libkd_hip_jitter.so"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "export_digest.py")],
+                           capture_output=True, text=True, timeout=300, env={**os.environ, "KD_HIP_LIB": lib})
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("digest")]
+        assert line, r.stdout
+        digests.append(line[0])
+    assert digests[0] == digests[1] == digests[2], digests
+    assert int(digests[0].split()[-1]) > 1000

@@ -16,8 +16,8 @@ if [ -f kaldi-decoder_amd/python/kaldi_decoder/lib/libkd_hip_tiny.so ]; then
   KD_HIP_LIB=libkd_hip_tiny.so KD_FUZZ_HEAVY=0.2 timeout 300 python tools/fuzz_gpu.py 150 3204 2>&1 | tail -1
 fi
 for i in 1 2 3; do
-  timeout 900 python bench.py --no-cpu --headline-only --workload hlg-large --min-seconds 1.0 > gpurun_out/r3_large_$i.json 2> /tmp/b.err
-  echo "hlg-large run $i rc=$? $(python -c "import json;d=json.load(open('gpurun_out/r3_large_$i.json'));print('%.2fM kernel %.1f ms alone %.1f frac %.3f'%(d['value']/1e6, d['roofline']['kernel_ms'], d['roofline']['launch_alone']['kernel_ms'], d['roofline']['launch_alone']['frac']))" 2>/dev/null)"
+  timeout 900 python bench.py --no-cpu --headline-only --workload hlg-large --min-seconds 1.0 > gpurun_out/${R}_large_$i.json 2> /tmp/b.err
+  echo "hlg-large run $i rc=$? $(python -c "import json;d=json.load(open('gpurun_out/${R}_large_$i.json'));print('%.2fM kernel %.1f ms alone %.1f frac %.3f'%(d['value']/1e6, d['roofline']['kernel_ms'], d['roofline']['launch_alone']['kernel_ms'], d['roofline']['launch_alone']['frac']))" 2>/dev/null)"
 done
 bash tools/profile_round.sh $R 2>&1 | tail -3
 python - "$R" <<'PY'
