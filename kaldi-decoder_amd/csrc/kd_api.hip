@@ -586,7 +586,10 @@ int ReadBack(kd_batch *b) {
     auto pull_back = [&](uint64_t *raw, uint64_t base, uint64_t cap, size_t word) -> int {
       if (*raw - base <= cap) return KD_OK;
       const unsigned long long v = base + cap;
-      KD_HIP_TRY(hipMemcpy(reinterpret_cast<char *>(b->bctl.p) + word, &v, sizeof(v), hipMemcpyHostToDevice));
+      // (on the batch's own stream, which is idle here: the launch that overshot has been waited for)
+      KD_HIP_TRY(hipMemcpyAsync(reinterpret_cast<char *>(b->bctl.p) + word, &v, sizeof(v), hipMemcpyHostToDevice,
+                                b->stream));
+      KD_HIP_TRY(hipStreamSynchronize(b->stream));
       *raw = v;
       return KD_OK;
     };

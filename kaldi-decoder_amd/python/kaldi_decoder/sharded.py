@@ -248,6 +248,8 @@ class ResultGatherer:
         self.t.start()
 
     def _run(self):
+        import time
+
         import torch
         stream = None
         try:
@@ -256,7 +258,6 @@ class ResultGatherer:
                 if item is None:
                     return
                 seq, payload, ready = item
-                import time
                 t0 = time.perf_counter()
                 if payload.is_cuda:
                     if stream is None:
