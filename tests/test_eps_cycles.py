@@ -210,3 +210,32 @@ def test_gpu_lattice_is_the_links_within_lattice_beam_of_the_best_path():
                 for lat, lp in zip(lb.raw_lattices(), lps):
                     n_margin = lattice_ref.check_lattice(lat, g, lp, lbeam, 1e-4 * (T + 1))
                     assert n_margin <= max(2, len(lat.src) // 50), (name, n_margin)
+
+
+@pytest.mark.gpu
+def test_gpu_fused_log_softmax_lattice_is_the_lattice_of_the_normalised_rows():
+    """kd_batch_set_log_softmax: the batch is handed LOGITS.  The test next to the other
+    log-softmax tests can only compare with a decode of torch.log_softmax to rounding (the sums
+    are taken in another order), so it accepts 98 % arc overlap; here the fused path's lattice is
+    pinned by the independent definition instead: with a search beam that prunes nothing it must
+    be exactly the links within lattice_beam of the best path under the float64 log-softmax of the
+    same logits (margin for float32 against float64, as in the other lattice_ref tests)."""
+    import torch
+    import test_lattice_ref as tl
+    rng = np.random.default_rng(11)
+    for name, g, lex, V, T, lbeams in tl.CASES[:1] + tl.CASES[3:6]:
+        G = cabi.Graph(g)
+        lps = [synth.make_logprobs(T, V, 300 + utt, peak=2.0, lexicon=lex) for utt in range(3)]
+        shift = rng.normal(0, 4, (3, T, 1)).astype(np.float32)
+        logits = np.stack(lps) + shift  # (softmax is shift-invariant: same posteriors, other logits)
+        x = logits.astype(np.float64)
+        m = x.max(axis=-1, keepdims=True)
+        logp64 = x - (m + np.log(np.exp(x - m).sum(axis=-1, keepdims=True)))
+        dev = torch.from_numpy(logits).cuda()
+        for lbeam in lbeams[:1]:
+            lb = cabi.LatticeBatch(G, max_batch=3, beam=tl.WIDE, lattice_beam=lbeam, min_active=0)
+            lb.set_log_softmax(True)
+            lb.decode_tensor(dev)
+            for i, lat in enumerate(lb.raw_lattices()):
+                n_margin = lattice_ref.check_lattice(lat, g, logp64[i], lbeam, 2e-4 * (T + 1))
+                assert n_margin <= max(3, len(lat.src) // 30), (name, n_margin)
