@@ -364,3 +364,25 @@ def test_best_path_longer_than_the_staging_queue_grows_the_queue(oracle):
     with pytest.raises(RuntimeError, match="best path longer than the staging queue"):
         fixed.decode_host([lp])
         fixed.best_paths()
+
+
+def test_largest_ilabel_the_arc_record_holds():
+    """ilabel 2^20 - 1 (all twenty bits of the arc record's label field) next to ilabel 1, over a
+    log-likelihood row of 2^20 - 1 columns (read in place: rows this wide are not staged in
+    LDS): the label comes back whole, the right column was read."""
+    big = (1 << 20) - 1
+    arcs = [(0, 1, big, 5, 0.5), (0, 1, 1, 6, 0.25), (1, 1, big, 0, 0.0)]
+    g = synth.graph_from_arcs(2, 0, arcs, {1: 0.0})
+    G = cabi.Graph(g)
+    lp = np.full((2, big), -8.0, np.float32)
+    lp[0, big - 1] = -1.0   # frame 0: the big label is cheap (0.5 + 1 against 0.25 + 8)
+    lp[1, big - 1] = -2.0
+    bt = cabi.Batch(G, max_batch=1, beam=16.0, min_active=0)
+    bt.decode_host([lp])
+    p = bt.best_paths()[0]
+    assert p.ok and p.ilabel.tolist() == [big, big] and p.olabel.tolist() == [5, 0]
+    assert p.ac_cost.tolist() == [1.0, 2.0] and p.graph_cost.tolist() == [0.5, 0.0]
+    lb = cabi.LatticeBatch(G, max_batch=1, beam=16.0, lattice_beam=10.0, min_active=0)
+    lb.decode_host([lp])
+    lat = lb.raw_lattices()[0]
+    assert sorted(lat.ilabel.tolist()) == [1, big, big]

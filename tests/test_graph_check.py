@@ -99,3 +99,18 @@ def test_epsilon_cycle_check_on_a_long_chain_and_a_big_cycle(driver):
     out = r.stdout.decode().splitlines()
     assert out[0].startswith("1") and out[1].startswith("0") and "total weight zero" in out[1]
     assert out[2].startswith("0") and "negative-weight arc" in out[2]
+
+
+def test_ilabels_beyond_twenty_bits_are_refused():
+    """An arc record keeps 20 bits for the ilabel (the other 12 carry the destination's arc
+    degrees): kd_graph_create says so instead of truncating.  (Checked before the GPU is
+    touched: this needs none.)"""
+    from kaldi_decoder import cabi, synth
+    g = synth.graph_from_arcs(2, 0, [(0, 1, (1 << 20), 0, 0.5)], {1: 0.0})
+    with pytest.raises(RuntimeError, match="exceeds the largest supported"):
+        cabi.Graph(g)
+    g = synth.graph_from_arcs(2, 0, [(0, 1, (1 << 20) - 1, 0, 0.5)], {1: 0.0})
+    try:
+        cabi.Graph(g)
+    except RuntimeError as e:  # (without a GPU the upload fails -- not the label check)
+        assert "largest supported" not in str(e) and cabi.device_count() == 0, e
