@@ -695,3 +695,59 @@ def test_decode_from_host_matrices_in_one_launch(oracle):
         d.decode(lps[i])
         p = d.get_best_path()
         assert paths[i].ilabel.tolist() == p.ilabel.tolist() and paths[i].ac_cost.tolist() == p.ac_cost.tolist()
+
+
+def test_two_host_threads_decode_on_batches_of_their_own_over_one_graph(oracle):
+    """The reference's contract (threading): a decoder instance is not re-entrant,
+    distinct instances may share one FST read-only.  Here: one kd_graph, two host threads, each
+    with batch objects and streams of its own (ctypes releases the GIL around the C calls, so
+    the two threads are in the library at the same time: enqueueing, growing pools that start
+    too small, reading results), a dozen calls each; an error raised in one thread must not
+    show up in the other (kd_last_error is thread-local)."""
+    import threading
+    import torch
+    g = synth.hlg_graph(V=60, n_words=400, n_hist=400, avg_succ=10, seed=7)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T, V = 8, 60, 60
+    opts = dict(beam=11.0, lattice_beam=6.0, min_active=0)
+    sets = [[synth.make_logprobs(T, V, 900 + 50 * k + i, peak=4.0, lexicon=g["lexicon"]) for i in range(B)]
+            for k in range(2)]
+    want = []
+    for lps in sets:
+        w = []
+        for lp in lps:
+            can = oracle.CanonLatticeDecoder(OG, beam=11.0, lattice_beam=6.0)
+            can.decode(lp)
+            w.append(can.get_raw_lattice())
+        want.append(w)
+    errors, bad = [], []
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream()
+            dev = torch.from_numpy(np.stack(sets[k])).cuda()
+            lb = cabi.LatticeBatch(G, max_batch=B, stream=st.cuda_stream, arena_tokens=2048, arena_links=2048,
+                                   **opts)
+            for it in range(12):
+                if it % 4 == 3:  # an error of this thread's own, in between
+                    try:
+                        lb.decode_device([dev[i].data_ptr() for i in range(B)], [T] * B, 3)
+                        bad.append((k, it, "no error for a matrix of 3 columns"))
+                    except RuntimeError as e:
+                        if "columns" not in str(e):
+                            bad.append((k, it, str(e)))
+                    continue
+                lb.decode_tensor(dev)
+                lats = lb.raw_lattices()
+                for i in range(B):
+                    if lats[i].arc_set() != want[k][i].arc_set() or lats[i].state_set() != want[k][i].state_set():
+                        bad.append((k, it, i))
+        except BaseException as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+    assert not errors and not bad, (errors, bad[:5])
