@@ -151,6 +151,12 @@ constexpr int kT1Front = KD_T1_FRONT;
 constexpr int kT1Narrow = 0;  // ... of which frames up to this size run on four waves (0: never;
                                // measured slower on MI355X: fewer loads in flight per round trip)
 constexpr int kQL = kT1Slots / 2;
+#ifndef KD_T1_SOFTQ
+#define KD_T1_SOFTQ (3 * (1 << (KD_LOG2_SLOTS - 2)))  // three times the LDS part of the queue (kQL)
+#endif
+constexpr int kT1SoftQueue = KD_T1_SOFTQ;         // (0: off) see RunUtterance
+constexpr int kT1SoftFront = KD_T1_FRONT * 3 / 4;
+static_assert(KD_T1_SOFTQ == 0 || KD_T1_SOFTQ >= 2 * kQL, "the soft limit is a multiple of the LDS queue part");
 constexpr int kT1W16 = 512;    // tokens of at most 16 arcs (in Shared::hist)
 constexpr int kSecondPart = 0x8000;  // 16-lane list entry: arcs 32..47 of a token of 33..48 arcs
 static_assert(KD_T1_FRONT <= kSecondPart, "work-list entries are frontier indices below the flag");
@@ -2921,6 +2927,7 @@ __device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long 
     if (c.simple) c.cutoff = 0.0 + static_cast<double>(p.beam);
   }
   c.replay = filtered;
+  if (kT1SoftQueue > 0 && tid == 0) s.ctl[0].pad = q_emit;  // (read back by RunUtterance behind this call's barriers)
   // the queue is a complete journal of the frame's inserts: a frame that does
   // not fit the LDS table is replayed from it into the global table
   if (q_emit > c.q_cap) return KD_UTT_TABLE_FULL;
@@ -3083,6 +3090,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   Counters tot;  // per-lane work counters of the small frames, folded when the launch ends
   int visited = do_init ? -1 : Uni(ToG(p.mem)[utt].visited);
 
+  [[maybe_unused]] int prev_q_emit = 0;  // candidates the previous frame's emitting filter queued
   while (err == 0 && frame < target) {
     if constexpr (M == 1) {
       // PruneActiveTokens every prune_interval frames, BEFORE the frame is processed like
@@ -3127,6 +3135,12 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     Counters cnt;
     bool small = false;
     if constexpr (!c.simple) small = frame >= 0 && c.n_in <= kT1Front;
+    // A frontier in the upper quarter of the tier's range that follows a frame which queued
+    // several times what the LDS part of the candidate queue holds goes to the big tiers at once
+    // (a deterministic rule: sizes of the decode, not timings): its queue will be in global
+    // memory mostly, its states will overflow the 4096-slot table, and handing a frame over
+    // AFTER its filter costs more than either tier.
+    if constexpr (kT1SoftQueue > 0) small = small && !(c.n_in > kT1SoftFront && prev_q_emit > kT1SoftQueue);
     uint32_t r = kRetry;
     int q_emit = 0;
     bool filtered = false;  // the emitting filter already ran (tier 1 did not fit)
@@ -3173,6 +3187,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       if (r == 0) {
         c.base_in = Uni(s.ctl[frame & 1].base_out);
         c.n_in = Uni(s.ctl[frame & 1].n_in);
+        if constexpr (kT1SoftQueue > 0) prev_q_emit = Uni(s.ctl[frame & 1].q_emit);
         front_lds = c.n_in <= kT1Front;
         tot.tokens_expanded += cnt.tokens_expanded;
         tot.eps_exp += cnt.eps_exp;
@@ -3226,6 +3241,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       if (r == 0) {
         c.base_in = Uni(s.base_out);
         c.n_in = Uni(c.simple ? s.n_act : s.n_live);
+        if constexpr (kT1SoftQueue > 0) prev_q_emit = Uni(s.ctl[0].pad);  // (BigFrame leaves it there)
       }
       // the next frame's start state; every wave's token stores have landed before a
       // small team reads them
