@@ -881,8 +881,9 @@ __device__ __forceinline__ bool ScoreArc(const FrameCtx<M> &c, const ArcRec &a, 
 // 64-bit ds_min orders them by cost as before, and the slot ends up holding the word), its
 // degrees in bits 16..27 of the source word (a tier-1 source is a frontier index or a slot:
 // 13 bits and the epsilon flag).  The token a candidate creates thus knows its arcs: neither
-// the epsilon rounds nor the next frame's frontier fetch a state record (two dependent round
-// trips of a frame that consists of little else).
+// the epsilon rounds nor the next frame's frontier fetch a state record.  (Measured + 0.5 % on
+// the bench: the fetch was L2-resident and cheap -- DESIGN section 5 -- but it is work removed,
+// and a new token's arcs are known the moment it is created.)
 constexpr uint32_t kT1SrcMask = kSrcEps | 0xFFFFu;
 constexpr int kT1SrcDegShift = 16;
 static_assert(kT1Slots <= 0x10000 && kT1Front <= 0x10000, "a tier-1 source fits 16 bits");
