@@ -37,7 +37,10 @@ WORKLOADS = {
                         opts=dict(beam=15.0, lattice_beam=8.0, min_active=0, prune_interval=25),
                         batch=128, frames=250, V=500,
                         desc="LatticeFasterDecoder over synthetic LibriSpeech-like HLG (bigram G, "
-                             "20k words, V=500), beam=15, lattice_beam=8, B=128/GPU, T=250"),
+                             "20k words, V=500), beam=15, lattice_beam=8, B=128/GPU, T=250; headline at "
+                             "LatticeSimpleDecoderConfig's cutoff (min_active=0, max_active=INT_MAX: the one "
+                             "lattice decoder the reference implements), LatticeFasterDecoderConfig's own "
+                             "defaults (min_active=200) and max_active=10000 as side figures"),
     # BASELINE configs[4] on one GPU: the same generator at 200 k words -- 52.8 M states,
     # 141 M arcs = 2.26 GB of 16-byte arc records (stresses HBM: the graph is nine times the
     # Infinity Cache), beam 17
@@ -45,7 +48,8 @@ WORKLOADS = {
                       lattice=True, opts=dict(beam=17.0, lattice_beam=8.0, min_active=0, prune_interval=25),
                       batch=128, frames=250, V=500,
                       desc="LatticeFasterDecoder over synthetic large-LM HLG (bigram G, 200k words, "
-                           "141M arcs = 2.26 GB, V=500), beam=17, lattice_beam=8, B=128/GPU, T=250"),
+                           "141M arcs = 2.26 GB, V=500), beam=17, lattice_beam=8, B=128/GPU, T=250 "
+                           "(min_active=0, max_active=INT_MAX)"),
     "hlg-1best": dict(kind="hlg", graph=HLG, lattice=False, opts=dict(beam=15.0),
                       batch=128, frames=250, V=500,
                       desc="FasterDecoder 1-best over synthetic LibriSpeech-like HLG "
@@ -282,6 +286,9 @@ def main():
                     help="skip the side measurements whose launches are of another shape than the "
                          "headline's (prune_interval off, host input): what tools/profile_round.sh "
                          "runs under rocprofv3, so that the trace's average launch is the headline's")
+    ap.add_argument("--no-large-lm", action="store_true",
+                    help="skip the large-LM workload (BASELINE configs[4] on one GPU) that the default "
+                         "invocation runs as a child process after the headline and embeds as `large_lm`")
     ap.add_argument("--steps-per-call", type=int, default=8,
                     help="steps (batches of B utterances) handed to the library in one "
                          "kd_batch_decode call: one kernel launch whose persistent workgroups take "
@@ -546,25 +553,51 @@ def main():
     # utterance length (no periodic sweeps, no collector; the lattices are the same either
     # way -- the knob trades time for memory, and a 10 s utterance needs 5 MB) is reported
     # next to the headline as `value_prune_interval_off`.
-    value_pi_off = None
-    if wl["lattice"] and not args.search_only and not args.prune_interval and not args.headline_only:
+    def side_value(extra, label):
+        """The headline's pipeline with other decoder options (batch objects of its own, the
+        same streams, utterances and lent buffers): audio frames/s, and the counters of one call."""
+        nonlocal bts
         keep = bts
-        bts = [cls(Gr, max_batch=per_slot, max_frames=T, stream=st.cuda_stream,
-                   **{**wl["opts"], "prune_interval": 1 << 20}) for st in streams]
-        if out_bufs is not None:
-            for bt_, buf_ in zip(bts, out_bufs):
-                bt_.set_output_buffer(buf_)
-        run_steps(2 * n_fly * G)
-        fence()
-        # (as long a timed region as the headline's: the pipeline's fill and drain -- one call's
-        # duration with fewer than n_fly calls in flight -- must not weigh more here than there)
-        n_off = max(args.steps, int(steps_timed * 0.6) // (n_fly * G) * (n_fly * G), n_fly * G)
-        t_off = time.perf_counter()
-        run_steps(n_off)
-        fence()
-        value_pi_off = world * B * T * n_off * SUBSAMPLING / (time.perf_counter() - t_off)
-        del bts
-        bts = keep
+        try:
+            bts = [cls(Gr, max_batch=per_slot, max_frames=T, stream=st.cuda_stream,
+                       **{**wl["opts"], **extra}) for st in streams]
+            if out_bufs is not None:
+                for bt_, buf_ in zip(bts, out_bufs):
+                    bt_.set_output_buffer(buf_)
+            run_steps(2 * n_fly * G)
+            fence()
+            # (as long a timed region as the headline's: the pipeline's fill and drain -- one call's
+            # duration with fewer than n_fly calls in flight -- must not weigh more here than there)
+            n_side = max(args.steps, int(steps_timed * 0.6) // (n_fly * G) * (n_fly * G), n_fly * G)
+            t_side = time.perf_counter()
+            run_steps(n_side)
+            fence()
+            v = world * B * T * n_side * SUBSAMPLING / (time.perf_counter() - t_side)
+            st_ = bts[0].stats()
+            sm = st_.sum(axis=0)
+            return dict(value=v, unit="audio_frames/s", options=label,
+                        tokens_in_per_frame=float(sm[1]) / max(float(sm[0]), 1.0),
+                        tokens_expanded_per_frame=float(sm[2]) / max(float(sm[0]), 1.0),
+                        max_tokens=int(st_[:, 8].max()))
+        finally:
+            bts = keep
+
+    # The workloads run at the reference's default prune_interval (25): PruneActiveTokens
+    # every 25 frames plus the collector that keeps an utterance's footprint at its pruned
+    # lattice and a window of recent frames.  The same pipeline with the interval above the
+    # utterance length (no periodic sweeps, no collector; the lattices are the same either
+    # way -- the knob trades time for memory, and a 10 s utterance needs 5 MB) is reported
+    # next to the headline as `value_prune_interval_off`.
+    value_pi_off = side_min200 = side_max10k = None
+    if wl["lattice"] and not args.search_only and not args.prune_interval and not args.headline_only:
+        value_pi_off = side_value({"prune_interval": 1 << 20}, "prune_interval off")["value"]
+        # ... and at the options of the decoder the workload is named after: the reference
+        # DECLARES LatticeFasterDecoder (config only: lattice-faster-decoder.h:48-55 defaults
+        # min_active = 200, max_active = INT_MAX) and implements LatticeSimpleDecoder, whose
+        # cutoff (no min / max_active) is the headline's; SURVEY 8(d) config 3 also asks for
+        # max_active = 10000
+        side_min200 = side_value({"min_active": 200}, "LatticeFasterDecoderConfig defaults: min_active=200, max_active=INT_MAX")
+        side_max10k = side_value({"min_active": 200, "max_active": 10000}, "min_active=200, max_active=10000")
     # a full call alone on the GPU (no other launch sharing the CUs): what the launch's
     # own duration is when nothing stretches it
     alone_ms = []
@@ -632,6 +665,34 @@ def main():
     gather_ms = gatherer.mean_ms()
     verified = verify_gather() if args.verify_gather else None
 
+    # BASELINE configs[4] on this GPU, in front of the driver too: the one workload whose graph
+    # (2.26 GB of arc records) does not fit the Infinity Cache.  A CHILD process of its own
+    # (another graph, other pools), started when this process's GPU work is done.
+    large_lm = None
+    if (rank == 0 and world == 1 and args.workload == "hlg-lattice" and not args.search_only
+            and not args.headline_only and not args.no_large_lm and not args.batch):
+        import subprocess
+        t_l = time.time()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "hlg-large",
+                                "--no-cpu", "--headline-only", "--min-seconds", "5", "--steps", str(n_fly * G)],
+                               capture_output=True, text=True, timeout=1500)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            large_lm = dict(value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"],
+                            frac=d["roofline"]["frac"], kernel_ms=d["roofline"]["kernel_ms"],
+                            launch_alone_frac=d["roofline"]["launch_alone"]["frac"],
+                            traffic=d["roofline"]["traffic"], traffic_source=d["roofline"]["traffic_source"],
+                            algorithmic_bytes_per_launch=d["roofline"]["algorithmic_bytes_per_launch"],
+                            workload=d["config"]["workload"], graph_arcs=d["config"]["graph_arcs"],
+                            arcs_scanned_per_frame=d["config"]["arcs_scanned_per_frame"],
+                            links_per_frame=d["config"]["links_per_frame"],
+                            steps_timed=d["steps_timed"], setup_s=d["setup_s"], wall_s=time.time() - t_l)
+            for k in ("arcs_read_per_frame", "index_probes_per_frame"):
+                if k in d["config"]:
+                    large_lm[k] = d["config"][k]
+        except Exception as e:  # (reported, not fatal: the headline stands on its own)
+            large_lm = dict(error=repr(e)[:300])
+
     if rank == 0 and args.search_only:
         print(json.dumps({"diagnostic": "search only", "ms_per_step": elapsed / steps_timed * 1e3,
                           "launch_ms": float(np.mean([k for k, n in launches if n == G] or [0])),
@@ -664,6 +725,10 @@ def main():
             "ms_per_step": elapsed / steps_timed * 1e3,
             "timed_seconds": elapsed,
             "value_prune_interval_off": value_pi_off,
+            "value_min_active_200": side_min200["value"] if side_min200 else None,
+            "value_max_active_10000": side_max10k["value"] if side_max10k else None,
+            "side_runs": [x for x in (side_min200, side_max10k) if x],
+            "large_lm": large_lm,
             "host_input": host_input,
             "single_batch_ms": single_batch_ms,
             "single_batch_value": B * T * SUBSAMPLING / (single_batch_ms * 1e-3),

@@ -26,10 +26,13 @@ from kaldi_decoder import synth  # noqa: E402
 from kaldi_decoder.scoring import ctc_collapse, edit_distance  # noqa: E402
 
 
-def main(kind=None, n_utts=None, graph_path=None):
+def main(kind=None, n_utts=None, graph_path=None, results=None):
     """Returns (WER, utterances on which the lattice decoder's best path equals the 1-best
     decoder's).  With `graph_path` the graph goes through an OpenFst binary file, as a real
-    setup's HLG.fst does."""
+    setup's HLG.fst does.  `results` (a list) receives, per utterance, what the 1-best decoder
+    returned: (log_probs, isyms, osyms, (graph cost, acoustic cost), reached_final) -- and its
+    first entry is the graph dictionary the file was written from (tests compare with the
+    oracle's decode of THAT graph)."""
     kind = kind or (sys.argv[1] if len(sys.argv) > 1 else "HLG")
     n_utts = n_utts or (int(sys.argv[2]) if len(sys.argv) > 2 else 8)
     V, T = 60, 120
@@ -41,6 +44,8 @@ def main(kind=None, n_utts=None, graph_path=None):
     else:
         g = synth.hlg_graph(V=V, n_words=500, n_hist=500, avg_succ=10, seed=2)
         lex = g["lexicon"]
+    if results is not None:
+        results.append(g)
     fst = kd.fst_from_dict(g)
     if graph_path:  # a real setup: kd.Fst.read("HLG.fst")
         fst.write(graph_path)
@@ -57,6 +62,9 @@ def main(kind=None, n_utts=None, graph_path=None):
         ok, best_path = decoder.get_best_path()
         ok2, isyms, osyms, total = kd.get_linear_symbol_sequence(best_path)
         hyp = ctc_collapse(isyms) if kind == "H" else list(osyms)
+        if results is not None:
+            results.append((log_probs, list(isyms), list(osyms), (float(total[0]), float(total[1])),
+                            decoder.reached_final()))
         lat_decoder.decode(kd.DecodableCtc(log_probs))
         ok3, lat_best = lat_decoder.get_best_path()
         _, li, lo, _ = kd.get_linear_symbol_sequence(lat_best)

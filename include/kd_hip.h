@@ -216,7 +216,8 @@ enum {
   KD_STAT_FRAMES = 0,
   KD_STAT_TOKENS_IN,        /* tokens entering ProcessEmitting                 */
   KD_STAT_TOKENS_EXPANDED,  /* of those, cost < weight_cutoff                  */
-  KD_STAT_ARCS_SCANNED,     /* emitting arcs read                              */
+  KD_STAT_ARCS_SCANNED,     /* emitting arcs of expanded tokens (the arcs the reference's loop visits,
+                               faster-decoder.cc:204-211; equal to the oracle's count)        */
   KD_STAT_ARCS_KEPT,        /* of those, below the running cutoff              */
   KD_STAT_TOKENS_OUT,       /* tokens written (after closure)                  */
   KD_STAT_EPS_ARCS_SCANNED, /* epsilon arcs read in ProcessNonemitting         */
@@ -225,6 +226,10 @@ enum {
   KD_STAT_SPILL_FRAMES,     /* frames that fell back to the global table       */
   KD_STAT_LINKS,            /* forward links written (lattice decoders)        */
   KD_STAT_SMALL_FRAMES,     /* frames run entirely out of LDS (frontier <= 1024) */
+  KD_STAT_ARCS_SKIPPED,     /* of ARCS_SCANNED, arcs never fetched: a lower bound of their cost was
+                               already at or beyond the running cutoff (label index, kd_search.hip);
+                               arcs READ = ARCS_SCANNED - ARCS_SKIPPED                          */
+  KD_STAT_INDEX_PROBES,     /* 4-byte label-index entries read to find the arcs that were fetched */
   KD_NUM_STATS
 };
 int kd_batch_stats(kd_batch *b, int64_t *out /* [batch][KD_NUM_STATS] */);

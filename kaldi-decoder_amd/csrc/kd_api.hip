@@ -59,6 +59,8 @@ struct kd_graph {
   DevBuf<StateRec> states;
   DevBuf<ArcPacked> arcs;
   DevBuf<int32_t> olabels;  // [arcs], in the arcs' device order (emitting first per state)
+  DevBuf<uint32_t> lab_idx; // [arcs], label index of the emitting ranges (kd_device.h)
+  float emit_w_min = 0.0f;  // lowest emitting-arc weight (NaN if a weight is NaN)
 };
 
 struct kd_batch {
@@ -164,6 +166,8 @@ struct kd_batch {
     p.states = g->states.p;
     p.arcs = g->arcs.p;
     p.arc_olabel = g->olabels.p;
+    p.lab_idx = g->lab_idx.p;
+    p.emit_w_min = g->emit_w_min;
     p.start = g->start;
     p.beam = o.beam;
     p.max_active = o.max_active;
@@ -754,9 +758,37 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
       ol[at] = olabel[a];
     }
   }
+  // Label index: per state, (ilabel, offset) of its emitting arcs sorted by ilabel -- the arcs
+  // themselves keep their order (arc indices are tie-breakers and leave the library in lattices).
+  // A token whose cost leaves room for one or two labels of the frame only looks THOSE up
+  // (kd_search.hip, IndexedArcs) instead of reading every arc: the loop of
+  // faster-decoder.cc:204-211 / lattice-simple-decoder.cc:375-399 visits arcs whose cost is known
+  // to be beyond the cutoff from a lower bound (this frame's second-lowest acoustic cost, the
+  // graph's lowest emitting weight).  States of 4096 emitting arcs or more keep no index.
+  std::vector<uint32_t> li(std::max<int64_t>(na, 1), 0xFFFFFFFFu);
+  float w_min = std::numeric_limits<float>::infinity();
+  bool w_nan = false;
+  {
+    std::vector<uint32_t> tmp;
+    for (int32_t s = 0; s < num_states; ++s) {
+      const int32_t b = st[s].arc_begin, e = st[s].emit_end;
+      for (int32_t a = b; a < e; ++a) {
+        const float w = ar[a].weight;
+        if (w != w) w_nan = true;
+        else if (w < w_min) w_min = w;
+      }
+      if (e - b >= (1 << kIdxOffBits)) continue;
+      tmp.resize(e - b);
+      for (int32_t a = b; a < e; ++a)
+        tmp[a - b] = (ar[a].lab & static_cast<uint32_t>(kMaxIlabel)) << kIdxOffBits | static_cast<uint32_t>(a - b);
+      std::sort(tmp.begin(), tmp.end());
+      std::copy(tmp.begin(), tmp.end(), li.begin() + b);
+    }
+  }
   KD_HIP_TRY(hipSetDevice(device));
   kd_graph *g = new (std::nothrow) kd_graph;
   if (!g) return Fail(KD_E_INVALID, "out of host memory");
+  g->emit_w_min = w_nan ? std::numeric_limits<float>::quiet_NaN() : w_min;
   g->device = device;
   g->num_states = num_states;
   g->start = start;
@@ -765,6 +797,8 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
   hipError_t e = g->states.Alloc(num_states);
   if (e == hipSuccess) e = g->arcs.Alloc(ar.size());
   if (e == hipSuccess) e = g->olabels.Alloc(ol.size());
+  if (e == hipSuccess) e = g->lab_idx.Alloc(li.size());
+  if (e == hipSuccess) e = hipMemcpy(g->lab_idx.p, li.data(), li.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(g->states.p, st.data(), st.size() * sizeof(StateRec), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(g->arcs.p, ar.data(), ar.size() * sizeof(ArcPacked), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(g->olabels.p, ol.data(), ol.size() * sizeof(int32_t), hipMemcpyHostToDevice);
@@ -780,7 +814,7 @@ void kd_graph_destroy(kd_graph *g) { delete g; }
 int32_t kd_graph_num_states(const kd_graph *g) { return g ? g->num_states : 0; }
 int64_t kd_graph_num_arcs(const kd_graph *g) { return g ? g->num_arcs : 0; }
 size_t kd_graph_device_bytes(const kd_graph *g) {
-  return g ? g->states.bytes() + g->arcs.bytes() + g->olabels.bytes() : 0;
+  return g ? g->states.bytes() + g->arcs.bytes() + g->olabels.bytes() + g->lab_idx.bytes() : 0;
 }
 
 void kd_faster_options_default(kd_faster_options *o) {

@@ -100,21 +100,11 @@ __device__ __forceinline__ float FInf() { return __int_as_float(0x7F800000); }
 // Exclusive prefix sum of one int per thread over the workgroup; `total` = the sum.
 __device__ __forceinline__ int BlockExclScanI(TailShared &s, int v, int &total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int y = __shfl_up(x, d, 64);
-    if (lane >= d) x += y;
-  }
+  const int x = WaveInclusiveSumInt(v);
   if (lane == 63) s.red_i[wave] = x;
   __syncthreads();
   if (wave == 0) {
-    int w = lane < kWaves ? s.red_i[lane] : 0, xs = w;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-      int y = __shfl_up(xs, d, 64);
-      if (lane >= d) xs += y;
-    }
+    const int w = lane < kWaves ? s.red_i[lane] : 0, xs = WaveInclusiveSumInt(w);
     if (lane < kWaves) s.red_i[lane] = xs - w;
     if (lane == kWaves - 1) s.count = xs;
   }
@@ -291,12 +281,7 @@ __device__ __forceinline__ int SweepWindow(CParams &p, TailShared &s, const Stag
     const long long base = ToG(p.frame_base)[at], eb = ToG(p.link_emit_base)[at], pb = ToG(p.link_eps_base)[at];
     int n = ToG(p.frame_count)[at], en = ToG(p.link_emit_count)[at], pn = ToG(p.link_eps_count)[at];
     if (!in) { n = 0; en = 0; pn = 0; }
-    int ct = n, cl = en + pn;
-#pragma unroll
-    for (int d = 1; d < kWinMax; d <<= 1) {
-      const int yt = __shfl_up(ct, d, 64), yl = __shfl_up(cl, d, 64);
-      if (lane >= d) { ct += yt; cl += yl; }
-    }
+    const int ct = WaveInclusiveSumInt(n), cl = WaveInclusiveSumInt(en + pn);
     const unsigned long long m = __ballot(in && ct <= kWinToks && cl <= kWinLinks);
     const int W = m == ~0ull ? 64 : __builtin_ctzll(~m);
     if (lane < kWinMax) {

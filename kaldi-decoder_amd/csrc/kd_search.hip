@@ -119,8 +119,9 @@ constexpr int kLog2Slots = KD_LOG2_SLOTS;
 constexpr int kSlots = 1 << kLog2Slots;
 constexpr int kLdsFillLimit = kSlots * 3 / 4;
 constexpr int kVmax = KD_VMAX;  // log-likelihood row staged in LDS when V <= kVmax
-// the waves a four-wave team leaves idle fetch the next frame's row meanwhile
-constexpr int kLlLanes = KD_BLOCK - 256, kLlRegs = (kVmax + kLlLanes - 1) / kLlLanes;
+// the waves a one-wave team leaves idle fetch the next frame's row meanwhile
+constexpr int kNarrowLanes = 64;
+constexpr int kLlLanes = KD_BLOCK - kNarrowLanes, kLlRegs = (kVmax + kLlLanes - 1) / kLlLanes;
 // ... a whole-workgroup team carries it in registers through the emitting filter
 constexpr int kPfRegs = (kVmax + KD_BLOCK - 1) / KD_BLOCK;
 #ifndef KD_SMALL_DEG
@@ -129,6 +130,16 @@ constexpr int kPfRegs = (kVmax + KD_BLOCK - 1) / KD_BLOCK;
 #ifndef KD_GROUP
 #define KD_GROUP 4
 #endif
+// Label index (IndexedArcs): on (1) / off (0), and the smallest frontier of an LDS-resident frame
+// that uses it -- below that a frame's few high-degree tokens are a handful of wave rows whose
+// arcs arrive in ONE round trip, against the index's chain of dependent probes.
+#ifndef KD_LABEL_INDEX
+#define KD_LABEL_INDEX 1
+#endif
+#ifndef KD_IDX_MIN_FRONT
+#define KD_IDX_MIN_FRONT 192
+#endif
+constexpr int kIdxMinFront = KD_IDX_MIN_FRONT;
 constexpr int kSmallDeg = KD_SMALL_DEG;  // tokens with at most this many arcs stay on their lane
 constexpr int kGroup = KD_GROUP;  // queued tokens a wave scores at a time
 #ifndef KD_BIG_GROUP
@@ -148,8 +159,21 @@ constexpr int kBigGroup = KD_BIG_GROUP;  // ... in the big tiers' filter (BigLoo
 constexpr int kT1Log2 = kLog2Slots - 1;
 constexpr int kT1Slots = 1 << kT1Log2;
 constexpr int kT1Front = KD_T1_FRONT;
-constexpr int kT1Narrow = 0;  // ... of which frames up to this size run on four waves (0: never;
-                               // measured slower on MI355X: fewer loads in flight per round trip)
+// ... of which frames up to this size are run by ONE wave (0: never -- the shipped setting).
+// A frame of a handful of tokens is a chain of two dozen phases, each a few dependent LDS or
+// memory round trips and a workgroup barrier: 23-25 k cycles whether it holds 3 tokens or 100
+// (tools/prof_sizes.py).  One wave needs no barrier at all (its LDS operations execute in
+// order: Team::Sync is a wait for its own counters) -- and is SLOWER: round 5, A/B on one box,
+// frames of up to 4 / 8 / 16 / 64 tokens on one wave: 36.7 / 35.6 / 35.5 / 35.0 M audio frames/s
+// against 38.4 M.  What the twelve waves buy a small frame is not lanes but independent
+// instruction streams: the best token's row, the other tokens' arcs, the three work-item lists
+// and the table clears are requested by different waves at once, and one wave walks them one
+// memory round trip after the other.  (Until round 3 a team of FOUR waves synchronised through
+// an LDS counter: slower too.)  The knob stays for the measurement.
+#ifndef KD_T1_NARROW
+#define KD_T1_NARROW 0
+#endif
+constexpr int kT1Narrow = KD_T1_NARROW;
 constexpr int kQL = kT1Slots / 2;
 #ifndef KD_T1_SOFTQ
 #define KD_T1_SOFTQ (3 * (1 << (KD_LOG2_SLOTS - 2)))  // three times the LDS part of the queue (kQL)
@@ -229,6 +253,12 @@ struct Shared {
   long long link_end;
   unsigned long long ud_ll;     // the utterance's UttCtl::ll and ::offset (read once from
   int32_t ud_offset, ud_pad;    // pinned host memory when the utterance is taken up)
+  // The row in `ll`: each wave's share of its two highest log-likelihoods (top_a0 >= top_a1)
+  // and the column of the highest -- written by whoever stages the row, combined by every
+  // wave that needs them (LoadRowTop): the label index asks "can any label but the likeliest
+  // still pass this token's cutoff?"
+  float top_a0[kWaves], top_a1[kWaves];
+  int32_t top_i0[kWaves];
   int32_t soft_bar;             // team barrier arrivals since the launch began
   int32_t alloc_ok;             // result of the last chunk allocation (0 ok, else a KD_UTT_* bit)
   // what a tier-1 frame leaves for the waves that sat it out, by frame parity:
@@ -352,6 +382,8 @@ __device__ __forceinline__ ArcRec LoadArcRecIf(const ArcPacked *base, uint32_t i
 // Per-frame, per-lane work counters, folded into LDS at the end of the frame.
 struct Counters {
   int tokens_expanded = 0, eps_exp = 0, arcs_scanned = 0, eps_arcs = 0;
+  // label index: arcs of expanded tokens that were never fetched, index entries read
+  int arcs_skipped = 0, idx_probes = 0;
 };
 
 // Diagnostic build only (make prof): a lap timer on lane 0.  KD_LAP(s, i) adds
@@ -411,6 +443,10 @@ struct Team {
     Shared &s = Lds();
     if (with_global) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (nt == 64) {  // (one wave: program order is the barrier)
+      KdJitter();
+      return;
+    }
     gen += nt >> 6;
     if ((threadIdx.x & 63) == 0) atomicAdd(&s.soft_bar, 1);
     // (each team wave has a SIMD to itself: spinning costs nobody an issue slot)
@@ -454,23 +490,172 @@ __device__ __forceinline__ void ResetFrame(Shared &s, int lane0 = 0) {
   if (l == kFrameZeroWords + 2) s.f_best_next = kCostDead;
 }
 
-// ---- block-wide primitives (wave64 shuffles + one LDS hop) -----------------
-// Sum over the wave.  (An atomicAdd of a per-lane value makes hipcc serialise the
-// lanes in a waterfall loop -- thousands of cycles for sixteen waves -- so reduce
-// with shuffles first and let one lane add.)
+// ---- wave-wide primitives: DPP row operations and v_readlane -- no LDS -----------------
+// A reduction over the wave's 64 lanes is four DPP steps inside each row of 16 lanes (quad
+// permutes, then the mirror of 8 and of 16 lanes: after step k every lane holds the
+// aggregate of its group of 2^k), then the four rows' values are read into scalar registers
+// (v_readlane) and combined there: the result is wave-uniform.  Until round 5 these were
+// __shfl_xor loops, which hipcc compiles to ds_bpermute_b32 -- the LDS crossbar: six dependent
+// round trips behind s_waitcnt lgkmcnt on the queue the token table's atomics use (234
+// ds_bpermute in SearchKernel<1>), on the critical path of the running cutoff and of every
+// counter.  `old` is what a lane whose source lane is inactive keeps: the operation's identity.
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E;          // quad_perm [1,0,3,2], [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141, kDppMirror = 0x140;  // lane i <- 7 - i of 8, 15 - i of 16
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ int Dpp(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long DppMin64(unsigned long long v) {
+  const uint32_t lo = static_cast<uint32_t>(Dpp<CTRL>(-1, static_cast<int>(static_cast<uint32_t>(v))));
+  const uint32_t hi = static_cast<uint32_t>(Dpp<CTRL>(-1, static_cast<int>(static_cast<uint32_t>(v >> 32))));
+  const unsigned long long y = static_cast<unsigned long long>(hi) << 32 | lo;
+  return y < v ? y : v;
+}
+__device__ __forceinline__ unsigned long long ReadLane64(unsigned long long v, int l) {
+  const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(v)), l));
+  const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(v >> 32)), l));
+  return static_cast<unsigned long long>(hi) << 32 | lo;
+}
+
+// Sum over the wave (wave-uniform result).  (An atomicAdd of a per-lane value makes hipcc
+// serialise the lanes in a waterfall loop, so reduce first and let one lane add.)
 __device__ __forceinline__ int WaveSumInt(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  v += Dpp<kDppXor1>(0, v);
+  v += Dpp<kDppXor2>(0, v);
+  v += Dpp<kDppHalfMirror>(0, v);
+  v += Dpp<kDppMirror>(0, v);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+         __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
 __device__ __forceinline__ unsigned long long WaveMinU64(unsigned long long v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    unsigned long long y = __shfl_xor(v, d, 64);
-    v = y < v ? y : v;
+  v = DppMin64<kDppXor1>(v);
+  v = DppMin64<kDppXor2>(v);
+  v = DppMin64<kDppHalfMirror>(v);
+  v = DppMin64<kDppMirror>(v);
+  const unsigned long long a = ReadLane64(v, 0), b = ReadLane64(v, 16), c = ReadLane64(v, 32),
+                           d = ReadLane64(v, 48);
+  const unsigned long long ab = a < b ? a : b, cd = c < d ? c : d;
+  return ab < cd ? ab : cd;
+}
+
+__device__ __forceinline__ float WaveMaxF(float v) {
+  v = fmaxf(v, __int_as_float(Dpp<kDppXor1>(__float_as_int(v), __float_as_int(v))));
+  v = fmaxf(v, __int_as_float(Dpp<kDppXor2>(__float_as_int(v), __float_as_int(v))));
+  v = fmaxf(v, __int_as_float(Dpp<kDppHalfMirror>(__float_as_int(v), __float_as_int(v))));
+  v = fmaxf(v, __int_as_float(Dpp<kDppMirror>(__float_as_int(v), __float_as_int(v))));
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)),
+              b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)),
+              c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)),
+              d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+// Sum of floats over the wave in a FIXED association (pairs, quads, eights, rows, then the
+// four rows left to right): the same bits whichever wave computes it.
+__device__ __forceinline__ float WaveSumF(float v) {
+  v += __int_as_float(Dpp<kDppXor1>(0, __float_as_int(v)));
+  v += __int_as_float(Dpp<kDppXor2>(0, __float_as_int(v)));
+  v += __int_as_float(Dpp<kDppHalfMirror>(0, __float_as_int(v)));
+  v += __int_as_float(Dpp<kDppMirror>(0, __float_as_int(v)));
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)),
+              b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)),
+              c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)),
+              d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return ((a + b) + c) + d;
+}
+
+// Inclusive prefix sum over the wave's lanes: doubling steps inside a row (row_shr 1, 2, 4, 8:
+// a lane without a source adds 0), then lane 15 of rows 0 and 2 into the row above
+// (row_bcast15 to rows 1 and 3), then lane 31 into the upper half (row_bcast31).
+__device__ __forceinline__ int WaveInclusiveSumInt(int x) {
+  x += Dpp<0x111>(0, x);
+  x += Dpp<0x112>(0, x);
+  x += Dpp<0x114>(0, x);
+  x += Dpp<0x118>(0, x);
+  x += Dpp<0x142, 0xA>(0, x);
+  x += Dpp<0x143, 0xC>(0, x);
+  return x;
+}
+
+// The two largest values of a set and where the largest is: (a0, i0, a1), a0 >= a1.  Ties go to
+// the lower index, so the result does not depend on how the set was split.  NaNs are never taken
+// (every comparison with one is false): a label whose log-likelihood is NaN cannot pass a cutoff.
+struct Top2 {
+  float a0, a1;
+  int i0;
+};
+__device__ __forceinline__ Top2 Top2Empty() {
+  return Top2{-__int_as_float(0x7F800000), -__int_as_float(0x7F800000), 0x7FFFFFFF};
+}
+__device__ __forceinline__ void Top2Add(Top2 &t, float v, int i) {
+  if (v > t.a0 || (v == t.a0 && i < t.i0)) { t.a1 = t.a0; t.a0 = v; t.i0 = i; }
+  else if (v > t.a1) t.a1 = v;
+}
+__device__ __forceinline__ Top2 Top2Merge(const Top2 &x, const Top2 &y) {
+  const bool take_y = y.a0 > x.a0 || (y.a0 == x.a0 && y.i0 < x.i0);
+  Top2 r;
+  r.a1 = take_y ? (x.a0 > y.a1 ? x.a0 : y.a1) : (x.a1 > y.a0 ? x.a1 : y.a0);
+  r.a0 = take_y ? y.a0 : x.a0;
+  r.i0 = take_y ? y.i0 : x.i0;
+  return r;
+}
+template <int CTRL>
+__device__ __forceinline__ Top2 Top2Step(const Top2 &t) {
+  Top2 y;
+  y.a0 = __int_as_float(Dpp<CTRL>(__float_as_int(t.a0), __float_as_int(t.a0)));
+  y.a1 = __int_as_float(Dpp<CTRL>(__float_as_int(t.a1), __float_as_int(t.a1)));
+  y.i0 = Dpp<CTRL>(t.i0, t.i0);
+  return Top2Merge(t, y);
+}
+__device__ __forceinline__ Top2 Top2ReadLane(const Top2 &t, int l) {
+  Top2 r;
+  r.a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.a0), l));
+  r.a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.a1), l));
+  r.i0 = __builtin_amdgcn_readlane(t.i0, l);
+  return r;
+}
+// ... of the wave's lanes' sets (wave-uniform).  Call with the whole wave active.
+__device__ __forceinline__ Top2 WaveTop2(Top2 t) {
+  t = Top2Step<kDppXor1>(t);
+  t = Top2Step<kDppXor2>(t);
+  t = Top2Step<kDppHalfMirror>(t);
+  t = Top2Step<kDppMirror>(t);
+  return Top2Merge(Top2Merge(Top2ReadLane(t, 0), Top2ReadLane(t, 16)),
+                   Top2Merge(Top2ReadLane(t, 32), Top2ReadLane(t, 48)));
+}
+
+// This wave's share of the top two of the row in `ll` (whole workgroup; the row is complete
+// in LDS; a barrier must follow before LoadRowTop).
+__device__ __forceinline__ void StoreRowTop(Shared &s, int V) {
+  Top2 t = Top2Empty();
+  for (int v = threadIdx.x; v < V; v += kBlock) Top2Add(t, s.ll[v], v);
+  t = WaveTop2(t);
+  if ((threadIdx.x & 63) == 0) {
+    s.top_a0[threadIdx.x >> 6] = t.a0;
+    s.top_a1[threadIdx.x >> 6] = t.a1;
+    s.top_i0[threadIdx.x >> 6] = t.i0;
   }
-  return v;
+}
+// The row's lowest acoustic cost m0 (= minus its highest log-likelihood), that label's column
+// l0, and the second lowest m1 (+inf for a row of one column): wave-uniform.
+static_assert(kWaves <= 16, "LoadRowTop combines the waves' shares in one row of 16 lanes");
+__device__ __forceinline__ void LoadRowTop(Shared &s, float &m0, float &m1, int &l0) {
+  const int lane = threadIdx.x & 63;
+  Top2 t = Top2Empty();
+  const int w = lane < kWaves ? lane : 0;
+  const float a0 = s.top_a0[w], a1 = s.top_a1[w];
+  const int i0 = s.top_i0[w];
+  if (lane < kWaves) { t.a0 = a0; t.a1 = a1; t.i0 = i0; }
+  t = Top2Step<kDppXor1>(t);
+  t = Top2Step<kDppXor2>(t);
+  t = Top2Step<kDppHalfMirror>(t);
+  t = Top2Step<kDppMirror>(t);
+  t = Top2ReadLane(t, 0);
+  m0 = -t.a0;
+  m1 = -t.a1;
+  l0 = t.i0;
 }
 
 // atomicMin(p, v) from the lanes with `on`, to one LDS word.  hipcc turns such a
@@ -962,6 +1147,45 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
   }
 }
 
+// The arcs with input label `il` among the emitting arcs [abeg, abeg + deg) of a state, through
+// the label index (SearchParams::lab_idx: the range's (ilabel, offset) pairs, sorted): a binary
+// search over 4-byte entries -- ceil(log2(deg + 1)) dependent loads that mostly hit the one or
+// two cache lines the range's entries occupy -- then `visit(arc index, arc)` for every match.
+// Replaces, for a token whose cost leaves room for this one label only, the loop over all its
+// arcs (faster-decoder.cc:204-211, lattice-simple-decoder.cc:375-399).  `probes` counts the
+// entries read, `fetched` the arcs.
+template <class Visit>
+__device__ __forceinline__ void IndexedArcs(CParams &p, int abeg, int deg, uint32_t il, int &probes,
+                                            int &fetched, Visit visit) {
+  const KD_G uint32_t *idx = ToG(p.lab_idx) + abeg;
+  const uint32_t target = il << kIdxOffBits;
+  constexpr uint32_t kOffMask = (1u << kIdxOffBits) - 1u;
+  int lo = 0, n = deg;
+  uint32_t cand = 0xFFFFFFFFu;  // the entry at the final `lo` (its probe was the last to answer ">=")
+  while (n > 0) {
+    const int half = n >> 1;
+    const uint32_t e = idx[lo + half];
+    ++probes;
+    if (e < target) {
+      lo += half + 1;
+      n -= half + 1;
+    } else {
+      n = half;
+      cand = e;
+    }
+  }
+  while (lo < deg && (cand >> kIdxOffBits) == il) {
+    const uint32_t aidx = static_cast<uint32_t>(abeg) + (cand & kOffMask);
+    const ArcRec ar = LoadArcRec(p.arcs, aidx);
+    ++lo;
+    // (the next entry is requested with the arc: a state may hold several arcs of one label)
+    cand = idx[lo < deg ? lo : deg - 1];
+    ++probes;
+    ++fetched;
+    visit(aidx, ar);
+  }
+}
+
 // Folds the lanes' running minima into s.min_new.  Call where the wave is converged.
 template <int M>
 __device__ __forceinline__ void PublishMin(const FrameCtx<M> &c) {
@@ -1160,6 +1384,14 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
   // and the one after's token fields are already in flight (loads return in order: the wait
   // for the arcs covers them), so a chunk costs one round trip, not three.  (An index past
   // the frontier reads record 0, which exists.)
+  // label index (see the tier-1 frames' second pass): the row's two lowest acoustic costs
+  [[maybe_unused]] float t_m0 = 0.0f, t_m1 = 0.0f;
+  [[maybe_unused]] int t_l0 = 0;
+  [[maybe_unused]] bool idx_on = false;
+  if constexpr (!EPS && M != 2 && KD_LABEL_INDEX != 0) {
+    idx_on = c.ll_in_lds && c.adaptive_beam >= 0.0f;
+    if (idx_on) LoadRowTop(s, t_m0, t_m1, t_l0);
+  }
   [[maybe_unused]] uint32_t pf_st = 0, pf_st2 = 0;
   [[maybe_unused]] double pf_cst = 0.0, pf_cst2 = 0.0;
   [[maybe_unused]] bool pf_ok = false;
@@ -1226,7 +1458,34 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
         const int deg = EPS ? r.arc_end - r.emit_end : r.emit_end - r.arc_begin;
         if (EPS) { cnt.eps_exp += 1; cnt.eps_arcs += deg; }
         else { cnt.tokens_expanded += 1; cnt.arcs_scanned += deg; }
-        if (deg > kSmallDeg) {
+        bool indexed = false;
+        if constexpr (!EPS && M != 2 && KD_LABEL_INDEX != 0) {
+          if (idx_on && deg > kSmallDeg && deg < (1 << kIdxOffBits)) {
+            unsigned long long seen = s.min_new;
+            seen = c.run_min < seen ? c.run_min : seen;
+            bool others_out, best_in;
+            if constexpr (M == 1) {
+              const float cur = static_cast<float>(cst), lim = KCf<M>(seen) + c.adaptive_beam;
+              others_out = (cur + t_m1) + p.emit_w_min >= lim;
+              best_in = (cur + t_m0) + p.emit_w_min < lim;
+            } else {
+              const double lim = KC<M>(seen) + static_cast<double>(c.adaptive_beam);
+              others_out = (static_cast<double>(p.emit_w_min) + cst) + static_cast<double>(t_m1) >= lim;
+              best_in = (static_cast<double>(p.emit_w_min) + cst) + static_cast<double>(t_m0) < lim;
+            }
+            if (others_out) {
+              indexed = true;
+              int probes = 0, fetched = 0;
+              if (best_in)
+                IndexedArcs(p, abeg, deg, static_cast<uint32_t>(t_l0 + 1), probes, fetched,
+                            [&](uint32_t aidx, const ArcRec &ar) { FilterArc<EPS>(c, ar, aidx, cst, srcid); });
+              cnt.arcs_skipped += deg - fetched;
+              cnt.idx_probes += probes;
+            }
+          }
+        }
+        if (indexed) {
+        } else if (deg > kSmallDeg) {
           const int q = deg > 32 ? AggInc(&s.it_count[par])
                                  : kT1Front - 1 - AggInc(par ? &s.it_n16 : &s.it_n32);
           s.it_abeg[q] = abeg;
@@ -1371,7 +1630,7 @@ __device__ __forceinline__ float SelectKth(Shared *sp, const double *tok_cost, l
   uint32_t prefix = 0, pmask = 0;
   int kk = k;
   for (int shift = 24; shift >= 0; shift -= 8) {
-    if (tid < 256) s.hist[tid] = 0;
+    for (int b = tid; b < 256; b += tm.nt) s.hist[b] = 0;
     tm.Sync(false);
     for (int i = tid; i < n_in; i += tm.nt) {
       const uint32_t key =
@@ -1383,12 +1642,7 @@ __device__ __forceinline__ float SelectKth(Shared *sp, const double *tok_cost, l
       const int c0 = s.hist[4 * lane], c1 = s.hist[4 * lane + 1], c2 = s.hist[4 * lane + 2],
                 c3 = s.hist[4 * lane + 3];
       const int tot = c0 + c1 + c2 + c3;
-      int x = tot;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        int y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-      }
+      const int x = WaveInclusiveSumInt(tot);
       const int excl = x - tot;
       if (kk >= excl && kk < x) {
         int r = kk - excl, b = 0;
@@ -1552,6 +1806,13 @@ __device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
     Filter<true, false>(c, none, c.n_in, nullptr, cnt);
   }
   if (c.simple) return;
+  {  // (the label index's counters of this frame: straight into the launch totals)
+    const int w0 = WaveSumInt(cnt.arcs_skipped), w1 = WaveSumInt(cnt.idx_probes);
+    if ((tid & 63) == 0 && (w0 | w1)) {
+      atomicAdd(&s.ustat[KD_STAT_ARCS_SKIPPED], static_cast<unsigned long long>(w0));
+      atomicAdd(&s.ustat[KD_STAT_INDEX_PROBES], static_cast<unsigned long long>(w1));
+    }
+  }
   if (c.lattice)  // float, lattice-simple-decoder.cc:388-390
     c.cutoff = KCf<M>(s.min_new) + c.adaptive_beam;
   else
@@ -2293,10 +2554,14 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     ll_next[k] = have_next && nt == kBlock && v < p.num_cols ? next_row[v] : 0.0f;
   }
 #endif
-  if (tid < kMaskWords) wlmask[tid] = 0;  // worklist 0 collects the emitting insert's tokens
+  for (int w = tid; w < kMaskWords; w += nt) wlmask[w] = 0;  // worklist 0 collects the emitting insert's tokens
   c.run_min = kCostInf<M>;
   GetCutoff<true>(c, tm);
   KD_LAP(s, 1);
+  // (workgroup-uniform; a negative adaptive beam -- beam_delta below zero -- would let a bound
+  // at the cutoff hide the frame's minimum)
+  const bool idx_frame = KD_LABEL_INDEX != 0 && M != 2 && n_in >= kIdxMinFront && c.ll_in_lds &&
+                         c.adaptive_beam >= 0.0f;
 
   // ---- emitting filter over the LDS frontier (faster-decoder.cc:195-236)
   // The frontier's best token goes first (faster-decoder.cc:176-189 does the same to
@@ -2323,8 +2588,9 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
         __ballot(ok && deg > kSmallDeg && deg <= 64 && CK<M>(cst) == best_key);
     const int leader = first ? __builtin_ctzll(first) : -1;
     if (leader >= 0) {
-      const int b_abeg = __shfl(abeg, leader, 64), b_deg = __shfl(deg, leader, 64);
-      const int b_i = __shfl(i, leader, 64);
+      // (the leader is wave-uniform: v_readlane, not a shuffle through LDS)
+      const int b_abeg = __builtin_amdgcn_readlane(abeg, leader), b_deg = __builtin_amdgcn_readlane(deg, leader);
+      const int b_i = __builtin_amdgcn_readlane(i, leader);
       const double b_cst = s.it_cost[b_i];
       ArcRec ar1[1];
       int aidx1[1];
@@ -2341,12 +2607,78 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     }
     if (ok && lane != leader) {
       if (deg <= kSmallDeg) lane_arcs(EpsNo{}, abeg, deg, cst, static_cast<uint32_t>(i));
-      else push_items(EpsNo{}, i, abeg, deg, cst, static_cast<uint32_t>(i));
+      else if (!idx_frame) push_items(EpsNo{}, i, abeg, deg, cst, static_cast<uint32_t>(i));
     }
   }
   PublishMin(c);
   tm.Sync(false);
   KD_LAP(s, 3);
+  if (idx_frame) {
+    // ---- the tokens of more than kSmallDeg arcs, now that the best token's arcs have bounded
+    // the cutoff.  94 % of the arcs a frame used to score died at the cutoff: with peaky CTC
+    // posteriors a token that is not among the frame's best can only continue along the
+    // likeliest label.  Exactly: an arc out of a token with cost `cur` costs
+    // fl(fl(cur + ac[ilabel]) + weight) (lattice-simple-decoder.cc:383-385; faster-decoder.cc:210
+    // in double); float addition is monotone, so for every label but the row's likeliest it is at
+    // least fl(fl(cur + m1) + w_min) -- m1 the row's second-lowest acoustic cost, w_min the graph's
+    // lowest emitting weight.  If that bound is not below the RUNNING cutoff (which never
+    // undercuts the final one), none of those arcs can be kept, whatever they are: the token
+    // looks up its arcs of the likeliest label alone -- if even that label's bound is below the
+    // cutoff -- through the label index, and scores them as ever.  Tokens with more room take
+    // the work-item rows as before.  Which arcs are queued changes (fewer doomed ones); which
+    // are below the final cutoff, and the minimum that defines it, do not.
+    float t_m0, t_m1;
+    int t_l0;
+    LoadRowTop(s, t_m0, t_m1, t_l0);
+    const float w_min = p.emit_w_min;
+    for (int i0 = 0; i0 < n_in; i0 += nt) {
+      const int i = i0 + tid;
+      int abeg = 0, deg = 0;
+      double cst = 0.0;
+      bool ok = false;
+      if (i < n_in) {
+        cst = s.it_cost[i];
+        ok = cst < c.weight_cutoff;  // :202
+        if (ok) {
+          abeg = s.it_abeg[i];
+          deg = s.it_deg[i];
+        }
+      }
+      // (the same leader as in the pass above: its row is done)
+      const unsigned long long first =
+          __ballot(ok && deg > kSmallDeg && deg <= 64 && CK<M>(cst) == best_key);
+      const int leader = first ? __builtin_ctzll(first) : -1;
+      if (ok && deg > kSmallDeg && lane != leader) {
+        unsigned long long seen = s.min_new;
+        seen = c.run_min < seen ? c.run_min : seen;
+        bool others_out, best_in;
+        if constexpr (M == 1) {
+          const float cur = static_cast<float>(cst), lim = KCf<M>(seen) + c.adaptive_beam;
+          others_out = (cur + t_m1) + w_min >= lim;
+          best_in = (cur + t_m0) + w_min < lim;
+        } else {
+          const double lim = KC<M>(seen) + static_cast<double>(c.adaptive_beam);
+          others_out = (static_cast<double>(w_min) + cst) + static_cast<double>(t_m1) >= lim;
+          best_in = (static_cast<double>(w_min) + cst) + static_cast<double>(t_m0) < lim;
+        }
+        if (others_out && deg < (1 << kIdxOffBits)) {
+          int probes = 0, fetched = 0;
+          if (best_in)
+            IndexedArcs(p, abeg, deg, static_cast<uint32_t>(t_l0 + 1), probes, fetched,
+                        [&](uint32_t aidx, const ArcRec &ar) {
+                          FilterArc<false, true>(c, ar, aidx, cst, static_cast<uint32_t>(i));
+                        });
+          cnt.arcs_skipped += deg - fetched;
+          cnt.idx_probes += probes;
+        } else {
+          push_items(EpsNo{}, i, abeg, deg, cst, static_cast<uint32_t>(i));
+        }
+      }
+    }
+    PublishMin(c);
+    tm.Sync(false);
+    KD_LAP(s, 2);
+  }
   // The next frame's log-likelihood row is requested HERE, next to the work items' arc
   // gathers, and stored when the emitting filter is done with this frame's row.  (Requested
   // when the frame began -- as until round 3 -- its latency was not hidden but exposed: the
@@ -2366,10 +2698,22 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // the emitting filter is done with this frame's log-likelihood row: the next
   // frame's row (fetched into registers when this frame began) takes its place
   if (have_next && nt == kBlock) {
+    Top2 top = Top2Empty();
 #pragma unroll
     for (int k = 0; k < kPfRegs; ++k) {
       const int v = tid + k * kBlock;
-      if (v < p.num_cols) s.ll[v] = ll_next[k];
+      if (v < p.num_cols) {
+        s.ll[v] = ll_next[k];
+        Top2Add(top, ll_next[k], v);
+      }
+    }
+    // ... and this wave's share of the new row's two likeliest labels (LoadRowTop; read by
+    // the next frame, behind the frame-end barrier)
+    top = WaveTop2(top);
+    if (lane == 0) {
+      s.top_a0[tid >> 6] = top.a0;
+      s.top_a1[tid >> 6] = top.a1;
+      s.top_i0[tid >> 6] = top.i0;
     }
   }
   const int q_emit = Uni(s.q_n);
@@ -2434,7 +2778,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // ---- ProcessNonemitting to a fixpoint (:59-119)
   int cur = 0, q_begin = q_emit;
   while (Uni(s.wl_count[cur]) != 0) {
-    if (tid < kMaskWords) wlmask[(cur ^ 1) * kMaskWords + tid] = 0;
+    for (int w = tid; w < kMaskWords; w += nt) wlmask[(cur ^ 1) * kMaskWords + w] = 0;
     if (tid == 0) {
       s.wl_count[cur ^ 1] = 0;
       s.it_count[0] = 0;
@@ -2450,14 +2794,18 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     // The team's threads scan the worklist mask, 8 slots each (a lane rarely finds
     // more than one token).  Tokens are taken two at a time: both state records are
     // requested before either is used, and so are the arcs of low-degree tokens.
-    for (int w8 = tid; w8 < kT1Slots / 8; w8 += nt) {
-      uint32_t m = (wlmask[cur * kMaskWords + (w8 >> 2)] >> ((w8 & 3) * 8)) & 0xFFu;
+    // (a one-wave team takes whole words: two per lane instead of eight bytes)
+    const int gshift = nt == 64 ? 5 : 3;
+    for (int w8 = tid; w8 < (kT1Slots >> gshift); w8 += nt) {
+      const uint32_t mword = wlmask[cur * kMaskWords + ((w8 << gshift) >> 5)];
+      uint32_t m = gshift == 5 ? mword : (mword >> ((w8 & 3) * 8)) & 0xFFu;
+      const int hbase = w8 << gshift;
       while (m) {
         uint32_t h[2];
-        h[0] = static_cast<uint32_t>(w8 * 8 + __builtin_ctz(m));
+        h[0] = static_cast<uint32_t>(hbase + __builtin_ctz(m));
         m &= m - 1;
         const bool two = m != 0;
-        h[1] = two ? static_cast<uint32_t>(w8 * 8 + __builtin_ctz(m)) : h[0];
+        h[1] = two ? static_cast<uint32_t>(hbase + __builtin_ctz(m)) : h[0];
         if (two) m &= m - 1;
         double cst[2];
         bool ok[2], own[2];
@@ -2582,8 +2930,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // The new frontier's state records (at most kNextRecs tokens per lane when the next
   // frame is a tier-1 frame): requested here, used when the frame ends -- the gather
   // overlaps the passes in between.
-  constexpr int kNextRecs = (kT1Front + kBlock - 1) / kBlock;
-  static_assert(kT1Narrow == 0, "kNextRecs assumes the whole workgroup runs the frame");
+  constexpr int kNextRecs = (kT1Front + kBlock - 1) / kBlock;  // (a one-wave team: see the end of the frame)
   ArcRange next_rec[kNextRecs];
   bool next_on[kNextRecs];
   {
@@ -2630,6 +2977,8 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
         if (emit != kEmitDegEscape) {
           s.it_abeg[i] = static_cast<int32_t>(static_cast<uint32_t>(ck));
           s.it_deg[i] = static_cast<int32_t>(emit);
+        } else {
+          s.it_deg[i] = -1;  // (looked up: next_rec, or the one-wave team's pass at the end)
         }
       }
     }
@@ -2725,6 +3074,17 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     if (next_on[j]) {
       s.it_abeg[tid + j * nt] = next_rec[j].arc_begin;
       s.it_deg[tid + j * nt] = next_rec[j].emit_end - next_rec[j].arc_begin;
+    }
+  }
+  if (nt != kBlock && next_small) {
+    // a one-wave team's frontier of more than kNextRecs tokens per lane (rare: such a frame
+    // starts from a handful of tokens): the rest of the records, fetched here
+    for (int i = tid + kNextRecs * nt; i < n_out; i += nt) {
+      if (M != 1 || s.it_deg[i] < 0) {
+        const ArcRange r = LoadArcRange(p.states, s.it_src[i]);
+        s.it_abeg[i] = r.arc_begin;
+        s.it_deg[i] = r.emit_end - r.arc_begin;
+      }
     }
   }
   // Everything below that READS the frame's counters (n_emit_fin, n_eps_fin, best_next) and
@@ -2975,8 +3335,7 @@ __device__ __forceinline__ void NormalizeRow(Shared &s, int V) {
   float *red = reinterpret_cast<float *>(s.red64);
   float m = -FLT_MAX;
   for (int v = tid; v < V; v += kBlock) m = fmaxf(m, s.ll[v]);
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+  m = WaveMaxF(m);
   if (lane == 0) red[wave] = m;
   LdsBarrier();
   float mx = red[0];
@@ -2985,8 +3344,7 @@ __device__ __forceinline__ void NormalizeRow(Shared &s, int V) {
   LdsBarrier();
   float sum = 0.0f;
   for (int v = tid; v < V; v += kBlock) sum += expf(s.ll[v] - mx);
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+  sum = WaveSumF(sum);
   if (lane == 0) red[wave] = sum;
   LdsBarrier();
   float total = red[0];
@@ -3078,10 +3436,9 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     if (!c.ll_in_lds || f < 0 || f >= target) return;
     const KD_G float *row = row_of(f);
     for (int v = tid; v < p.num_cols; v += kBlock) s.ll[v] = row[v];
-    if (p.log_softmax) {  // (logits: normalised here, once per staging)
-      LdsBarrier();
-      NormalizeRow(s, p.num_cols);
-    }
+    LdsBarrier();
+    if (p.log_softmax) NormalizeRow(s, p.num_cols);  // (logits: normalised here, once per staging)
+    StoreRowTop(s, p.num_cols);  // (the label index's view of the row)
   };
   // At the top of the loop the per-frame counters are reset and s.ll holds the
   // frame's log-likelihood row: a frame boundary costs one barrier.
@@ -3147,7 +3504,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     bool filtered = false;  // the emitting filter already ran (tier 1 did not fit)
     if (small) {
       // a small frame of few tokens is run by the first four waves alone
-      const Team tm{kT1Narrow > 0 && c.n_in <= kT1Narrow ? 256 : kBlock, gen};
+      const Team tm{kT1Narrow > 0 && c.n_in <= kT1Narrow ? kNarrowLanes : kBlock, gen};
       const bool have_next = c.ll_in_lds && frame + 1 < target;
       if (tid < tm.nt) {
         const KD_G float *ll_next = row_of(have_next ? frame + 1 : frame);
@@ -3164,11 +3521,14 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
         // the idle waves hold the next frame's row in registers until the frame is over
         float ll_next[kLlRegs];
         const KD_G float *row = row_of(have_next ? frame + 1 : frame);
+        Top2 top = Top2Empty();
 #pragma unroll
         for (int k = 0; k < kLlRegs; ++k) {
           const int v = tid - (kBlock - kLlLanes) + k * kLlLanes;
           ll_next[k] = have_next && v < p.num_cols ? row[v] : 0.0f;
+          if (have_next && v < p.num_cols) Top2Add(top, ll_next[k], v);
         }
+        top = WaveTop2(top);
         LdsBarrier();
         if (have_next) {
 #pragma unroll
@@ -3176,13 +3536,29 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
             const int v = tid - (kBlock - kLlLanes) + k * kLlLanes;
             if (v < p.num_cols) s.ll[v] = ll_next[k];
           }
+          // (the new row's likeliest labels, by wave: the team's own share is empty)
+          if ((tid & 63) == 0) {
+            s.top_a0[tid >> 6] = top.a0;
+            s.top_a1[tid >> 6] = top.a1;
+            s.top_i0[tid >> 6] = top.i0;
+          }
+          if (tid == kNarrowLanes) {
+            const Top2 none = Top2Empty();
+            s.top_a0[0] = none.a0;
+            s.top_a1[0] = none.a1;
+            s.top_i0[0] = none.i0;
+          }
         }
       }
       if (tm.nt != kBlock) LdsBarrier();  // the next frame's row is in place
       r = Uni(s.ctl[frame & 1].r);
       // (logits: the row the frame swapped in for the next one; a frame that is run again
       // below stages its rows afresh)
-      if (p.log_softmax && r == 0 && have_next) NormalizeRow(s, p.num_cols);
+      if (p.log_softmax && r == 0 && have_next) {
+        NormalizeRow(s, p.num_cols);
+        StoreRowTop(s, p.num_cols);  // (the frame noted the top of the logits)
+        LdsBarrier();
+      }
       upper_dirty = true;
       best_stale = true;
       if (r == 0) {
@@ -3194,6 +3570,8 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
         tot.eps_exp += cnt.eps_exp;
         tot.arcs_scanned += cnt.arcs_scanned;
         tot.eps_arcs += cnt.eps_arcs;
+        tot.arcs_skipped += cnt.arcs_skipped;
+        tot.idx_probes += cnt.idx_probes;
       } else if (r == kRedo) {
         // the queue overflowed: all of the frame again in the big path, which
         // needs this frame's row back (its place was taken by the next frame's)
@@ -3228,6 +3606,8 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
         filtered = true;
         cnt.eps_exp = 0;
         cnt.eps_arcs = 0;
+        tot.arcs_skipped += cnt.arcs_skipped;  // (the emitting filter is not run again)
+        tot.idx_probes += cnt.idx_probes;
       }
     }
     if (r == kRetry) {
@@ -3274,6 +3654,11 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       atomicAdd(&s.ustat[KD_STAT_EPS_EXPANSIONS], static_cast<unsigned long long>(w1));
       atomicAdd(&s.ustat[KD_STAT_ARCS_SCANNED], static_cast<unsigned long long>(w2));
       atomicAdd(&s.ustat[KD_STAT_EPS_ARCS_SCANNED], static_cast<unsigned long long>(w3));
+    }
+    const int w4 = WaveSumInt(tot.arcs_skipped), w5 = WaveSumInt(tot.idx_probes);
+    if ((tid & 63) == 0) {
+      atomicAdd(&s.ustat[KD_STAT_ARCS_SKIPPED], static_cast<unsigned long long>(w4));
+      atomicAdd(&s.ustat[KD_STAT_INDEX_PROBES], static_cast<unsigned long long>(w5));
     }
   }
   __syncthreads();

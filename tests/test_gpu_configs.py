@@ -185,6 +185,58 @@ def test_bench_scale_hlg_1024_per_call_two_calls_in_flight(oracle):
     assert checked >= 64
 
 
+@pytest.mark.parametrize("max_active", [INT_MAX, 10000])
+def test_cfg3_lattice_faster_defaults_full_size(oracle, max_active):
+    """configs[2] with the options of the decoder it NAMES: the reference declares
+    LatticeFasterDecoder's config only (lattice-faster-decoder.h:48-55: min_active = 200,
+    max_active = INT_MAX, beam_delta = 0.5) -- GetCutoff of faster-decoder.cc:244-336 on the
+    lattice decoder's float costs -- and SURVEY 8(d) config 3 asks for max_active = 10000 too.
+    The bench graph (13 M arcs), beam 15, lattice beam 8, 128 utterances of T = 250 in ONE
+    launch: GetCutoff's counting pass every frame of more than 200 tokens, SelectKth over a
+    frontier in global memory where max_active binds (frontiers reach several times 10000).
+    8 sampled utterances: lattice SET EQUALITY with the canonical oracle at the same options,
+    FinalRelativeCost; and the counters say that the cutoff really bound."""
+    import torch
+    import bench
+    wl = bench.WORKLOADS["hlg-lattice"]
+    g = _bench_graph("hlg-lattice")
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    N, T, V = 128, wl["frames"], wl["V"]
+    # (a quarter of the batch with flatter posteriors: frontiers beyond 10000 tokens)
+    ids = list(range(9000, 9000 + N))
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        lps = list(ex.map(lambda u: synth.make_logprobs(T, V, u, peak=8.0 if u % 4 == 3 else 12.0,
+                                                        lexicon=g["lexicon"]), ids))
+    dev = torch.from_numpy(np.stack(lps)).cuda()
+    opts = dict(beam=15.0, lattice_beam=8.0, min_active=200, max_active=max_active, prune_interval=25)
+    lb = cabi.LatticeBatch(G, max_batch=N, max_frames=T, **opts)
+    assert lb.lopts.beam_delta == 0.5
+    lb.decode_tensor(dev)
+    assert lb.num_frames_decoded().tolist() == [T] * N
+    assert not lb.status().any()
+    lats, frc, st = lb.raw_lattices(), lb.final_relative_cost(), lb.stats()
+    # the cutoff bound: tokens that entered a frame and were NOT expanded (LatticeSimpleDecoder
+    # expands every token: tokens_expanded == tokens_in there)
+    assert (st[:, 2] < st[:, 1]).sum() >= N // 2, (st[:, 1].sum(), st[:, 2].sum())
+    if max_active != INT_MAX:
+        assert st[:, 8].max() > max_active  # frontiers larger than max_active occurred ...
+        big = st[:, 8] > max_active
+        assert (st[big, 2] < st[big, 1]).all()  # ... and were cut
+    oopts = {k: v for k, v in opts.items() if k != "prune_interval"}
+    sample = [0, 3, 7, 31, 64, 99, 126, 127]  # (3, 7, 31, 99, 127: the flat ones)
+    if max_active != INT_MAX:
+        assert any(st[i, 8] > max_active for i in sample)
+    for i in sample:
+        can = oracle.CanonLatticeDecoder(OG, **oopts)
+        can.decode(lps[i])
+        cl, gl = can.get_raw_lattice(), lats[i]
+        assert gl.state_set() == cl.state_set(), i
+        assert gl.arc_set() == cl.arc_set() and len(gl.src) == len(cl.src), i
+        assert gl.final_set() == cl.final_set(), i
+        assert frc[i] == np.float32(can.final_relative_cost()), i
+
+
 def test_bench_scale_large_lm_256_per_launch_three_times(oracle):
     """BASELINE configs[4]'s graph (141 M arcs, beam 17) at bench scale: 256 utterances in one
     launch, one per workgroup, library-default capacities (the pools and tables grow in the
@@ -216,14 +268,34 @@ def test_bench_scale_large_lm_256_per_launch_three_times(oracle):
 
 
 @pytest.mark.parametrize("kind", ["H", "HL", "HLG"])
-def test_icefall_style_driver_runs_end_to_end(kind, tmp_path):
+def test_icefall_style_driver_runs_end_to_end(kind, tmp_path, oracle):
     """examples/decode_ctc.py: DecodableCtc -> FasterDecoder(max_active=3000).decode ->
     reached_final -> get_best_path -> linear symbol sequence -> tokens / words -> WER, with
-    the graph going through an OpenFst binary file (Fst.read) on the way."""
+    the graph going through an OpenFst binary file (Fst.read) on the way.  What the decoder
+    over the graph READ FROM THE FILE returns is compared with the oracle's decode of the graph
+    the file was written from: labels equal, costs within 1e-4 (the host sums
+    the path's float arc costs; the oracle hands back its own sums), reached_final equal --
+    against the canonical decoder and, for the labels, the reference-order one."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "examples"))
     import decode_ctc
-    wer, agree = decode_ctc.main(kind, 4, graph_path=str(tmp_path / f"{kind}.fst"))
+    got = []
+    wer, agree = decode_ctc.main(kind, 4, graph_path=str(tmp_path / f"{kind}.fst"), results=got)
     assert agree == 4  # the lattice decoder's best path is the 1-best decoder's
+    g, per_utt = got[0], got[1:]
+    assert len(per_utt) == 4
+    OG = oracle.Graph(g)
+    for utt, (lp, isyms, osyms, (gc, ac), rf) in enumerate(per_utt):
+        can = oracle.FasterDecoder(OG, policy=1, max_active=3000)
+        can.decode(lp)
+        p = can.get_best_path()
+        assert p.ok and rf == can.reached_final(), (kind, utt)
+        assert isyms == p.isyms.tolist() and osyms == p.osyms.tolist(), (kind, utt)
+        assert abs(gc - p.total_cost[0]) <= 1e-4 * max(1.0, abs(gc)), (kind, utt)
+        assert abs(ac - p.total_cost[1]) <= 1e-4 * max(1.0, abs(ac)), (kind, utt)
+        ref = oracle.FasterDecoder(OG, policy=0, max_active=3000)
+        ref.decode(lp)
+        pr = ref.get_best_path()
+        assert isyms == pr.isyms.tolist() and osyms == pr.osyms.tolist(), (kind, utt)
     if kind != "H":
         assert wer is not None and wer < 0.35  # peaky synthetic posteriors: few errors

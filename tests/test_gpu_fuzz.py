@@ -61,9 +61,11 @@ def test_exports_are_byte_identical_under_timing_perturbation():
     every wave passes every barrier at another time than in the shipped one and than in its own
     previous run: results, order included, do not depend on wave scheduling."""
     digests = []
-    for lib in ("libkd_hip.so", "libkd_hip_jitter_full.so" if os.path.exists(os.path.join(
-            ROOT, "kaldi-decoder_amd", "python", "kaldi_decoder", "lib", "libkd_hip_jitter_full.so"))
-            else "libkd_hip_jitter.so", "libkd_hip_jitter.so"):
+    libs = ("libkd_hip.so", "libkd_hip_jitter_full.so", "libkd_hip_jitter.so")
+    for lib in libs:  # (all three are part of `make all`: a missing one fails, it does not degrade)
+        assert os.path.exists(os.path.join(ROOT, "kaldi-decoder_amd", "python", "kaldi_decoder", "lib", lib)), \
+            f"{lib} is missing: make -C kaldi-decoder_amd all"
+    for lib in libs:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "export_digest.py")],
                            capture_output=True, text=True, timeout=300, env={**os.environ, "KD_HIP_LIB": lib})
         assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]

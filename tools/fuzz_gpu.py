@@ -64,6 +64,13 @@ def main():
     keep_going = os.environ.get("KD_FUZZ_KEEP_GOING") == "1"  # (diagnosis: count mismatches, do not stop)
     while time.time() < t_end:
         g, lex, V = graph(rng)
+        if rng.random() < 0.25:
+            # emitting arcs with negative weights (a weight-pushed graph): the label index's
+            # lower bound uses the graph's lowest emitting weight
+            w = g["weight"].copy()
+            emit = g["ilabel"] != 0
+            w[emit] -= np.float32(rng.uniform(0.1, 2.0)) * (rng.random(int(emit.sum())) < 0.5).astype(np.float32)
+            g = dict(g, weight=w.astype(np.float32))
         G, OG = cabi.Graph(g), oracle.Graph(g)
         heavy = g["num_states"] >= 8000
         B = int(rng.integers(1, 4 if heavy else 9))
