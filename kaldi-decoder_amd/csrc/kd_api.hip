@@ -15,6 +15,7 @@
 
 #include "kd_device.h"
 #include "kd_graph_check.h"
+#include "kd_label_index.h"
 #include "kd_hip.h"
 
 using namespace kd;
@@ -758,18 +759,18 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
       ol[at] = olabel[a];
     }
   }
-  // Label index: per state, (ilabel, offset) of its emitting arcs sorted by ilabel -- the arcs
-  // themselves keep their order (arc indices are tie-breakers and leave the library in lattices).
-  // A token whose cost leaves room for one or two labels of the frame only looks THOSE up
-  // (kd_search.hip, IndexedArcs) instead of reading every arc: the loop of
+  // Label index (kd_label_index.h): per state, the keys (ilabel, offset) of its emitting arcs as an
+  // implicit 5-ary search tree, in an array parallel to the arcs -- the arcs themselves keep their
+  // order.  A token whose cost leaves room for the frame's likeliest label only looks THAT label
+  // up (kd_search.hip, IndexedArcs) instead of reading every arc: the loop of
   // faster-decoder.cc:204-211 / lattice-simple-decoder.cc:375-399 visits arcs whose cost is known
   // to be beyond the cutoff from a lower bound (this frame's second-lowest acoustic cost, the
-  // graph's lowest emitting weight).  States of 4096 emitting arcs or more keep no index.
-  std::vector<uint32_t> li(std::max<int64_t>(na, 1), 0xFFFFFFFFu);
+  // graph's lowest emitting weight).  (+ 4 entries: a node read at the end of the array is 16 bytes.)
+  std::vector<uint32_t> li(static_cast<size_t>(std::max<int64_t>(na, 1)) + 4, kIdxNone);
   float w_min = std::numeric_limits<float>::infinity();
   bool w_nan = false;
   {
-    std::vector<uint32_t> tmp;
+    std::vector<uint32_t> labs, tmp;
     for (int32_t s = 0; s < num_states; ++s) {
       const int32_t b = st[s].arc_begin, e = st[s].emit_end;
       for (int32_t a = b; a < e; ++a) {
@@ -777,12 +778,11 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
         if (w != w) w_nan = true;
         else if (w < w_min) w_min = w;
       }
-      if (e - b >= (1 << kIdxOffBits)) continue;
+      if (e - b >= kIdxMaxDeg) continue;
+      labs.resize(e - b);
       tmp.resize(e - b);
-      for (int32_t a = b; a < e; ++a)
-        tmp[a - b] = (ar[a].lab & static_cast<uint32_t>(kMaxIlabel)) << kIdxOffBits | static_cast<uint32_t>(a - b);
-      std::sort(tmp.begin(), tmp.end());
-      std::copy(tmp.begin(), tmp.end(), li.begin() + b);
+      for (int32_t a = b; a < e; ++a) labs[a - b] = ar[a].lab & static_cast<uint32_t>(kMaxIlabel);
+      LabelIndexBuild(labs.data(), e - b, li.data() + b, tmp.data());
     }
   }
   KD_HIP_TRY(hipSetDevice(device));

@@ -39,7 +39,7 @@ struct __attribute__((aligned(16))) ArcPacked {
   uint32_t next;      // bits 0..30 next state, bit 31: that state has epsilon arcs
 };
 constexpr int kIlabelBits = 20;
-constexpr int kIdxOffBits = 12;  // label-index entries: offsets below 4096 (larger states: no index)
+constexpr int kIdxOffBits = 12;  // label-index keys: ilabel << 12 | offset << 1 | more (kd_label_index.h)
 constexpr int32_t kMaxIlabel = (1 << kIlabelBits) - 1;
 // degrees that do not fit are stored as these, and looked up in the state record as before
 constexpr uint32_t kEmitDegEscape = 255u, kEpsDegEscape = 15u;
@@ -178,9 +178,9 @@ struct SearchParams {
   const StateRec *states;
   const ArcPacked *arcs;
   const int32_t *arc_olabel;  // [arcs] read by GetRawLattice / GetBestPath only
-  // label index (kd_api.hip, BuildLabelIndex): entry a of a state's emitting range holds
-  // (ilabel << kIdxOffBits | offset of that arc in the range), the range sorted by it -- so a
-  // token finds its arcs of ONE ilabel by binary search instead of reading all its arcs
+  // label index (kd_label_index.h): parallel to the arcs; a state's emitting range holds the keys
+  // (ilabel, offset of the arc in the range) as an implicit 5-ary search tree -- so a token finds
+  // its arcs of ONE ilabel in a few dependent 16-byte loads instead of reading all its arcs
   const uint32_t *lab_idx;
   float emit_w_min;           // the lowest weight of any emitting arc of the graph (NaN: unknown)
   int32_t start;

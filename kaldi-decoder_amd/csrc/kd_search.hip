@@ -52,6 +52,7 @@
 
 #include "kd_device.h"
 #include "kd_hip.h"
+#include "kd_label_index.h"
 
 // Timing-perturbation build (make jitter; -DKD_JITTER=<unit>): behind EVERY workgroup barrier
 // -- __syncthreads, LdsBarrier, Team::Sync -- each wave sleeps a pseudo-random time of its own
@@ -119,8 +120,8 @@ constexpr int kLog2Slots = KD_LOG2_SLOTS;
 constexpr int kSlots = 1 << kLog2Slots;
 constexpr int kLdsFillLimit = kSlots * 3 / 4;
 constexpr int kVmax = KD_VMAX;  // log-likelihood row staged in LDS when V <= kVmax
-// the waves a one-wave team leaves idle fetch the next frame's row meanwhile
-constexpr int kNarrowLanes = 64;
+// the waves a four-wave team leaves idle fetch the next frame's row meanwhile
+constexpr int kNarrowLanes = 256;
 constexpr int kLlLanes = KD_BLOCK - kNarrowLanes, kLlRegs = (kVmax + kLlLanes - 1) / kLlLanes;
 // ... a whole-workgroup team carries it in registers through the emitting filter
 constexpr int kPfRegs = (kVmax + KD_BLOCK - 1) / KD_BLOCK;
@@ -140,6 +141,13 @@ constexpr int kPfRegs = (kVmax + KD_BLOCK - 1) / KD_BLOCK;
 #define KD_IDX_MIN_FRONT 192
 #endif
 constexpr int kIdxMinFront = KD_IDX_MIN_FRONT;
+// The best token's row is scored ahead of the others (a tight running cutoff early: half as many
+// candidates queued) in frames of at least this many tokens; a smaller frame queues the little
+// it has either way, and the row's round trip ahead of the work items is the dearer.
+#ifndef KD_LEAD_MIN_FRONT
+#define KD_LEAD_MIN_FRONT 0
+#endif
+constexpr int kLeadMinFront = KD_LEAD_MIN_FRONT;
 constexpr int kSmallDeg = KD_SMALL_DEG;  // tokens with at most this many arcs stay on their lane
 constexpr int kGroup = KD_GROUP;  // queued tokens a wave scores at a time
 #ifndef KD_BIG_GROUP
@@ -159,17 +167,21 @@ constexpr int kBigGroup = KD_BIG_GROUP;  // ... in the big tiers' filter (BigLoo
 constexpr int kT1Log2 = kLog2Slots - 1;
 constexpr int kT1Slots = 1 << kT1Log2;
 constexpr int kT1Front = KD_T1_FRONT;
-// ... of which frames up to this size are run by ONE wave (0: never -- the shipped setting).
-// A frame of a handful of tokens is a chain of two dozen phases, each a few dependent LDS or
-// memory round trips and a workgroup barrier: 23-25 k cycles whether it holds 3 tokens or 100
-// (tools/prof_sizes.py).  One wave needs no barrier at all (its LDS operations execute in
-// order: Team::Sync is a wait for its own counters) -- and is SLOWER: round 5, A/B on one box,
-// frames of up to 4 / 8 / 16 / 64 tokens on one wave: 36.7 / 35.6 / 35.5 / 35.0 M audio frames/s
-// against 38.4 M.  What the twelve waves buy a small frame is not lanes but independent
-// instruction streams: the best token's row, the other tokens' arcs, the three work-item lists
-// and the table clears are requested by different waves at once, and one wave walks them one
-// memory round trip after the other.  (Until round 3 a team of FOUR waves synchronised through
-// an LDS counter: slower too.)  The knob stays for the measurement.
+// ... of which frames up to this size are run by FOUR waves, one per SIMD, while the other
+// eight execute nothing but the team's barriers (RunUtterance: the quiet waves' loop).  A frame
+// of a handful of tokens is a chain of two dozen phases that costs 23-25 k cycles whether it
+// holds 3 tokens or 100 (tools/prof_sizes.py) -- and what it is made of is INSTRUCTION ISSUE:
+// every one of the twelve waves walks the frame's whole control path (~1.4 k vector
+// instructions a frame, nearly all of them finding nothing to do), three waves share a SIMD,
+// and a SIMD issues one vector instruction in four cycles: 3 x 1.4 k x 4 = 17 k cycles.  (Round
+// 5 found it by giving the CU more workgroups: three 256-thread workgroups per CU decode a
+// beam-9 workload -- 6 tokens a frame -- 1.8 x as fast as one of 768 threads, and lose at beam
+// 15, where the frames that hold the cycles want the whole CU's LDS.)  With four waves the SIMD
+// issues one wave's instructions; the quiet waves cost it three instructions a barrier.  What
+// did NOT work: ONE wave (round 5: frames of up to 4 / 8 / 16 / 64 tokens on one wave 36.7 /
+// 35.6 / 35.5 / 35.0 M audio frames/s against 38.4 M -- one wave walks the frame's independent
+// gathers one round trip after the other), and (until round 3) four waves that synchronised
+// through an LDS counter and spun on it.
 #ifndef KD_T1_NARROW
 #define KD_T1_NARROW 0
 #endif
@@ -259,7 +271,7 @@ struct Shared {
   // still pass this token's cutoff?"
   float top_a0[kWaves], top_a1[kWaves];
   int32_t top_i0[kWaves];
-  int32_t soft_bar;             // team barrier arrivals since the launch began
+  int32_t bar_final;            // a team's frame: the number of its last barrier (0: not known yet)
   int32_t alloc_ok;             // result of the last chunk allocation (0 ok, else a KD_UTT_* bit)
   // what a tier-1 frame leaves for the waves that sat it out, by frame parity:
   // result, new frontier (size, arena base), and what a replay in the big table needs
@@ -298,7 +310,7 @@ struct Shared {
   int lap_on, lap_pad;  // (KD_PROF_NMIN / KD_PROF_NMAX: only frames of that frontier size are timed)
 #endif
 };
-static_assert(sizeof(Shared) <= 163840 / KD_WG_PER_CU, "LDS budget");
+static_assert(sizeof(Shared) + 16 <= 163840 / KD_WG_PER_CU, "LDS budget (the block and the work-item word)");
 
 // The workgroup's LDS block.  Functions that are not inlined into the kernel reach
 // it through this (an LDS pointer passed as an argument would become a flat one).
@@ -428,31 +440,17 @@ __device__ __forceinline__ void TableBarrier() {
   if constexpr (LDS) LdsBarrier(); else __syncthreads();
 }
 
-// The threads that run a phase: the whole workgroup (hardware barrier), or its
-// first waves only (a counter in LDS; the rest of the workgroup is parked at the
-// frame-end barrier, so s_barrier is not available to the team).
+// The threads that run a frame: the whole workgroup, or (a frame of few tokens) its first
+// waves only -- one per SIMD -- while the other waves do nothing but keep the team company at
+// its barriers (QuietWaves below).  Either way a barrier is the hardware's s_barrier; a team
+// counts the barriers it passes, so that the quiet waves know which one is the last.
 struct Team {
   int nt;    // threads tid < nt take part; a multiple of 64
-  int &gen;  // this wave's count of team barriers passed (small teams)
+  int &gen;  // barriers this wave has passed since the frame began
   // LDS traffic only, or (with_global) global stores too
   __device__ __forceinline__ void Sync(bool with_global) const {
-    if (nt == kBlock) {
-      if (with_global) __syncthreads(); else LdsBarrier();
-      return;
-    }
-    Shared &s = Lds();
-    if (with_global) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (nt == 64) {  // (one wave: program order is the barrier)
-      KdJitter();
-      return;
-    }
-    gen += nt >> 6;
-    if ((threadIdx.x & 63) == 0) atomicAdd(&s.soft_bar, 1);
-    // (each team wave has a SIMD to itself: spinning costs nobody an issue slot)
-    while (__hip_atomic_load(&s.soft_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - gen < 0) {}
-    asm volatile("" ::: "memory");
-    KdJitter();
+    if (with_global) __syncthreads(); else LdsBarrier();
+    ++gen;
   }
 };
 
@@ -1148,42 +1146,40 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
 }
 
 // The arcs with input label `il` among the emitting arcs [abeg, abeg + deg) of a state, through
-// the label index (SearchParams::lab_idx: the range's (ilabel, offset) pairs, sorted): a binary
-// search over 4-byte entries -- ceil(log2(deg + 1)) dependent loads that mostly hit the one or
-// two cache lines the range's entries occupy -- then `visit(arc index, arc)` for every match.
-// Replaces, for a token whose cost leaves room for this one label only, the loop over all its
-// arcs (faster-decoder.cc:204-211, lattice-simple-decoder.cc:375-399).  `probes` counts the
-// entries read, `fetched` the arcs.
-template <class Visit>
-__device__ __forceinline__ void IndexedArcs(CParams &p, int abeg, int deg, uint32_t il, int &probes,
-                                            int &fetched, Visit visit) {
+// the label index (kd_label_index.h: the range's (ilabel, offset) keys as an implicit 5-ary
+// search tree, one 16-byte node per level -- three dependent loads for the 38-arc states that make
+// up an HLG frontier), then `visit(arc index, arc)` for every match: a state may hold several
+// arcs of one label, and the next one is looked for with the arc's fetch in flight.  Replaces,
+// for a token whose cost leaves room for this one label only, the loop over all its arcs
+// (faster-decoder.cc:204-211, lattice-simple-decoder.cc:375-399).  `probes` counts the
+// nodes read, `fetched` the arcs.
+typedef uint32_t IdxNodeVec __attribute__((ext_vector_type(4)));
+typedef IdxNodeVec IdxNodeMem __attribute__((aligned(4)));  // (a node starts wherever its range does)
+// The first key of label `il` in the range (kIdxNone: the state has no such arc) ...
+__device__ __forceinline__ uint32_t IndexFind(CParams &p, int abeg, int deg, uint32_t from_key, int &probes) {
   const KD_G uint32_t *idx = ToG(p.lab_idx) + abeg;
-  const uint32_t target = il << kIdxOffBits;
-  constexpr uint32_t kOffMask = (1u << kIdxOffBits) - 1u;
-  int lo = 0, n = deg;
-  uint32_t cand = 0xFFFFFFFFu;  // the entry at the final `lo` (its probe was the last to answer ">=")
-  while (n > 0) {
-    const int half = n >> 1;
-    const uint32_t e = idx[lo + half];
-    ++probes;
-    if (e < target) {
-      lo += half + 1;
-      n -= half + 1;
-    } else {
-      n = half;
-      cand = e;
-    }
-  }
-  while (lo < deg && (cand >> kIdxOffBits) == il) {
-    const uint32_t aidx = static_cast<uint32_t>(abeg) + (cand & kOffMask);
+  return LabelIndexLowerBound([&](int j) {
+    const IdxNodeVec m = *reinterpret_cast<const KD_G IdxNodeMem *>(idx + 4 * j);
+    return IdxNode{{m.x, m.y, m.z, m.w}};
+  }, deg, from_key, probes);
+}
+// ... and, from it, the arcs of that label.
+template <class Visit>
+__device__ __forceinline__ void IndexedArcsFrom(CParams &p, int abeg, int deg, uint32_t il, uint32_t cand,
+                                                int &probes, int &fetched, Visit visit) {
+  while (cand != kIdxNone && IdxKeyLabel(cand) == il) {
+    const uint32_t aidx = static_cast<uint32_t>(abeg) + IdxKeyOffset(cand);
     const ArcRec ar = LoadArcRec(p.arcs, aidx);
-    ++lo;
-    // (the next entry is requested with the arc: a state may hold several arcs of one label)
-    cand = idx[lo < deg ? lo : deg - 1];
-    ++probes;
+    // (the key says whether another arc of this label follows: looked for with the fetch in flight)
+    cand = IdxKeyMore(cand) ? IndexFind(p, abeg, deg, cand + 1, probes) : kIdxNone;
     ++fetched;
     visit(aidx, ar);
   }
+}
+template <class Visit>
+__device__ __forceinline__ void IndexedArcs(CParams &p, int abeg, int deg, uint32_t il, int &probes,
+                                            int &fetched, Visit visit) {
+  IndexedArcsFrom(p, abeg, deg, il, IndexFind(p, abeg, deg, IdxKey(il, 0), probes), probes, fetched, visit);
 }
 
 // Folds the lanes' running minima into s.min_new.  Call where the wave is converged.
@@ -1460,7 +1456,7 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
         else { cnt.tokens_expanded += 1; cnt.arcs_scanned += deg; }
         bool indexed = false;
         if constexpr (!EPS && M != 2 && KD_LABEL_INDEX != 0) {
-          if (idx_on && deg > kSmallDeg && deg < (1 << kIdxOffBits)) {
+          if (idx_on && deg > kSmallDeg && deg < kIdxMaxDeg) {
             unsigned long long seen = s.min_new;
             seen = c.run_min < seen ? c.run_min : seen;
             bool others_out, best_in;
@@ -2562,6 +2558,15 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // at the cutoff hide the frame's minimum)
   const bool idx_frame = KD_LABEL_INDEX != 0 && M != 2 && n_in >= kIdxMinFront && c.ll_in_lds &&
                          c.adaptive_beam >= 0.0f;
+  // (this frame's lowest and second-lowest acoustic costs, the likeliest label; what each of this
+  // lane's tokens found in its state's label index)
+  constexpr int kIdxSlots = (kT1Front + kBlock - 1) / kBlock;
+  float idx_m0 = 0.0f, idx_m1 = 0.0f;
+  int idx_l0 = 0;
+  uint32_t idx_found[kIdxSlots];
+#pragma unroll
+  for (int j = 0; j < kIdxSlots; ++j) idx_found[j] = kIdxNone;
+  if (idx_frame) LoadRowTop(s, idx_m0, idx_m1, idx_l0);
 
   // ---- emitting filter over the LDS frontier (faster-decoder.cc:195-236)
   // The frontier's best token goes first (faster-decoder.cc:176-189 does the same to
@@ -2585,7 +2590,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       }
     }
     const unsigned long long first =
-        __ballot(ok && deg > kSmallDeg && deg <= 64 && CK<M>(cst) == best_key);
+        __ballot(n_in >= kLeadMinFront && ok && deg > kSmallDeg && deg <= 64 && CK<M>(cst) == best_key);
     const int leader = first ? __builtin_ctzll(first) : -1;
     if (leader >= 0) {
       // (the leader is wave-uniform: v_readlane, not a shuffle through LDS)
@@ -2609,6 +2614,21 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       if (deg <= kSmallDeg) lane_arcs(EpsNo{}, abeg, deg, cst, static_cast<uint32_t>(i));
       else if (!idx_frame) push_items(EpsNo{}, i, abeg, deg, cst, static_cast<uint32_t>(i));
     }
+    // Label index, first half: where this token's arcs of the row's likeliest label are.  The
+    // descent does not depend on the cutoff -- only the decision below does -- so its three
+    // dependent loads run here, next to the other tokens' arc fetches and the best token's row,
+    // instead of behind the barrier that publishes the bound.
+    if (idx_frame && i0 / nt < kIdxSlots) {
+      int probes = 0;
+      uint32_t found = kIdxNone;
+      if (ok && lane != leader && deg > kSmallDeg && deg < kIdxMaxDeg)
+        found = IndexFind(p, abeg, deg, IdxKey(static_cast<uint32_t>(idx_l0 + 1), 0), probes);
+      // (a register array: written and read through constant indices only)
+#pragma unroll
+      for (int k = 0; k < kIdxSlots; ++k)
+        if (k == i0 / nt) idx_found[k] = found;
+      cnt.idx_probes += probes;
+    }
   }
   PublishMin(c);
   tm.Sync(false);
@@ -2627,9 +2647,8 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     // cutoff -- through the label index, and scores them as ever.  Tokens with more room take
     // the work-item rows as before.  Which arcs are queued changes (fewer doomed ones); which
     // are below the final cutoff, and the minimum that defines it, do not.
-    float t_m0, t_m1;
-    int t_l0;
-    LoadRowTop(s, t_m0, t_m1, t_l0);
+    const float t_m0 = idx_m0, t_m1 = idx_m1;
+    const int t_l0 = idx_l0;
     const float w_min = p.emit_w_min;
     for (int i0 = 0; i0 < n_in; i0 += nt) {
       const int i = i0 + tid;
@@ -2646,7 +2665,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       }
       // (the same leader as in the pass above: its row is done)
       const unsigned long long first =
-          __ballot(ok && deg > kSmallDeg && deg <= 64 && CK<M>(cst) == best_key);
+          __ballot(n_in >= kLeadMinFront && ok && deg > kSmallDeg && deg <= 64 && CK<M>(cst) == best_key);
       const int leader = first ? __builtin_ctzll(first) : -1;
       if (ok && deg > kSmallDeg && lane != leader) {
         unsigned long long seen = s.min_new;
@@ -2661,13 +2680,17 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
           others_out = (static_cast<double>(w_min) + cst) + static_cast<double>(t_m1) >= lim;
           best_in = (static_cast<double>(w_min) + cst) + static_cast<double>(t_m0) < lim;
         }
-        if (others_out && deg < (1 << kIdxOffBits)) {
+        if (others_out && deg < kIdxMaxDeg) {
           int probes = 0, fetched = 0;
+          uint32_t found = kIdxNone;
+#pragma unroll
+          for (int k = 0; k < kIdxSlots; ++k)
+            if (k == i0 / nt) found = idx_found[k];
           if (best_in)
-            IndexedArcs(p, abeg, deg, static_cast<uint32_t>(t_l0 + 1), probes, fetched,
-                        [&](uint32_t aidx, const ArcRec &ar) {
-                          FilterArc<false, true>(c, ar, aidx, cst, static_cast<uint32_t>(i));
-                        });
+            IndexedArcsFrom(p, abeg, deg, static_cast<uint32_t>(t_l0 + 1), found, probes, fetched,
+                            [&](uint32_t aidx, const ArcRec &ar) {
+                              FilterArc<false, true>(c, ar, aidx, cst, static_cast<uint32_t>(i));
+                            });
           cnt.arcs_skipped += deg - fetched;
           cnt.idx_probes += probes;
         } else {
@@ -2695,6 +2718,16 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   item_loop(EpsNo{});
   queue_sync();
   KD_LAP(s, 4);
+  // (the epsilon rounds' work-item lists start empty: reset here, published by the insert's barrier)
+  if (tid == 0) {
+    s.it_count[0] = 0;
+    s.it_next[0] = 0;
+    s.it_count[1] = 0;
+    s.it_n32 = 0;
+    s.it_n16 = 0;
+    s.it_next32 = 0;
+    s.it_next16 = 0;
+  }
   // the emitting filter is done with this frame's log-likelihood row: the next
   // frame's row (fetched into registers when this frame began) takes its place
   if (have_next && nt == kBlock) {
@@ -2776,11 +2809,14 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   if (Uni(s.overflow)) return kRetry;
 
   // ---- ProcessNonemitting to a fixpoint (:59-119)
-  int cur = 0, q_begin = q_emit;
-  while (Uni(s.wl_count[cur]) != 0) {
-    for (int w = tid; w < kMaskWords; w += nt) wlmask[(cur ^ 1) * kMaskWords + w] = 0;
+  // A round is scan -> barrier -> (work items, if any were pushed) -> insert -> barrier.  The
+  // other mask is cleared at the top without a barrier of its own (its last readers were the
+  // scan of the round before, two barriers ago; its next writers are this round's inserts,
+  // behind the scan's barrier), and the work-item counters are reset by one lane between a
+  // round's work items and its inserts (reset_items): until round 5 a round began with both and a
+  // barrier, and ran the work-item pass with its barrier whether or not there were items.
+  auto reset_items = [&]() {
     if (tid == 0) {
-      s.wl_count[cur ^ 1] = 0;
       s.it_count[0] = 0;
       s.it_next[0] = 0;
       s.it_count[1] = 0;
@@ -2789,17 +2825,16 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       s.it_next32 = 0;
       s.it_next16 = 0;
     }
-    tm.Sync(false);
-    KD_LAP(s, 6);
+  };
+  int cur = 0, q_begin = q_emit;
+  while (Uni(s.wl_count[cur]) != 0) {
+    for (int w = tid; w < kMaskWords; w += nt) wlmask[(cur ^ 1) * kMaskWords + w] = 0;
     // The team's threads scan the worklist mask, 8 slots each (a lane rarely finds
     // more than one token).  Tokens are taken two at a time: both state records are
     // requested before either is used, and so are the arcs of low-degree tokens.
-    // (a one-wave team takes whole words: two per lane instead of eight bytes)
-    const int gshift = nt == 64 ? 5 : 3;
-    for (int w8 = tid; w8 < (kT1Slots >> gshift); w8 += nt) {
-      const uint32_t mword = wlmask[cur * kMaskWords + ((w8 << gshift) >> 5)];
-      uint32_t m = gshift == 5 ? mword : (mword >> ((w8 & 3) * 8)) & 0xFFu;
-      const int hbase = w8 << gshift;
+    for (int w8 = tid; w8 < kT1Slots / 8; w8 += nt) {
+      uint32_t m = (wlmask[cur * kMaskWords + (w8 >> 2)] >> ((w8 & 3) * 8)) & 0xFFu;
+      const int hbase = w8 * 8;
       while (m) {
         uint32_t h[2];
         h[0] = static_cast<uint32_t>(hbase + __builtin_ctz(m));
@@ -2885,8 +2920,16 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     }
     tm.Sync(false);
     KD_LAP(s, 7);
-    item_loop(EpsYes{});
-    queue_sync();
+    if (Uni(s.it_count[0] | s.it_n32 | s.it_n16) != 0) {
+      item_loop(EpsYes{});
+      queue_sync();
+      reset_items();
+    } else if (Uni(s.q_n) > kQL) {
+      tm.Sync(true);  // (queue entries past the LDS part: their stores have landed)
+    }
+    // (every wave has tested wl_count[cur] at the top of this round; the next round's inserts,
+    // two barriers from here, raise it again)
+    if (tid == 0) s.wl_count[cur] = 0;
     KD_LAP(s, 8);
     const int q_end = Uni(s.q_n);
     if (q_end > c.q_cap) return kRetry;
@@ -2930,7 +2973,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // The new frontier's state records (at most kNextRecs tokens per lane when the next
   // frame is a tier-1 frame): requested here, used when the frame ends -- the gather
   // overlaps the passes in between.
-  constexpr int kNextRecs = (kT1Front + kBlock - 1) / kBlock;  // (a one-wave team: see the end of the frame)
+  constexpr int kNextRecs = (kT1Front + kBlock - 1) / kBlock;  // (a four-wave team: see the end of the frame)
   ArcRange next_rec[kNextRecs];
   bool next_on[kNextRecs];
   {
@@ -2978,7 +3021,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
           s.it_abeg[i] = static_cast<int32_t>(static_cast<uint32_t>(ck));
           s.it_deg[i] = static_cast<int32_t>(emit);
         } else {
-          s.it_deg[i] = -1;  // (looked up: next_rec, or the one-wave team's pass at the end)
+          s.it_deg[i] = -1;  // (looked up: next_rec, or the four-wave team's pass at the end)
         }
       }
     }
@@ -3077,7 +3120,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     }
   }
   if (nt != kBlock && next_small) {
-    // a one-wave team's frontier of more than kNextRecs tokens per lane (rare: such a frame
+    // a four-wave team's frontier of more than kNextRecs tokens per lane (rare: such a frame
     // starts from a handful of tokens): the rest of the records, fetched here
     for (int i = tid + kNextRecs * nt; i < n_out; i += nt) {
       if (M != 1 || s.it_deg[i] < 0) {
@@ -3385,7 +3428,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   if (tid < KD_NUM_STATS) s.stat[tid] = 0;
   if (tid < 4) s.frame_cnt[tid] = 0;
   if (tid == 0) {
-    s.soft_bar = 0;
+    s.bar_final = 0;
     s.ud_ll = reinterpret_cast<unsigned long long>(ud.ll);
     s.ud_offset = ud.offset;
   }
@@ -3506,19 +3549,29 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       // a small frame of few tokens is run by the first four waves alone
       const Team tm{kT1Narrow > 0 && c.n_in <= kT1Narrow ? kNarrowLanes : kBlock, gen};
       const bool have_next = c.ll_in_lds && frame + 1 < target;
+      gen = 0;
       if (tid < tm.nt) {
         const KD_G float *ll_next = row_of(have_next ? frame + 1 : frame);
         c.ll_row = row_of(frame);
+        // (a team: the number of its last barrier is not known yet -- written before its first
+        // barrier, read by the quiet waves behind it)
+        if (tm.nt != kBlock && tid == 0) s.bar_final = 0;
         if (!front_lds) LoadFront(c, tm);
         // (two copies of the frame on purpose: in each the compiler knows where the
         // log-likelihood row is, and the copy for rows held in LDS loses the branch --
         // and the wait for outstanding vector-memory operations -- per arc)
         if (c.ll_in_lds) r = SmallFrame(c, t1, frame, cnt, tm, ll_next, have_next);
         else r = SmallFrame(c, t1, frame, cnt, tm, ll_next, have_next);
-        if (tid == 0) s.ctl[frame & 1].r = r;
+        if (tid == 0) {
+          s.ctl[frame & 1].r = r;
+          s.bar_final = gen + 1;  // (the barrier below)
+        }
         LdsBarrier();  // the whole workgroup again: nobody reads this frame's row any more
       } else {
-        // the idle waves hold the next frame's row in registers until the frame is over
+        // The quiet waves: they request the next frame's row, hold it in registers, and keep
+        // the team company at its barriers -- s_barrier counts every wave of the workgroup --
+        // until the barrier the team has announced as its last: three instructions a barrier
+        // instead of the frame's whole control path.
         float ll_next[kLlRegs];
         const KD_G float *row = row_of(have_next ? frame + 1 : frame);
         Top2 top = Top2Empty();
@@ -3529,7 +3582,11 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
           if (have_next && v < p.num_cols) Top2Add(top, ll_next[k], v);
         }
         top = WaveTop2(top);
-        LdsBarrier();
+        int n_bar = 0;
+        do {
+          LdsBarrier();
+          ++n_bar;
+        } while (Uni(__hip_atomic_load(&s.bar_final, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != n_bar);
         if (have_next) {
 #pragma unroll
           for (int k = 0; k < kLlRegs; ++k) {
@@ -3731,6 +3788,9 @@ __shared__ int kd_work_item;
 
 template <int M>
 // (HIP's second bound is waves per SIMD: the workgroups sharing a CU spread over four)
+#if KD_WG_PER_CU > 1
+__attribute__((amdgpu_waves_per_eu((KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4)))
+#endif
 __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) void SearchKernel(const SearchParams p_by_value) {
   Shared &s = Lds();
   (void)p_by_value;  // the only argument: it is the kernel-argument segment
