@@ -477,6 +477,11 @@ __device__ __forceinline__ float Uni(float v) { return __int_as_float(Uni(__floa
 // one wave (`lane0` is that wave's first thread), one word each -- not word after
 // word by a single thread while the workgroup waits at the frame barrier.
 constexpr int kFrameZeroWords = 20;
+// ... of which the work-item lists' counters and cursors: it_count[2], it_next[2], it_n32, it_n16,
+// it_next32, it_next16 -- one contiguous run too, reset between a pass over the lists and the next
+constexpr int kItemWords = 8;
+static_assert(offsetof(Shared, it_next16) - offsetof(Shared, it_count) == 4 * (kItemWords - 1),
+              "the work-item counters are one contiguous run");
 template <int M>
 __device__ __forceinline__ void ResetFrame(Shared &s, int lane0 = 0) {
   static_assert(offsetof(Shared, it_next16) - offsetof(Shared, f_nlt) == 4 * (kFrameZeroWords - 1),
@@ -1618,10 +1623,16 @@ __device__ __forceinline__ void Insert(const FrameCtx<M> &c, const Table<LDS> &t
 // byte-wise radix select on order-preserving keys (std::nth_element in
 // faster-decoder.cc:298-321; tmp_array_ is std::vector<float>, :278).
 // Rare (only when max_active / min_active bind).
+// Out of line (round 5): inlined, its two copies held 50 of the kernel's scratch reloads and
+// their registers in the frame loop of every decode, and it runs only when max_active /
+// min_active bind.  (The LDS block is reached through Lds(): a pointer argument would be flat.)
+constexpr int kSelectKthBarriers = 16;  // (four passes of four: a team's caller counts them)
 template <bool FRONT_LDS>
-__device__ __forceinline__ float SelectKth(Shared *sp, const double *tok_cost, long long base_in,
-                                        int n_in, int k, const Team &tm) {
-  Shared &s = *sp;
+__device__ __noinline__ float SelectKth(const double *tok_cost, long long base_in, int n_in, int k,
+                                        int team_threads) {
+  Shared &s = Lds();
+  int gen_here = 0;  // (the caller's count lives in a register: no address of it comes here)
+  const Team tm{team_threads, gen_here};
   const int tid = threadIdx.x, lane = tid & 63;
   uint32_t prefix = 0, pmask = 0;
   int kk = k;
@@ -1719,7 +1730,8 @@ __device__ __forceinline__ void GetCutoff(FrameCtx<M> &c, const Team &tm) {
   const int n_lt = Uni(s.f_nlt), n_le = Uni(s.f_nle);
   // tmp_array_[k] < x  <=>  #{v < x} >= k+1 ;  tmp_array_[k] > x  <=>  #{v <= x} <= k
   if (c.n_in > p.max_active && static_cast<long long>(n_lt) >= static_cast<long long>(p.max_active) + 1) {
-    const double max_active_cutoff = SelectKth<FRONT_LDS>(&s, p.tok_cost, c.base_in, c.n_in, p.max_active, tm);  // :297-309
+    const double max_active_cutoff = SelectKth<FRONT_LDS>(p.tok_cost, c.base_in, c.n_in, p.max_active, tm.nt);  // :297-309
+    tm.gen += kSelectKthBarriers;
     c.adaptive_beam = max_active_cutoff - best_cost + p.beam_delta;
     c.weight_cutoff = max_active_cutoff;
     return;
@@ -1729,7 +1741,10 @@ __device__ __forceinline__ void GetCutoff(FrameCtx<M> &c, const Team &tm) {
   double min_active_cutoff = beam_cutoff;  // "not looser" unless proven below
   if (c.n_in > p.min_active) {             // :311-323
     if (p.min_active == 0) min_active_cutoff = best_cost;
-    else if (n_le <= p.min_active) min_active_cutoff = SelectKth<FRONT_LDS>(&s, p.tok_cost, c.base_in, c.n_in, p.min_active, tm);
+    else if (n_le <= p.min_active) {
+      min_active_cutoff = SelectKth<FRONT_LDS>(p.tok_cost, c.base_in, c.n_in, p.min_active, tm.nt);
+      tm.gen += kSelectKthBarriers;
+    }
   } else {
     min_active_cutoff = __longlong_as_double(0x7FF0000000000000ll);
   }
@@ -2719,15 +2734,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   queue_sync();
   KD_LAP(s, 4);
   // (the epsilon rounds' work-item lists start empty: reset here, published by the insert's barrier)
-  if (tid == 0) {
-    s.it_count[0] = 0;
-    s.it_next[0] = 0;
-    s.it_count[1] = 0;
-    s.it_n32 = 0;
-    s.it_n16 = 0;
-    s.it_next32 = 0;
-    s.it_next16 = 0;
-  }
+  if (tid < kItemWords) (&s.it_count[0])[tid] = 0;
   // the emitting filter is done with this frame's log-likelihood row: the next
   // frame's row (fetched into registers when this frame began) takes its place
   if (have_next && nt == kBlock) {
@@ -2816,15 +2823,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // round's work items and its inserts (reset_items): until round 5 a round began with both and a
   // barrier, and ran the work-item pass with its barrier whether or not there were items.
   auto reset_items = [&]() {
-    if (tid == 0) {
-      s.it_count[0] = 0;
-      s.it_next[0] = 0;
-      s.it_count[1] = 0;
-      s.it_n32 = 0;
-      s.it_n16 = 0;
-      s.it_next32 = 0;
-      s.it_next16 = 0;
-    }
+    if (tid < kItemWords) (&s.it_count[0])[tid] = 0;
   };
   int cur = 0, q_begin = q_emit;
   while (Uni(s.wl_count[cur]) != 0) {
@@ -3488,7 +3487,10 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   ResetFrame<M>(s);
   if (err == 0) row_to_lds(frame);
   __syncthreads();
-  Counters tot;  // per-lane work counters of the small frames, folded when the launch ends
+  auto fold = [&](int stat, int v) {  // a per-lane count of this frame into the launch's totals
+    const int w = WaveSumInt(v);
+    if ((tid & 63) == 0 && w) atomicAdd(&s.ustat[stat], static_cast<unsigned long long>(w));
+  };
   int visited = do_init ? -1 : Uni(ToG(p.mem)[utt].visited);
 
   [[maybe_unused]] int prev_q_emit = 0;  // candidates the previous frame's emitting filter queued
@@ -3623,12 +3625,14 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
         c.n_in = Uni(s.ctl[frame & 1].n_in);
         if constexpr (kT1SoftQueue > 0) prev_q_emit = Uni(s.ctl[frame & 1].q_emit);
         front_lds = c.n_in <= kT1Front;
-        tot.tokens_expanded += cnt.tokens_expanded;
-        tot.eps_exp += cnt.eps_exp;
-        tot.arcs_scanned += cnt.arcs_scanned;
-        tot.eps_arcs += cnt.eps_arcs;
-        tot.arcs_skipped += cnt.arcs_skipped;
-        tot.idx_probes += cnt.idx_probes;
+        // (the frame's per-lane work counters go to the launch totals here: six wave sums a
+        // frame, instead of six more registers per lane held across the whole frame loop)
+        fold(KD_STAT_TOKENS_EXPANDED, cnt.tokens_expanded);
+        fold(KD_STAT_EPS_EXPANSIONS, cnt.eps_exp);
+        fold(KD_STAT_ARCS_SCANNED, cnt.arcs_scanned);
+        fold(KD_STAT_EPS_ARCS_SCANNED, cnt.eps_arcs);
+        fold(KD_STAT_ARCS_SKIPPED, cnt.arcs_skipped);
+        fold(KD_STAT_INDEX_PROBES, cnt.idx_probes);
       } else if (r == kRedo) {
         // the queue overflowed: all of the frame again in the big path, which
         // needs this frame's row back (its place was taken by the next frame's)
@@ -3663,8 +3667,8 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
         filtered = true;
         cnt.eps_exp = 0;
         cnt.eps_arcs = 0;
-        tot.arcs_skipped += cnt.arcs_skipped;  // (the emitting filter is not run again)
-        tot.idx_probes += cnt.idx_probes;
+        fold(KD_STAT_ARCS_SKIPPED, cnt.arcs_skipped);  // (the emitting filter is not run again)
+        fold(KD_STAT_INDEX_PROBES, cnt.idx_probes);
       }
     }
     if (r == kRetry) {
@@ -3701,23 +3705,6 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     frame++;
   }
 
-  __syncthreads();
-  // fold the small frames' per-lane work counters into the launch totals
-  {
-    const int w0 = WaveSumInt(tot.tokens_expanded), w1 = WaveSumInt(tot.eps_exp),
-              w2 = WaveSumInt(tot.arcs_scanned), w3 = WaveSumInt(tot.eps_arcs);
-    if ((tid & 63) == 0) {
-      atomicAdd(&s.ustat[KD_STAT_TOKENS_EXPANDED], static_cast<unsigned long long>(w0));
-      atomicAdd(&s.ustat[KD_STAT_EPS_EXPANSIONS], static_cast<unsigned long long>(w1));
-      atomicAdd(&s.ustat[KD_STAT_ARCS_SCANNED], static_cast<unsigned long long>(w2));
-      atomicAdd(&s.ustat[KD_STAT_EPS_ARCS_SCANNED], static_cast<unsigned long long>(w3));
-    }
-    const int w4 = WaveSumInt(tot.arcs_skipped), w5 = WaveSumInt(tot.idx_probes);
-    if ((tid & 63) == 0) {
-      atomicAdd(&s.ustat[KD_STAT_ARCS_SKIPPED], static_cast<unsigned long long>(w4));
-      atomicAdd(&s.ustat[KD_STAT_INDEX_PROBES], static_cast<unsigned long long>(w5));
-    }
-  }
   __syncthreads();
   const int frames_done = frame < 0 ? -1 : frame;
   if (tid == 0) {
