@@ -342,7 +342,9 @@ int kd_batch_set_output_buffer(kd_batch *b, void *device_words, int64_t cap_word
  * whichever export ran: the one fused into a decode writes both copies; an export that the
  * host has to put in order first (an un-finalized lattice, kd_batch_raw_lattice_prepare apart
  * from the decode, a lattice that outgrew the staging lists) is ordered in the pinned pool
- * and copied into the buffer by this call. */
+ * and copied into the buffer by this call -- once per export, on the batch's stream, which the
+ * call waits for: work of the caller's that still READS the lent buffer (the previous call's
+ * gather payload, say) must have completed before this call is made. */
 int kd_batch_raw_lattice_table(kd_batch *b, int64_t *used_words, int64_t *table /* [batch][5] */);
 
 

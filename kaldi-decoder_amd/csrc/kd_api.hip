@@ -90,6 +90,7 @@ struct kd_batch {
   uint64_t out_ext_cap = 0;
   std::vector<uint8_t> h_lat_arena;  // the export of utterance i is in arena order (general export)
   bool canon_done = true;
+  bool mirrored = true;    // arena-order exports have been copied into the lent buffer (out_ext)
   // ---- per utterance
   DevBuf<long long> frame_base, link_emit_base, link_eps_base;
   DevBuf<int32_t> frame_count, link_emit_count, link_eps_count, frame_state_off, frame_arc_off;
@@ -566,6 +567,7 @@ int ReadBack(kd_batch *b) {
           b->h_lat_arena[i] = (uo[i].phase & kPhaseArenaOrder) && uo[i].out_off >= 0;
         }
         b->canon_done = false;
+        b->mirrored = false;
         b->exported_use_final = (b->l_tail_flags & kUttExport) ? 1 : 0;
       }
     }
@@ -1108,7 +1110,16 @@ static int StageHost(kd_batch *b, const float *const *loglikes, int32_t num_cols
   // hipHostRegister, torch pin_memory) it is truly asynchronous, and a caller that refills its
   // buffer for the next call would overwrite rows still on their way.  Wait for the last copy
   // -- not for the launch, which is enqueued behind it.
-  if (total > 0) {
+  // (only then -- a call fed pageable matrices returns as soon as HIP's own
+  // staging lets it, as before round 4.)
+  bool pinned = false;
+  for (int i = 0; i < b->batch && !pinned; ++i) {
+    if (!count[i]) continue;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, loglikes[i]) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();  // (plain malloc'ed memory: "invalid value", not an error of ours)
+  }
+  if (total > 0 && pinned) {
     KD_HIP_TRY(hipEventRecord(b->ev_staged, b->stream));
     KD_HIP_TRY(hipEventSynchronize(b->ev_staged));
   }
@@ -1455,6 +1466,7 @@ int kd_batch_set_output_buffer(kd_batch *b, void *device_words, int64_t cap_word
   b->out_ext = static_cast<unsigned long long *>(device_words);
   b->out_ext_cap = device_words ? static_cast<uint64_t>(cap_words) : 0;
   b->exported_use_final = -1;  // (what was exported is not in the new buffer)
+  b->mirrored = false;
   return KD_OK;
 }
 
@@ -1471,7 +1483,9 @@ int kd_batch_raw_lattice_table(kd_batch *b, int64_t *used_words, int64_t *table)
   // host: mirror those utterances' ordered regions into the lent buffer, so that buffer prefix +
   // table are complete whichever export ran.  (Rare; the staged export of a decode call writes
   // both copies itself.)
-  if (b->out_ext) {
+  // Once per export, on the batch's stream, waited for here: the lent buffer must not be read by
+  // work of the caller's that is still in flight when this call is made (include/kd_hip.h).
+  if (b->out_ext && !b->mirrored) {
     bool any = false;
     for (int i = 0; i < b->batch; ++i) any |= b->h_lat_arena[i] && b->h_lat_off[i] >= 0;
     if (any) {
@@ -1480,10 +1494,12 @@ int kd_batch_raw_lattice_table(kd_batch *b, int64_t *used_words, int64_t *table)
         if (!b->h_lat_arena[i] || b->h_lat_off[i] < 0) continue;
         const int32_t *sz = &b->h_lat_sizes[4 * i];
         const size_t words = static_cast<size_t>(sz[0]) + sz[2] + 3 * static_cast<size_t>(sz[1]);
-        KD_HIP_TRY(hipMemcpy(b->out_ext + b->h_lat_off[i], b->out_pool + b->h_lat_off[i], words * 8,
-                             hipMemcpyHostToDevice));
+        KD_HIP_TRY(hipMemcpyAsync(b->out_ext + b->h_lat_off[i], b->out_pool + b->h_lat_off[i], words * 8,
+                                  hipMemcpyHostToDevice, b->stream));
       }
+      KD_HIP_TRY(hipStreamSynchronize(b->stream));
     }
+    b->mirrored = true;
   }
   *used_words = static_cast<int64_t>(b->h_out_top);
   for (int i = 0; i < b->batch; ++i) {

@@ -14,15 +14,20 @@
 //     upwards from the zeros new tokens are created with (lattice-simple-decoder.cc:246-304)
 //     and leaves the cycle's tokens at extra cost 0 whatever their exits cost, the sweep here
 //     relaxes downwards from +infinity and finds the true distance -- another lattice.
-// Rule: inside a strongly connected component of the epsilon subgraph (an epsilon cycle), a
-// negative arc is refused (conservative: its cycle might still be positive), and so is a cycle
-// made of zero-weight arcs only.  HLG / HL / H graphs as icefall builds them have no epsilon
+// Rule (round 5): every epsilon cycle must have a POSITIVE total weight.  Negative arcs inside a
+// positive cycle are fine (weight-pushed and LM-scaled graphs carry them): per strongly
+// connected component of the epsilon subgraph the minimum cycle MEAN is computed (Karp, in
+// double; components are a handful of states) and the graph is refused only if it is <= 0 --
+// a cycle of total weight zero or less exists -- or not a number (a NaN weight on a cycle: the
+// closure's strict-improvement argument says nothing about it).  Until round 5 any negative arc
+// inside a component was refused.  HLG / HL / H graphs as icefall builds them have no epsilon
 // cycles at all (the common case costs one in-degree peel over the epsilon arcs).
 #ifndef KD_GRAPH_CHECK_H_
 #define KD_GRAPH_CHECK_H_
 
 #include <stdint.h>
 
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -107,58 +112,96 @@ inline bool EpsilonCyclesArePositive(int32_t num_states, const int32_t *row_ptr,
       }
     }
   }
-  // 3. inside a component that holds a cycle: no negative arc, no cycle of zero-weight arcs
-  std::vector<int32_t> zdeg(num_states, 0);
-  bool any_zero = false;
-  for (int32_t s = 0; s < num_states; ++s) {
-    if (comp[s] < 0) continue;
-    for (int32_t a = row_ptr[s]; a < row_ptr[s + 1]; ++a) {
-      if (ilabel[a] != 0) continue;
-      const int32_t d = nextstate[a];
-      if (comp[d] != comp[s]) continue;
-      if (comp_size[comp[s]] == 1 && d != s) continue;
-      // (an arc inside a non-trivial component, or a self-loop: it lies on an epsilon cycle)
-      if (weight[a] < 0.0f) {
-        *why = "graph has an epsilon cycle through state " + std::to_string(s) +
-               " with a negative-weight arc on it: the reference's ProcessNonemitting does not "
-               "terminate on a negative epsilon cycle, and positive ones with negative arcs are "
-               "not supported";
-        return false;
-      }
-      if (weight[a] == 0.0f) {
-        ++zdeg[d];
-        any_zero = true;
+  // 3. per component that holds a cycle: its minimum cycle mean must be positive
+  std::vector<std::vector<int32_t>> members(n_comp);
+  for (int32_t s = 0; s < num_states; ++s)
+    if (comp[s] >= 0) members[comp[s]].push_back(s);
+  std::vector<int32_t> local(num_states, -1);
+  for (int32_t c = 0; c < n_comp; ++c) {
+    const std::vector<int32_t> &ms = members[c];
+    const int32_t n = static_cast<int32_t>(ms.size());
+    struct Edge { int32_t u, v; double w; };
+    std::vector<Edge> edges;
+    for (int32_t i = 0; i < n; ++i) local[ms[i]] = i;
+    bool nan = false;
+    for (int32_t i = 0; i < n; ++i) {
+      const int32_t s = ms[i];
+      for (int32_t a = row_ptr[s]; a < row_ptr[s + 1]; ++a) {
+        if (ilabel[a] != 0 || comp[nextstate[a]] != c) continue;
+        if (weight[a] != weight[a]) nan = true;
+        edges.push_back({i, local[nextstate[a]], static_cast<double>(weight[a])});
       }
     }
-  }
-  if (!any_zero) return true;
-  // a cycle among the zero-weight arcs that stay inside a component: peel again
-  std::vector<int32_t> todo;
-  int64_t in_comp = 0, peeled = 0;
-  for (int32_t s = 0; s < num_states; ++s) {
-    if (comp[s] < 0) continue;
-    ++in_comp;
-    if (zdeg[s] == 0) todo.push_back(s);
-  }
-  while (!todo.empty()) {
-    const int32_t s = todo.back();
-    todo.pop_back();
-    ++peeled;
-    for (int32_t a = row_ptr[s]; a < row_ptr[s + 1]; ++a) {
-      if (ilabel[a] != 0 || weight[a] != 0.0f) continue;
-      const int32_t d = nextstate[a];
-      if (comp[d] != comp[s] || (comp_size[comp[s]] == 1 && d != s)) continue;
-      if (--zdeg[d] == 0) todo.push_back(d);
+    if (n == 1 && edges.empty()) continue;  // (a single state without a self-loop: no cycle)
+    if (nan) {
+      *why = "graph has an epsilon cycle through state " + std::to_string(ms[0]) +
+             " with a NaN weight on it";
+      return false;
+    }
+    double mu;  // the component's minimum cycle mean
+    if (static_cast<int64_t>(n) * n > (int64_t{1} << 26)) {
+      // A component too large for Karp's table (thousands of states on one epsilon cycle
+      // structure): the conservative rule of rounds 4 -- a negative arc refuses, and so does a
+      // cycle made of zero-weight arcs only (peel the zero-weight arcs' in-degrees).
+      mu = 1.0;
+      std::vector<int32_t> zdeg(n, 0), todo;
+      for (const Edge &e : edges) {
+        if (e.w < 0.0) mu = -1.0;
+        if (e.w == 0.0) ++zdeg[e.v];
+      }
+      if (mu > 0.0) {
+        std::vector<std::vector<int32_t>> zout(n);
+        for (const Edge &e : edges)
+          if (e.w == 0.0) zout[e.u].push_back(e.v);
+        int32_t peeled = 0;
+        for (int32_t i = 0; i < n; ++i)
+          if (zdeg[i] == 0) todo.push_back(i);
+        while (!todo.empty()) {
+          const int32_t u = todo.back();
+          todo.pop_back();
+          ++peeled;
+          for (int32_t v : zout[u])
+            if (--zdeg[v] == 0) todo.push_back(v);
+        }
+        if (peeled != n) mu = 0.0;
+      }
+    } else {
+      // Karp: D[k][v] = the lightest walk of exactly k arcs from member 0 to v;
+      // mu = min over v of max over k < n of (D[n][v] - D[k][v]) / (n - k)
+      const double inf = std::numeric_limits<double>::infinity();
+      std::vector<double> D(static_cast<size_t>(n + 1) * n, inf);
+      D[0] = 0.0;
+      for (int32_t k = 1; k <= n; ++k)
+        for (const Edge &e : edges) {
+          const double via = D[static_cast<size_t>(k - 1) * n + e.u] + e.w;
+          double &d = D[static_cast<size_t>(k) * n + e.v];
+          if (via < d) d = via;
+        }
+      mu = inf;
+      for (int32_t v = 0; v < n; ++v) {
+        const double dn = D[static_cast<size_t>(n) * n + v];
+        if (dn == inf) continue;
+        double worst = -inf;
+        for (int32_t k = 0; k < n; ++k) {
+          const double dk = D[static_cast<size_t>(k) * n + v];
+          if (dk == inf) continue;
+          const double m = (dn - dk) / (n - k);
+          if (m > worst) worst = m;
+        }
+        if (worst < mu) mu = worst;
+      }
+    }
+    if (!(mu > 0.0)) {
+      *why = std::string("graph has an epsilon cycle of total weight ") + (mu < 0.0 ? "below zero" : "zero") +
+             " (through or into state " + std::to_string(ms[0]) + "): " +
+             (mu < 0.0 ? "the reference's ProcessNonemitting does not terminate on a negative epsilon cycle"
+                       : "its tokens' back-pointers and lattice extra costs are not uniquely defined without "
+                         "the reference's container order") +
+             "; give the cycle a positive weight or remove it (fstrmepsilon)";
+      return false;
     }
   }
-  if (peeled == in_comp) return true;
-  int32_t bad = -1;
-  for (int32_t s = 0; s < num_states && bad < 0; ++s)
-    if (comp[s] >= 0 && zdeg[s] > 0) bad = s;
-  *why = "graph has an epsilon cycle of total weight zero (through or into state " + std::to_string(bad) +
-         "): its tokens' back-pointers and lattice extra costs are not uniquely defined without the "
-         "reference's container order; give the cycle a positive weight or remove it (fstrmepsilon)";
-  return false;
+  return true;
 }
 
 }  // namespace kd

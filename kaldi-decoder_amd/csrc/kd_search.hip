@@ -154,12 +154,6 @@ constexpr int kGroup = KD_GROUP;  // queued tokens a wave scores at a time
 #define KD_BIG_GROUP KD_GROUP
 #endif
 constexpr int kBigGroup = KD_BIG_GROUP;  // ... in the big tiers' filter (BigLoop)
-#ifndef KD_T2_ILP
-#define KD_T2_ILP 0
-#endif
-#ifndef KD_BIG_LANE_BATCH
-#define KD_BIG_LANE_BATCH 1
-#endif
 // Tier 1 (frames whose frontier is at most one token per lane -- 97% of the frames
 // of an HLG decode): the lower half of the table arrays is a 4096-slot table, the
 // upper half holds the first kQL entries of the candidate queue, and the frontier
@@ -1424,7 +1418,7 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
       pf_cst2 = ToG(p.tok_cost)[i2];
     }
     // (SimpleDecoder's emitting arcs are scored in two passes: FilterArc, not the batch)
-    constexpr bool kBatchLane = KD_BIG_LANE_BATCH != 0 && (EPS || M != 2);
+    constexpr bool kBatchLane = EPS || M != 2;
     [[maybe_unused]] bool lane_on = false;
     [[maybe_unused]] int lane_abeg = 0, lane_deg = 0;
     [[maybe_unused]] double lane_cst = 0.0;
@@ -1985,7 +1979,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
   {
     // (kSpillIlp tokens per lane: their live-list entries -- global memory in both big tiers --
     // and then their table words are fetched together)
-    constexpr int U = KD_T2_ILP ? kSpillIlp : (LDS ? 1 : kSpillIlp);
+    constexpr int U = LDS ? 1 : kSpillIlp;
     for (int i0 = tid; i0 < n_out; i0 += U * kBlock) {
       uint32_t h[U], kw[U], aw[U];
       unsigned long long ckv[U];
@@ -2065,64 +2059,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
   if (c.lattice) {
     const long long lbase = s.link_next;  // (room was taken with the token block)
     const int n_emit = s.n_emit_links;
-    if constexpr (LDS && KD_T2_ILP && M == 1) {
-      // LDS-table tier: the queue is in global memory here too -- kSpillIlp entries per lane,
-      // their six queue words requested together (read one by one behind the tests below, an
-      // entry cost four dependent round trips), then their table words
-      constexpr int U = kSpillIlp;
-      for (int i0 = tid; i0 < n_q; i0 += U * kBlock) {
-        uint32_t h[U], sr[U], aidx[U], kd[U], ks[U];
-        float qa[U], qg[U], cdf[U], csf[U];
-        unsigned long long nk[U];
-        bool ok[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int i = i0 + u * kBlock, idx = i < n_q ? i : 0;
-          h[u] = c.q_h[idx];
-          sr[u] = c.q_src[idx];
-          aidx[u] = c.q_arc[idx];
-          qa[u] = c.q_ac[idx];
-          qg[u] = c.q_gr[idx];
-          nk[u] = c.q_nk[idx];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int i = i0 + u * kBlock;
-          ok[u] = i < n_q && h[u] != kKeyEmpty;
-          const uint32_t hd = ok[u] ? h[u] : 0u, hs = ok[u] && i >= q_emit ? sr[u] & ~kSrcEps : 0u;
-          kd[u] = s.key[hd];  // (the token's place in the block: C1)
-          ks[u] = s.key[hs];
-          // (the lattice decoders' key is the high word; asking for the 64-bit word and letting
-          // hipcc narrow the read trips a bug in its instruction selection: see the tier-1 pass)
-          cdf[u] = KeyFloat(reinterpret_cast<const uint32_t *>(&s.cost[hd])[1]);
-          csf[u] = KeyFloat(reinterpret_cast<const uint32_t *>(&s.cost[hs])[1]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (!ok[u]) continue;
-          const int i = i0 + u * kBlock;
-          long long at, src_tok;
-          float ac;
-          if (i < q_emit) {
-            src_tok = c.base_in + sr[u];
-            ac = qa[u];
-            at = lbase + AggInc(&s.n_emit_written);
-          } else {
-            // source cost at generation vs its final cost (its slot's cost word is intact)
-            if (qa[u] != csf[u]) continue;
-            src_tok = base_out + ks[u];
-            ac = 0.0f;
-            at = lbase + n_emit + AggInc(&s.n_eps_links);
-          }
-          ToG(p.link_src)[at] = static_cast<int32_t>(src_tok);
-          ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + kd[u]);
-          ToG(p.link_arc)[at] = static_cast<int32_t>(aidx[u]);
-          ToG(p.link_ac)[at] = ac;
-          ToG(p.link_graph)[at] = qg[u];
-          ToG(p.link_delta)[at] = KCf<M>(nk[u]) - cdf[u];
-        }
-      }
-    } else if constexpr (LDS) {
+    if constexpr (LDS) {
       for (int i = tid; i < n_q; i += kBlock) {
         const uint32_t h = c.q_h[i];
         if (h == kKeyEmpty) continue;

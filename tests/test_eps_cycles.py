@@ -114,7 +114,7 @@ def _expect_refused(g, what):
 def test_graphs_with_zero_or_negative_epsilon_cycles_are_refused_at_the_boundary():
     """kd_graph_create runs the check before it touches the GPU: this needs none."""
     _expect_refused(graph_z(0.0), "epsilon cycle of total weight zero")
-    _expect_refused(graph_z(-0.25), "negative-weight arc")
+    _expect_refused(graph_z(-0.25), "epsilon cycle of total weight below zero")
     # a zero-weight epsilon self-loop
     g = synth.graph_from_arcs(2, 0, [(0, 1, 1, 0, 0.0), (1, 1, 0, 0, 0.0)], {1: 0.0})
     _expect_refused(g, "epsilon cycle of total weight zero")
@@ -126,7 +126,9 @@ def test_graphs_with_zero_or_negative_epsilon_cycles_are_refused_at_the_boundary
     ok1 = synth.graph_from_arcs(3, 0, [(0, 1, 1, 0, 0.0), (1, 2, 0, 0, -1.0)], {2: 0.0})
     ok2 = graph_z(0.5)
     ok3 = synth.random_graph(300, 3.5, 10, 0.45, 7, eps_back=0.6)
-    for g in (ok1, ok2, ok3):
+    # ... and (round 5) a NEGATIVE arc on a cycle whose total weight stays positive
+    ok4 = graph_zn()
+    for g in (ok1, ok2, ok3, ok4):
         try:
             cabi.Graph(g)
         except RuntimeError as e:
@@ -134,7 +136,76 @@ def test_graphs_with_zero_or_negative_epsilon_cycles_are_refused_at_the_boundary
             assert cabi.device_count() == 0, e  # (only the missing GPU may stop it)
 
 
+def graph_zn():
+    """Graph Z with its cycle 1 -> 2 -> 1 weighing 1.0 - 0.5 = 0.5: a positive epsilon cycle
+    that holds a negative arc (what weight pushing leaves behind)."""
+    arcs = [(0, 1, 1, 0, 0.0), (0, 3, 2, 0, 0.0), (1, 2, 0, 0, 1.0), (2, 1, 0, 0, -0.5), (2, 4, 1, 0, 5.0),
+            (3, 4, 1, 0, 0.0)]
+    return synth.graph_from_arcs(5, 0, arcs, {4: 0.0})
+
+
+def _negative_arc_cycle_graph(seed):
+    """A random graph with positive epsilon cycles in which a share of the epsilon arcs that lie
+    on NO shortcut of a cycle are made negative, the cycle-closing arcs heavy enough that every
+    cycle stays positive: kd_graph_create's Karp check is the judge (a graph it refuses is drawn
+    again)."""
+    rng = np.random.default_rng(seed)
+    for attempt in range(50):
+        g = synth.random_graph(int(rng.integers(60, 600)), float(rng.uniform(3, 5)), 12, 0.45,
+                               int(rng.integers(0, 10**6)), eps_back=0.5, eps_back_min_weight=4.0)
+        w = g["weight"].copy()
+        eps = g["ilabel"] == 0
+        neg = eps & (w < 1.0) & (rng.random(len(w)) < 0.3)
+        w[neg] = -w[neg] * 0.25
+        g = dict(g, weight=w.astype(np.float32))
+        try:
+            cabi.Graph(g)
+            return g
+        except RuntimeError as e:
+            if "epsilon cycle" not in str(e):
+                raise
+    raise AssertionError("no acceptable graph drawn")
+
+
 # ---- GPU ---------------------------------------------------------------------------------
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(3))
+def test_gpu_positive_cycles_with_negative_arcs(oracle, seed):
+    """epsilon cycles of positive total weight that hold negative arcs decode like
+    the reference (strict improvement still ends the closure: a trip round the cycle costs more
+    than it saves): graph Z's variant and random graphs, search and lattice against the
+    canonical oracle, the 1-best against the reference-order decoder too."""
+    graphs = [graph_zn(), _negative_arc_cycle_graph(100 + seed)]
+    for g in graphs:
+        V = int(g["ilabel"].max())
+        G, OG = cabi.Graph(g), oracle.Graph(g)
+        lps = [synth.make_logprobs(20, V, 900 + 7 * seed + i, peak=2.0) for i in range(3)]
+        for pi in (2, 1 << 20):
+            lb = cabi.LatticeBatch(G, max_batch=3, beam=9.0, lattice_beam=4.0, min_active=0, prune_interval=pi)
+            lb.decode_host(lps)
+            lats, frc = lb.raw_lattices(), lb.final_relative_cost()
+            for i, lp in enumerate(lps):
+                can = oracle.CanonLatticeDecoder(OG, beam=9.0, lattice_beam=4.0)
+                can.decode(lp)
+                cl = can.get_raw_lattice()
+                assert lats[i].arc_set() == cl.arc_set() and lats[i].state_set() == cl.state_set(), (pi, i)
+                assert lats[i].final_set() == cl.final_set()
+                assert frc[i] == can.final_relative_cost() or (np.isinf(frc[i]) and np.isinf(can.final_relative_cost()))
+        bt = cabi.Batch(G, max_batch=3, beam=9.0, min_active=0)
+        bt.decode_host(lps)
+        paths = bt.best_paths()
+        for i, lp in enumerate(lps):
+            d = oracle.FasterDecoder(OG, beam=9.0, min_active=0, policy=1)
+            d.decode(lp)
+            p = d.get_best_path()
+            assert paths[i].ok == p.ok and paths[i].state.tolist() == p.state.tolist()
+            assert paths[i].graph_cost.tolist() == p.graph_cost.tolist()
+            r = oracle.FasterDecoder(OG, beam=9.0, min_active=0, policy=0)
+            r.decode(lp)
+            pr = r.get_best_path()
+            assert paths[i].isyms.tolist() == pr.isyms.tolist() and paths[i].osyms.tolist() == pr.osyms.tolist()
 
 
 @pytest.mark.gpu

@@ -1,12 +1,13 @@
 """kd_graph_create's epsilon-cycle check (csrc/kd_graph_check.h: in-degree peel, iterative
-Tarjan, a second peel over the zero-weight arcs) against a brute-force statement of the same
+Tarjan, Karp's minimum cycle mean per component) against a brute-force statement of the same
 rule on thousands of small random graphs -- compiled on its own with
 -fsanitize=address,undefined, so that an index slip in the iterative SCC code shows as a
 report, not as a wrong answer on some real graph later.
 
-The rule: an epsilon arc s -> d lies on an epsilon cycle iff d reaches s through epsilon arcs
-(or d == s).  Refused: a NEGATIVE arc on a cycle; a cycle made of ZERO-weight arcs only
-(a zero-weight arc s -> d such that d reaches s through zero-weight epsilon arcs, or d == s)."""
+The rule (round 5): refused iff some epsilon cycle has a total weight of ZERO OR LESS -- a
+negative arc on a cycle whose total stays positive is accepted (weight-pushed graphs carry
+them).  Brute force: (min, +) powers of the epsilon arcs' weight matrix; a closed walk of at
+most S arcs with total <= 0 exists iff a simple cycle with total <= 0 does."""
 import os
 import subprocess
 
@@ -16,31 +17,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _closure(adj):
-    r = adj.copy()
-    n = len(r)
-    for k in range(n):
-        r |= np.outer(r[:, k], r[k, :])
-    return r
-
-
 def _rule(S, src, dst, il, w):
     eps = il == 0
-    adj = np.zeros((S, S), bool)
-    adj[src[eps], dst[eps]] = True
-    reach = _closure(adj)
-    z = eps & (w == 0.0)
-    zadj = np.zeros((S, S), bool)
-    zadj[src[z], dst[z]] = True
-    zreach = _closure(zadj)
+    W = np.full((S, S), np.inf)
     for a in np.nonzero(eps)[0]:
-        s, d = src[a], dst[a]
-        on_cycle = d == s or reach[d, s]
-        if on_cycle and w[a] < 0:
+        W[src[a], dst[a]] = min(W[src[a], dst[a]], float(w[a]))
+    P = W.copy()
+    for _ in range(S):
+        if (np.diag(P) <= 0.0).any():
             return False
-        if w[a] == 0.0 and (d == s or zreach[d, s]):
-            return False
-    return True
+        P = (P[:, :, None] + W[None, :, :]).min(axis=1)
+    return not (np.diag(P) <= 0.0).any()
 
 
 @pytest.fixture(scope="module")
@@ -98,7 +85,28 @@ def test_epsilon_cycle_check_on_a_long_chain_and_a_big_cycle(driver):
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     out = r.stdout.decode().splitlines()
     assert out[0].startswith("1") and out[1].startswith("0") and "total weight zero" in out[1]
-    assert out[2].startswith("0") and "negative-weight arc" in out[2]
+    assert out[2].startswith("0") and "below zero" in out[2]
+
+
+def test_negative_arc_on_a_positive_cycle_is_accepted_and_nan_is_not(driver):
+    """a weight-pushed graph may carry a negative epsilon arc inside a cycle
+    whose total is positive -- accepted; the same cycle at total zero or below, or with a NaN
+    weight, is refused."""
+    def blob(ws):
+        S = 3
+        row_ptr = np.asarray([0, 1, 2, 3], np.int32)
+        il = np.zeros(3, np.int32)
+        dst = np.asarray([1, 2, 0], np.int32)
+        return (np.asarray([S, 3], np.int32).tobytes() + row_ptr.tobytes() + il.tobytes() + dst.tobytes() +
+                np.asarray(ws, np.float32).tobytes())
+    cases = [[1.0, -0.75, 0.5], [1.0, -1.5, 0.5], [1.0, -1.75, 0.5], [1.0, float("nan"), 0.5]]
+    r = subprocess.run([driver], input=b"".join(blob(c) for c in cases), capture_output=True, timeout=60)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = r.stdout.decode().splitlines()
+    assert out[0].startswith("1")
+    assert out[1].startswith("0") and "total weight zero" in out[1]
+    assert out[2].startswith("0") and "below zero" in out[2]
+    assert out[3].startswith("0") and "NaN" in out[3]
 
 
 def test_ilabels_beyond_twenty_bits_are_refused():
