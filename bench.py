@@ -267,6 +267,46 @@ def _cpu_worker(idx):
     return frames, t0, time.perf_counter()
 
 
+def synth_graph(wl):
+    from kaldi_decoder import synth
+    return synth.hlg_graph(**wl["graph"]) if wl["kind"] == "hlg" else synth.hl_graph(**wl["graph"])
+
+
+def shared_graph(wl, name, rank, world, job, timeout_s=3600.0):
+    """The workload's graph for this rank.  One rank: synthesised here.  Several: rank 0
+    synthesises it ONCE and hands it to the others through a file in /dev/shm -- this package's
+    own OpenFst `const` file, read back with Fst.read (the large-LM graph takes a minute to
+    synthesise on one core; eight ranks doing that at once on the cores a container grants would
+    be most of the job's run time) -- plus the lexicon the log-probs are drawn from.  The file is
+    written under another name and renamed (the readers poll for it); rank 0 removes it when
+    every rank has passed the first barrier (main())."""
+    if world <= 1:
+        return synth_graph(wl), None
+    import kaldi_decoder as kd
+    base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"kd_bench_{name}_{job}")
+    path, lex_path = base + ".fst", base + ".lex.npz"
+    if rank == 0:
+        g = synth_graph(wl)
+        kd.fst_from_dict(g).write(path + ".tmp", "const")
+        toks, lens = g["lexicon"]
+        np.savez(lex_path + ".tmp.npz", toks=toks, lens=lens)
+        os.replace(lex_path + ".tmp.npz", lex_path)
+        os.replace(path + ".tmp", path)  # (last: its presence says both files are complete)
+        return g, (path, lex_path)
+    t_end = time.time() + timeout_s
+    while not os.path.exists(path):
+        if time.time() > t_end:
+            raise SystemExit(f"rank {rank}: the graph file {path} never appeared")
+        time.sleep(0.2)
+    f = kd.Fst.read(path)
+    row_ptr, ilabel, olabel, weight, nextstate, final = f.arrays()
+    lex = np.load(lex_path)
+    g = {"num_states": int(f.num_states), "start": int(f.start), "row_ptr": row_ptr, "ilabel": ilabel,
+         "olabel": olabel, "weight": weight, "nextstate": nextstate, "final": final,
+         "lexicon": (lex["toks"], lex["lens"])}
+    return g, None
+
+
 def spawn_ranks(n):
     """`bench.py --gpus N` started plainly (no WORLD_SIZE in the environment): start the N
     ranks as a CHILD `python -m torch.distributed.run` of this same command line and exit with
@@ -336,7 +376,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     wl = WORKLOADS[args.workload]
     t0 = time.time()
-    g = synth.hlg_graph(**wl["graph"]) if wl["kind"] == "hlg" else synth.hl_graph(**wl["graph"])
+    g, shared_files = shared_graph(wl, args.workload, rank, int(os.environ.get("WORLD_SIZE", "1")),
+                                   os.environ.get("MASTER_PORT", str(os.getppid())))
     # The CPU leg's worker processes are forked HERE, before this process loads the HIP
     # runtime: they inherit the graph and the sample's log-probs and never touch the GPU.
     cpu_pool = None
@@ -469,6 +510,15 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if world > 1:
+        dist.barrier()  # (every rank has read the graph file)
+        if shared_files:
+            for f_ in shared_files:
+                try:
+                    os.remove(f_)
+                except OSError:
+                    pass
 
     # A run of K steps is ceil(K / G) calls (the last one may be short), kept n_fly deep in
     # flight by ONE host thread: the library's decode call only enqueues, so the thread

@@ -96,3 +96,27 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
     k = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[k + 1:] == ["--gpus", "8", "--steps", "16", "--warmup", "2"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_ranks_share_one_synthesis_of_the_graph_through_a_file(monkeypatch):
+    """`bench.py --gpus N`: rank 0 synthesises the workload's graph once and writes it as this
+    package's OpenFst const file (plus the lexicon); the other ranks read it back with Fst.read
+    -- the same arrays, bit for bit (SURVEY 8(f)-1 exercised on the way)."""
+    import numpy as np
+    wl = bench.WORKLOADS["small"]
+    g0, files = bench.shared_graph(wl, "small", 0, 2, "unittest%d" % os.getpid())
+    try:
+        assert files and all(os.path.exists(f) for f in files)
+        g1, none = bench.shared_graph(wl, "small", 1, 2, "unittest%d" % os.getpid(), timeout_s=5.0)
+        assert none is None
+        for k in ("row_ptr", "ilabel", "olabel", "weight", "nextstate", "final"):
+            assert np.array_equal(np.asarray(g0[k]), np.asarray(g1[k])), k
+        assert g0["num_states"] == g1["num_states"] and g0["start"] == g1["start"]
+        assert np.array_equal(g0["lexicon"][0], g1["lexicon"][0]) and np.array_equal(g0["lexicon"][1], g1["lexicon"][1])
+    finally:
+        for f in files or ():
+            if os.path.exists(f):
+                os.remove(f)
+    # one rank: no file at all
+    g, files = bench.shared_graph(wl, "small", 0, 1, "unused")
+    assert files is None and g["num_states"] == g0["num_states"]
