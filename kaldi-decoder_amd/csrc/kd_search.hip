@@ -2562,31 +2562,6 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       score_batch(EpsNo{}, std::integral_constant<int, 1>{}, ar1, aidx1, on1, cst1, src1);
       LaneMin(&s.min_new, c.run_min, c.run_min != kCostInf<M>);
     }
-    // A best token of MORE than 64 arcs (a history state of a large LM: hundreds) has no row to
-    // go first -- and without an early bound every token of the frame has "room" and falls back
-    // to its rows (the large-LM workload read 12 k arcs a frame that way).  Its arc of the row's
-    // likeliest label, found through the index, bounds the cutoff just as well: scored here for
-    // the BOUND only (nothing is queued: the token's arcs are scored in the second pass like any
-    // other's; the cost is a real candidate's, so the minimum it seeds is one the frame reaches).
-    if (idx_frame) {
-      const unsigned long long big =
-          __ballot(leader < 0 && ok && deg > 64 && deg < kIdxMaxDeg && CK<M>(cst) == best_key);
-      if (big) {
-        if (lane == __builtin_ctzll(big)) {
-          int probes = 0, fetched = 0;
-          IndexedArcs(p, abeg, deg, static_cast<uint32_t>(idx_l0 + 1), probes, fetched,
-                      [&](uint32_t, const ArcRec &ar) {
-                        double nc;
-                        float aux;
-                        ScoreArc<false>(c, ar, cst, kCostInf<M>, nc, aux);
-                        const unsigned long long nk = CK<M>(nc);
-                        if (nk < c.run_min) c.run_min = nk;
-                      });
-          cnt.idx_probes += probes;
-        }
-        LaneMin(&s.min_new, c.run_min, c.run_min != kCostInf<M>);
-      }
-    }
     if (ok && lane != leader) {
       if (deg <= kSmallDeg) lane_arcs(EpsNo{}, abeg, deg, cst, static_cast<uint32_t>(i));
       else if (!idx_frame) push_items(EpsNo{}, i, abeg, deg, cst, static_cast<uint32_t>(i));
@@ -2598,8 +2573,26 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     if (idx_frame && i0 / nt < kIdxSlots) {
       int probes = 0;
       uint32_t found = kIdxNone;
-      if (ok && lane != leader && deg > kSmallDeg && deg < kIdxMaxDeg)
+      if (ok && lane != leader && deg > kSmallDeg && deg < kIdxMaxDeg) {
         found = IndexFind(p, abeg, deg, IdxKey(static_cast<uint32_t>(idx_l0 + 1), 0), probes);
+        // ... and what that arc costs, for the BOUND only: nothing is queued here (the arc is
+        // fetched and scored again in the second pass, by the index or with the token's row), but
+        // its cost is a real candidate's, so it may lower the running minimum -- and the second
+        // pass then decides, and queues, under a cutoff that EVERY token's likeliest-label arc has
+        // tightened, not the best token's row alone.  (Without it a frame whose best token lacks
+        // such an arc, or has more than 64 arcs and so no row to go first -- a history state of a
+        // large LM -- let a quarter of its tokens fall back to reading all their arcs: bench
+        // 38.2 -> 40.0 M, hlg-large 7.4-7.7 -> 8.0 M; candidates queued per frame 894 -> 615.)
+        if (found != kIdxNone && IdxKeyLabel(found) == static_cast<uint32_t>(idx_l0 + 1)) {
+          const ArcRec ar = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg) + IdxKeyOffset(found));
+          double nc;
+          float aux;
+          ScoreArc<false>(c, ar, cst, kCostInf<M>, nc, aux);
+          const unsigned long long nk = CK<M>(nc);
+          if (nk < c.run_min) c.run_min = nk;
+          cnt.arcs_skipped -= 1;  // (an arc read: `arcs_skipped` is scanned minus read)
+        }
+      }
       // (a register array: written and read through constant indices only)
 #pragma unroll
       for (int k = 0; k < kIdxSlots; ++k)
