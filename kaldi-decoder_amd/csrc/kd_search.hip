@@ -141,6 +141,10 @@ constexpr int kPfRegs = (kVmax + KD_BLOCK - 1) / KD_BLOCK;
 #define KD_IDX_MIN_FRONT 192
 #endif
 constexpr int kIdxMinFront = KD_IDX_MIN_FRONT;
+#ifndef KD_TOP_MIN_QUEUE
+#define KD_TOP_MIN_QUEUE (2 * KD_IDX_MIN_FRONT / 3)
+#endif
+constexpr int kTopMinQueue = KD_TOP_MIN_QUEUE;  // (see the row swap of a tier-1 frame)
 // The best token's row is scored ahead of the others (a tight running cutoff early: half as many
 // candidates queued) in frames of at least this many tokens; a smaller frame queues the little
 // it has either way, and the row's round trip ahead of the work items is the dearer.
@@ -265,6 +269,7 @@ struct Shared {
   // still pass this token's cutoff?"
   float top_a0[kWaves], top_a1[kWaves];
   int32_t top_i0[kWaves];
+  int32_t top_valid;            // ... have been noted for the row in `ll` (0: the frame does without the index)
   int32_t bar_final;            // a team's frame: the number of its last barrier (0: not known yet)
   int32_t alloc_ok;             // result of the last chunk allocation (0 ok, else a KD_UTT_* bit)
   // what a tier-1 frame leaves for the waves that sat it out, by frame parity:
@@ -1384,7 +1389,7 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
   [[maybe_unused]] int t_l0 = 0;
   [[maybe_unused]] bool idx_on = false;
   if constexpr (!EPS && M != 2 && KD_LABEL_INDEX != 0) {
-    idx_on = c.ll_in_lds && c.adaptive_beam >= 0.0f;
+    idx_on = c.ll_in_lds && c.adaptive_beam >= 0.0f && Uni(s.top_valid) != 0;
     if (idx_on) LoadRowTop(s, t_m0, t_m1, t_l0);
   }
   [[maybe_unused]] uint32_t pf_st = 0, pf_st2 = 0;
@@ -2509,7 +2514,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // (workgroup-uniform; a negative adaptive beam -- beam_delta below zero -- would let a bound
   // at the cutoff hide the frame's minimum)
   const bool idx_frame = KD_LABEL_INDEX != 0 && M != 2 && n_in >= kIdxMinFront && c.ll_in_lds &&
-                         c.adaptive_beam >= 0.0f;
+                         c.adaptive_beam >= 0.0f && Uni(s.top_valid) != 0;
   // (this frame's lowest and second-lowest acoustic costs, the likeliest label; what each of this
   // lane's tokens found in its state's label index)
   constexpr int kIdxSlots = (kT1Front + kBlock - 1) / kBlock;
@@ -2692,26 +2697,35 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   if (tid < kItemWords) (&s.it_count[0])[tid] = 0;
   // the emitting filter is done with this frame's log-likelihood row: the next
   // frame's row (fetched into registers when this frame began) takes its place
+  const int q_emit = Uni(s.q_n);
   if (have_next && nt == kBlock) {
-    Top2 top = Top2Empty();
 #pragma unroll
     for (int k = 0; k < kPfRegs; ++k) {
       const int v = tid + k * kBlock;
-      if (v < p.num_cols) {
-        s.ll[v] = ll_next[k];
-        Top2Add(top, ll_next[k], v);
+      if (v < p.num_cols) s.ll[v] = ll_next[k];
+    }
+    // ... and this wave's share of the new row's two likeliest labels (LoadRowTop; read by the
+    // next frame, behind the frame-end barrier) -- if the next frame can be one that uses the
+    // label index: a frame that queued a handful of candidates is followed by a small one, and
+    // these hundred instructions were on the critical path of EVERY frame (a 4-7-token frame:
+    // 24.7 k -> 26.1 k cycles when they went in).  A frame that finds no note does without.
+    const bool note = q_emit >= kTopMinQueue;
+    if (note) {
+      Top2 top = Top2Empty();
+#pragma unroll
+      for (int k = 0; k < kPfRegs; ++k) {
+        const int v = tid + k * kBlock;
+        if (v < p.num_cols) Top2Add(top, ll_next[k], v);
+      }
+      top = WaveTop2(top);
+      if (lane == 0) {
+        s.top_a0[tid >> 6] = top.a0;
+        s.top_a1[tid >> 6] = top.a1;
+        s.top_i0[tid >> 6] = top.i0;
       }
     }
-    // ... and this wave's share of the new row's two likeliest labels (LoadRowTop; read by
-    // the next frame, behind the frame-end barrier)
-    top = WaveTop2(top);
-    if (lane == 0) {
-      s.top_a0[tid >> 6] = top.a0;
-      s.top_a1[tid >> 6] = top.a1;
-      s.top_i0[tid >> 6] = top.i0;
-    }
+    if (tid == 0) s.top_valid = note ? 1 : 0;
   }
-  const int q_emit = Uni(s.q_n);
   if (c.lattice)  // float, lattice-simple-decoder.cc:388-390
     c.cutoff = KCf<M>(s.min_new) + c.adaptive_beam;
   else
@@ -3436,6 +3450,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     LdsBarrier();
     if (p.log_softmax) NormalizeRow(s, p.num_cols);  // (logits: normalised here, once per staging)
     StoreRowTop(s, p.num_cols);  // (the label index's view of the row)
+    if (tid == 0) s.top_valid = 1;
   };
   // At the top of the loop the per-frame counters are reset and s.ll holds the
   // frame's log-likelihood row: a frame boundary costs one barrier.
@@ -3443,6 +3458,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   if (err == 0) row_to_lds(frame);
   __syncthreads();
   auto fold = [&](int stat, int v) {  // a per-lane count of this frame into the launch's totals
+    if (__ballot(v != 0) == 0) return;  // (most waves of a small frame have counted nothing)
     const int w = WaveSumInt(v);
     if ((tid & 63) == 0 && w) atomicAdd(&s.ustat[stat], static_cast<unsigned long long>(w));
   };
@@ -3557,6 +3573,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
             s.top_i0[tid >> 6] = top.i0;
           }
           if (tid == kNarrowLanes) {
+            s.top_valid = 1;
             const Top2 none = Top2Empty();
             s.top_a0[0] = none.a0;
             s.top_a1[0] = none.a1;
@@ -3571,6 +3588,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       if (p.log_softmax && r == 0 && have_next) {
         NormalizeRow(s, p.num_cols);
         StoreRowTop(s, p.num_cols);  // (the frame noted the top of the logits)
+        if (tid == 0) s.top_valid = 1;
         LdsBarrier();
       }
       upper_dirty = true;
