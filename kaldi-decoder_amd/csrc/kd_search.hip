@@ -23,6 +23,11 @@
 //             arcs.  The log-likelihood row sits in LDS.  Arcs that beat the
 //             running cutoff are appended to a candidate queue (state, arc,
 //             source, cost key) -- this phase never touches the token table.
+//             A token whose cost leaves room for the row's likeliest label only
+//             does not read its arcs: it finds the one of that label in the
+//             label index (kd_label_index.h; exact: a lower bound of every
+//             other arc's cost is at or beyond the running cutoff), and those
+//             arcs' costs tighten the cutoff before anything is queued.
 //   insert    one queue entry per lane (dense): entries below the now exact
 //             cutoff do one ds_cmpst (claim) and one 64-bit ds_min (relax) on
 //             the 8192-slot LDS token table; a state's first cost appends its
@@ -2219,11 +2224,12 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
 // half, and epsilon worklists are slot bitmasks -- so the only global reads of the
 // frame are the arcs (and the state records of tokens with epsilon arcs).
 //
-// Such a frame is bound by instruction issue, not by memory: sixteen waves that
-// mostly step over empty loops still share four SIMDs.  A frame of at most
-// kT1Narrow tokens is therefore run by a team of four waves (one per SIMD) that
-// synchronise through an LDS counter while the other twelve wait at the
-// frame-end barrier; larger ones use the whole workgroup.
+// A small frame is a chain of dependent round trips -- a handful to memory, a few dozen
+// to LDS -- that most of the workgroup's waves only watch (two thirds of a wave's cycles
+// are barrier waits: profiles/r05_search_counters.json); a large one is bound by the
+// scattered requests it issues.  The frame can be run by a team of four waves (one per
+// SIMD) while the others execute nothing but its barriers (KD_T1_NARROW; measured: no
+// faster, off); the whole workgroup runs it as shipped.
 //
 // Same results as FrameFront + FrameBack<true>.  Returns 0, 1 (does not fit:
 // the caller replays the queue in the big table), 2 (the queue overflowed: the
