@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r05_step.sh -- on the GPU box: quick fuzz of every build, the bench-scale parity tests,
+# tools/quick_check.sh [side build names] -- on the GPU box: quick fuzz of every build, the bench-scale parity tests,
 # then an A/B of the side builds named on the command line.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
