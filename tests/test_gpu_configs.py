@@ -172,6 +172,10 @@ def test_bench_scale_hlg_1024_per_call_two_calls_in_flight(oracle):
     checked = 0
     for k in range(2):
         assert lbs[k].num_frames_decoded().tolist() == [T] * N
+        # the label index was at work (round 5): most of the arcs the reference's loop visits
+        # were never fetched -- and the lattices below are the oracle's all the same
+        st = dict(zip(cabi.STAT_NAMES, lbs[k].stats().sum(axis=0).tolist()))
+        assert st["index_probes"] > 0 and 0.5 * st["arcs_scanned"] < st["arcs_skipped"] < st["arcs_scanned"]
         lats, frc = lbs[k].raw_lattices(), lbs[k].final_relative_cost()
         for i in sample:
             can = oracle.CanonLatticeDecoder(OG, **oopts)
