@@ -303,6 +303,7 @@ struct Shared {
   int32_t it_next32, it_next16;
   // ---- (end of the zeroed run)
   int32_t sel_bin, sel_k;
+  int32_t idx_n;                // big tiers: tokens noted for the label-index pass (Filter)
   int32_t frame_cnt[4];         // this frame: expanded, eps_exp, arcs, eps_arcs
   union {  // whole launch (all values are non-negative)
     long long stat[KD_NUM_STATS];
@@ -1382,7 +1383,7 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
   // more than 32 arcs from the front of the it_* arrays (a 64-lane row each), the
   // others from the back (two per row).  Counters and cursors of the second list,
   // by chunk parity: (it_n32, it_next32) and (it_n16, it_next16).
-  if (tid == 0) { s.it_count[0] = 0; s.it_next[0] = 0; s.it_n32 = 0; s.it_next32 = 0; }
+  if (tid == 0) { s.it_count[0] = 0; s.it_next[0] = 0; s.it_n32 = 0; s.it_next32 = 0; s.idx_n = 0; }
   // The emitting filter's chain per chunk of tokens is token fields -> state record -> arcs,
   // three dependent round trips with the workgroup's barriers between chunks.  It is
   // software-pipelined: a chunk's arcs are requested while the NEXT chunk's state records
@@ -1397,6 +1398,10 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
     idx_on = c.ll_in_lds && c.adaptive_beam >= 0.0f && Uni(s.top_valid) != 0;
     if (idx_on) LoadRowTop(s, t_m0, t_m1, t_l0);
   }
+  // (the two epsilon worklists -- c.q_cap words, unused until the inserts -- as 16-byte notes)
+  [[maybe_unused]] const int idx_cap = c.q_cap / 4;
+  constexpr int kIdxDegBits = 11;
+  static_assert(kIdxMaxDeg <= (1 << kIdxDegBits), "a note's degree field");
   [[maybe_unused]] uint32_t pf_st = 0, pf_st2 = 0;
   [[maybe_unused]] double pf_cst = 0.0, pf_cst2 = 0.0;
   [[maybe_unused]] bool pf_ok = false;
@@ -1480,12 +1485,24 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
             }
             if (others_out) {
               indexed = true;
-              int probes = 0, fetched = 0;
-              if (best_in)
-                IndexedArcs(p, abeg, deg, static_cast<uint32_t>(t_l0 + 1), probes, fetched,
-                            [&](uint32_t aidx, const ArcRec &ar) { FilterArc<EPS>(c, ar, aidx, cst, srcid); });
-              cnt.arcs_skipped += deg - fetched;
-              cnt.idx_probes += probes;
+              // The lookup itself waits for the pass behind the chunk loop (below): done here,
+              // chunk after chunk, its three dependent node loads and the arc's fetch were the
+              // chunk's critical path -- 768 tokens at a time, one lookup a lane.  The token is
+              // noted in the (idle) epsilon worklists: {first arc, degree | frontier index, cost}.
+              int at = best_in ? AggInc(&s.idx_n) : -1;
+              if (best_in && at < idx_cap) {
+                const unsigned long long cb = static_cast<unsigned long long>(__double_as_longlong(cst));
+                reinterpret_cast<KD_G IdxNodeVec *>(c.wl0)[at] =
+                    IdxNodeVec{static_cast<uint32_t>(abeg), static_cast<uint32_t>(deg) | srcid << kIdxDegBits,
+                               static_cast<uint32_t>(cb), static_cast<uint32_t>(cb >> 32)};
+              } else {
+                int probes = 0, fetched = 0;
+                if (best_in)  // (the list is full: here and now, as until round 5)
+                  IndexedArcs(p, abeg, deg, static_cast<uint32_t>(t_l0 + 1), probes, fetched,
+                              [&](uint32_t aidx, const ArcRec &ar) { FilterArc<EPS>(c, ar, aidx, cst, srcid); });
+                cnt.arcs_skipped += deg - fetched;
+                cnt.idx_probes += probes;
+              }
             }
           }
         }
@@ -1562,6 +1579,84 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
       });
     if (chunk + kBlock < n_items) LdsBarrier();  // it_* arrays are reused by the next chunk
     KD_LAP(s, EPS ? 8 : 4);
+  }
+  if constexpr (!EPS && M != 2 && KD_LABEL_INDEX != 0) {
+    if (idx_on) {
+      // The label-index pass over the tokens the chunks noted: four per lane in flight, the
+      // descents level by level for all four (one dependent round trip per LEVEL for up to 3072
+      // tokens, not per level per chunk of 768), then the found arcs' fetches together.
+      __syncthreads();  // (the notes are global memory; idx_n is final)
+      const int n_noted = s.idx_n < idx_cap ? s.idx_n : idx_cap;
+      constexpr int U = 4;
+      const uint32_t il = static_cast<uint32_t>(t_l0 + 1);
+      const KD_G IdxNodeVec *notes = reinterpret_cast<const KD_G IdxNodeVec *>(c.wl0);
+      for (int e0 = tid; e0 < n_noted; e0 += U * kBlock) {
+        int abeg[U], deg[U], j[U];
+        uint32_t src[U], cand[U];
+        double cst[U];
+        bool on[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = e0 + u * kBlock;
+          on[u] = e < n_noted;
+          const IdxNodeVec r = notes[on[u] ? e : e0];
+          abeg[u] = static_cast<int>(r.x);
+          deg[u] = on[u] ? static_cast<int>(r.y & ((1u << kIdxDegBits) - 1u)) : 0;
+          src[u] = r.y >> kIdxDegBits;
+          cst[u] = __longlong_as_double(static_cast<long long>(static_cast<unsigned long long>(r.w) << 32 | r.z));
+          j[u] = 0;
+          cand[u] = kIdxNone;
+        }
+        const uint32_t target = IdxKey(il, 0);
+        int probes = 0;
+        while (true) {
+          bool act[U], any = false;
+          IdxNodeVec nd[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            act[u] = 4 * j[u] < deg[u];
+            any |= act[u];
+            nd[u] = *reinterpret_cast<const KD_G IdxNodeMem *>(ToG(p.lab_idx) + abeg[u] + (act[u] ? 4 * j[u] : 0));
+          }
+          if (!__ballot(any)) break;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (!act[u]) continue;
+            ++probes;
+            const int have = deg[u] - 4 * j[u];
+            const uint32_t k0 = nd[u].x, k1 = have > 1 ? nd[u].y : kIdxNone, k2 = have > 2 ? nd[u].z : kIdxNone,
+                           k3 = have > 3 ? nd[u].w : kIdxNone;
+            const int cc = (k0 < target) + (k1 < target) + (k2 < target) + (k3 < target);
+            const uint32_t kc = cc == 0 ? k0 : cc == 1 ? k1 : cc == 2 ? k2 : cc == 3 ? k3 : kIdxNone;
+            if (kc != kIdxNone) cand[u] = kc;
+            j[u] = 5 * j[u] + 1 + cc;
+          }
+        }
+        // the found arcs, requested together
+        bool hit[U];
+        ArcRec ar[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          hit[u] = on[u] && cand[u] != kIdxNone && IdxKeyLabel(cand[u]) == il;
+          ar[u] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg[u]) + IdxKeyOffset(hit[u] ? cand[u] : 0u), hit[u], 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!on[u]) continue;
+          int fetched = 0;
+          if (hit[u]) {
+            FilterArc<EPS>(c, ar[u], static_cast<uint32_t>(abeg[u]) + IdxKeyOffset(cand[u]), cst[u], src[u]);
+            fetched = 1;
+            if (IdxKeyMore(cand[u]))  // (a state with several arcs of the label: the rest, one by one)
+              IndexedArcsFrom(p, abeg[u], deg[u], il, IndexFind(p, abeg[u], deg[u], cand[u] + 1, probes), probes,
+                              fetched, [&](uint32_t aidx, const ArcRec &a2) { FilterArc<EPS>(c, a2, aidx, cst[u], src[u]); });
+          }
+          cnt.arcs_skipped += deg[u] - fetched;
+        }
+        cnt.idx_probes += probes;
+      }
+      PublishMin(c);
+    }
   }
   __syncthreads();  // candidate-queue stores visible to the insert phase
 }
