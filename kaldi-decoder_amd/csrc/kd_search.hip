@@ -142,6 +142,10 @@ constexpr int kPfRegs = (kVmax + KD_BLOCK - 1) / KD_BLOCK;
 #ifndef KD_LABEL_INDEX
 #define KD_LABEL_INDEX 1
 #endif
+// Noted tokens a lane looks up side by side in the big tiers' label-index pass (Filter).
+#ifndef KD_IDX_NOTE_ILP
+#define KD_IDX_NOTE_ILP 4
+#endif
 #ifndef KD_IDX_MIN_FRONT
 #define KD_IDX_MIN_FRONT 192
 #endif
@@ -1587,7 +1591,7 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
       // tokens, not per level per chunk of 768), then the found arcs' fetches together.
       __syncthreads();  // (the notes are global memory; idx_n is final)
       const int n_noted = s.idx_n < idx_cap ? s.idx_n : idx_cap;
-      constexpr int U = 4;
+      constexpr int U = KD_IDX_NOTE_ILP;
       const uint32_t il = static_cast<uint32_t>(t_l0 + 1);
       const KD_G IdxNodeVec *notes = reinterpret_cast<const KD_G IdxNodeVec *>(c.wl0);
       for (int e0 = tid; e0 < n_noted; e0 += U * kBlock) {
