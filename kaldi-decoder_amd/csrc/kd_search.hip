@@ -146,6 +146,11 @@ constexpr int kPfRegs = (kVmax + KD_BLOCK - 1) / KD_BLOCK;
 #ifndef KD_IDX_NOTE_ILP
 #define KD_IDX_NOTE_ILP 4
 #endif
+// Room for notes in that pass: 0 = what the two epsilon worklists hold; test builds set a few
+// dozen so that a frame meets the full list (the token then looks its arc up inline).
+#ifndef KD_IDX_NOTE_CAP
+#define KD_IDX_NOTE_CAP 0
+#endif
 #ifndef KD_IDX_MIN_FRONT
 #define KD_IDX_MIN_FRONT 192
 #endif
@@ -1403,7 +1408,7 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
     if (idx_on) LoadRowTop(s, t_m0, t_m1, t_l0);
   }
   // (the two epsilon worklists -- c.q_cap words, unused until the inserts -- as 16-byte notes)
-  [[maybe_unused]] const int idx_cap = c.q_cap / 4;
+  [[maybe_unused]] const int idx_cap = KD_IDX_NOTE_CAP > 0 ? KD_IDX_NOTE_CAP : c.q_cap / 4;
   constexpr int kIdxDegBits = 11;
   static_assert(kIdxMaxDeg <= (1 << kIdxDegBits), "a note's degree field");
   [[maybe_unused]] uint32_t pf_st = 0, pf_st2 = 0;
