@@ -230,6 +230,8 @@ enum {
                                already at or beyond the running cutoff (label index, kd_search.hip);
                                arcs READ = ARCS_SCANNED - ARCS_SKIPPED                          */
   KD_STAT_INDEX_PROBES,     /* 4-byte label-index entries read to find the arcs that were fetched */
+  KD_STAT_HANDOVERS,        /* times the utterance changed hands between the two kinds of workgroups */
+  KD_STAT_SMALL_WG_FRAMES,  /* frames run by a workgroup of the small kind (three to a CU) */
   KD_NUM_STATS
 };
 int kd_batch_stats(kd_batch *b, int64_t *out /* [batch][KD_NUM_STATS] */);

@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -50,6 +52,62 @@ struct DevBuf {
   size_t bytes() const { return n * sizeof(T); }
 };
 
+// ---- two kernels side by side (round 6; kd_device.h SchedCtl) ----------
+// The large and the small geometry's persistent workgroups must be resident TOGETHER and on
+// CUs of their own: a large workgroup fills a CU's LDS, three small ones fill another's, and a
+// CU that holds one small workgroup cannot take a large one.  Left to itself the dispatcher
+// spreads the small kernel one workgroup per CU over the whole chip (tools/ubench/cumask.hip);
+// with a CU mask per stream -- hipExtStreamCreateWithCUMask: the mask is a property of the
+// hardware queue -- the two kernels land on disjoint CUs whatever the launch order.  Mask bits
+// are dealt round-robin over the XCDs (bit i: XCD i % 8 -- measured, same tool), so "the first X
+// bits" is X / 8 CUs of every XCD.  A few pairs of masked streams per device are created once
+// and shared by the batches (round-robin): a masked stream is a hardware queue of its own, and
+// batches that are in flight together should not share one.
+struct SplitStreams {
+  hipStream_t large = nullptr, small = nullptr;
+};
+struct SplitDevice {
+  int large_cus = 0;
+  bool failed = false;
+  std::vector<SplitStreams> pairs;
+  unsigned next = 0;
+};
+std::mutex g_split_mu;
+std::map<int, SplitDevice> g_split;
+
+int EnvInt(const char *name, int def) {
+  const char *v = std::getenv(name);
+  return v && *v ? std::atoi(v) : def;
+}
+
+// A pair of streams masked to the first `large_cus` CU bits / the rest (false: not available).
+bool TakeSplitStreams(int device, int cus, int large_cus, SplitStreams *out) {
+  std::lock_guard<std::mutex> lock(g_split_mu);
+  SplitDevice &d = g_split[device];
+  if (d.failed) return false;
+  if (d.pairs.empty()) {
+    d.large_cus = large_cus;
+    const int n_pairs = std::max(1, std::min(8, EnvInt("KD_SPLIT_PAIRS", 4)));
+    const size_t words = static_cast<size_t>(cus + 31) / 32;
+    std::vector<uint32_t> ml(words, 0u), ms(words, 0u);
+    for (int i = 0; i < cus; ++i) (i < large_cus ? ml : ms)[i / 32] |= 1u << (i % 32);
+    for (int k = 0; k < n_pairs; ++k) {
+      SplitStreams sp;
+      if (hipExtStreamCreateWithCUMask(&sp.large, static_cast<uint32_t>(words), ml.data()) != hipSuccess ||
+          hipExtStreamCreateWithCUMask(&sp.small, static_cast<uint32_t>(words), ms.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        if (sp.large) (void)hipStreamDestroy(sp.large);
+        if (d.pairs.empty()) { d.failed = true; return false; }
+        break;
+      }
+      d.pairs.push_back(sp);
+    }
+  }
+  if (d.large_cus != large_cus) return false;  // (one partition per device and process)
+  *out = d.pairs[d.next++ % d.pairs.size()];
+  return true;
+}
+
 }  // namespace
 
 struct kd_graph {
@@ -61,6 +119,7 @@ struct kd_graph {
   DevBuf<ArcPacked> arcs;
   DevBuf<int32_t> olabels;  // [arcs], in the arcs' device order (emitting first per state)
   DevBuf<uint32_t> lab_idx; // [arcs], label index of the emitting ranges (kd_device.h)
+  DevBuf<int32_t> big_ilabel;  // [arcs] when the graph holds an input label of 2^20 - 1 or more (else empty)
   float emit_w_min = 0.0f;  // lowest emitting-arc weight (NaN if a weight is NaN)
 };
 
@@ -104,6 +163,19 @@ struct kd_batch {
   DevBuf<uint32_t> g_slot, g_used, g_wl, g_log_h, g_log_arc, g_log_src;
   DevBuf<unsigned long long> g_log_nk;
   DevBuf<float> g_log_ac, g_log_gr;
+  // ---- the two kinds of workgroups (kd_device.h SchedCtl): queues, the frame loop's state of an
+  // utterance that changes hands, the CU-masked streams the two kernels run on
+  bool split_ok = false;          // the batch can run split launches
+  int split_min_batch = 0;        // ... and does for calls of at least this many utterances
+  int cus = 0, large_cus = 0;
+  int wgs_single = 1, wgs_large = 0, wgs_small = 0;  // workgroups of an unsplit launch / of a split one, at most
+  int mig_lo = 0, mig_hi = 0, prune_small = 0;
+  SplitStreams split_streams;
+  hipEvent_t ev_fork = nullptr, ev_join_l = nullptr, ev_join_s = nullptr;
+  DevBuf<SchedCtl> sched_ctl;
+  DevBuf<uint32_t> sched_ring;
+  DevBuf<UttResume> resume;
+  int ring_cap = 1;
   // ---- launch control: UttCtl[B] | order[B] | UttOut[B] | HostTops in pinned host memory
   // the GPU reads and writes in place; BatchCtl (the atomic counters) in device memory
   DevBuf<BatchCtl> bctl;
@@ -148,6 +220,9 @@ struct kd_batch {
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev_staged) (void)hipEventDestroy(ev_staged);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join_l) (void)hipEventDestroy(ev_join_l);
+    if (ev_join_s) (void)hipEventDestroy(ev_join_s);
   }
 
   size_t DeviceBytes() const {
@@ -169,6 +244,7 @@ struct kd_batch {
     p.arcs = g->arcs.p;
     p.arc_olabel = g->olabels.p;
     p.lab_idx = g->lab_idx.p;
+    p.big_ilabel = g->big_ilabel.n ? g->big_ilabel.p : nullptr;
     p.emit_w_min = g->emit_w_min;
     p.start = g->start;
     p.beam = o.beam;
@@ -243,6 +319,16 @@ struct kd_batch {
     p.lat.out = out_pool;
     p.lat.out2 = out_ext;
     p.lat.out_cap = out_ext ? std::min<uint64_t>(out_cap, out_ext_cap) : out_cap;
+    p.sched.ctl = sched_ctl.p;
+    p.sched.ring = sched_ring.p;
+    p.sched.resume = resume.p;
+    p.sched.ring_cap = ring_cap;
+    p.sched.wg_base = 0;
+    p.sched.total_wgs = 0;  // (Enqueue)
+    p.sched.mig_lo = mig_lo;
+    p.sched.mig_hi = mig_hi;
+    p.sched.prune_small = prune_small;
+    p.sched.split = 0;
     return p;
   }
 };
@@ -253,6 +339,14 @@ constexpr uint32_t kRecoverable =
     KD_UTT_ARENA_FULL | KD_UTT_LINKS_FULL | KD_UTT_TABLE_FULL | KD_UTT_OUT_FULL | KD_UTT_PATH_QUEUE_FULL;
 constexpr uint64_t kIndexLimit = (1ull << 31) - 1;  // tokens and links are indexed with int32
 constexpr int kMaxLog2Slots = 19;  // the spill table's worklist bitmask lives in 64 KiB of LDS
+// A call is split over the two kinds of workgroups when it brings at least as many utterances
+// as the chip has CUs: below that every utterance has a CU of its own anyway.  (Test builds:
+// every call, so that fuzz-sized cases change hands.)
+#ifndef KD_SPLIT_MIN_BATCH
+#define KD_SPLIT_MIN_BATCH_DEFAULT(cus) (cus)
+#else
+#define KD_SPLIT_MIN_BATCH_DEFAULT(cus) (KD_SPLIT_MIN_BATCH)
+#endif
 
 int CheckOptions(const kd_faster_options &o) {
   // faster-decoder.cc:24-28
@@ -447,9 +541,36 @@ int Enqueue(kd_batch *b) {
   if (b->log_softmax && b->l_num_cols > SearchMaxLdsCols())
     return Fail(KD_E_INVALID, "log-softmax is fused into the staging of a row in LDS: at most " +
                               std::to_string(SearchMaxLdsCols()) + " columns");
-  const int wgs = std::min(b->batch, b->workgroups);
+  if (b->log_softmax && b->split_ok && b->l_num_cols > SearchMaxLdsColsSmall())
+    return Fail(KD_E_INVALID, "log-softmax is fused into the staging of a row in LDS: at most " +
+                              std::to_string(SearchMaxLdsColsSmall()) + " columns");
+  int wgs = 0;
   KD_HIP_TRY(hipEventRecord(b->ev0, b->stream));
-  KD_HIP_TRY(LaunchSearch(p, wgs, b->stream));
+  if (b->split_ok && b->batch >= b->split_min_batch) {
+    // Both kernels, each on its CU-masked stream, between a fork and a join on the batch's own
+    // stream.  Either kernel can finish the call alone (a large workgroup runs any frame; a
+    // small one hands a large frame over only to large workgroups that have started), so the
+    // order in which the hardware starts them decides nothing but speed.
+    const int wl = std::min(b->batch, b->wgs_large), ws = std::min(b->batch, b->wgs_small);
+    wgs = wl + ws;
+    p.sched.split = 1;
+    p.sched.total_wgs = wgs;
+    KD_HIP_TRY(hipEventRecord(b->ev_fork, b->stream));
+    KD_HIP_TRY(hipStreamWaitEvent(b->split_streams.large, b->ev_fork, 0));
+    KD_HIP_TRY(hipStreamWaitEvent(b->split_streams.small, b->ev_fork, 0));
+    p.sched.wg_base = 0;
+    KD_HIP_TRY(LaunchSearch(p, wl, b->split_streams.large));
+    p.sched.wg_base = wl;
+    KD_HIP_TRY(LaunchSearchSmall(p, ws, b->split_streams.small));
+    KD_HIP_TRY(hipEventRecord(b->ev_join_l, b->split_streams.large));
+    KD_HIP_TRY(hipEventRecord(b->ev_join_s, b->split_streams.small));
+    KD_HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join_l, 0));
+    KD_HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join_s, 0));
+  } else {
+    wgs = std::min(b->batch, b->wgs_single);
+    p.sched.total_wgs = wgs;
+    KD_HIP_TRY(LaunchSearch(p, wgs, b->stream));
+  }
   KD_HIP_TRY(hipEventRecord(b->ev1, b->stream));
   // every utterance is handed out once and every workgroup makes one failed attempt
   b->work_raw += static_cast<uint32_t>(b->batch + wgs);
@@ -733,9 +854,10 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
     if (!EpsilonCyclesArePositive(num_states, row_ptr, ilabel, weight, nextstate, &why))
       return Fail(KD_E_INVALID, why);
   }
-  if (max_ilabel > kMaxIlabel)
-    return Fail(KD_E_INVALID, "ilabel " + std::to_string(max_ilabel) + " exceeds the largest supported (" +
-                              std::to_string(kMaxIlabel) + ": 20 bits of the arc record)");
+  // (input labels of 2^20 - 1 and more do not fit the arc record's 20-bit field: it holds the
+  // escape code and the label stands in a side array -- kd_device.h kIlabelEscape)
+  const bool big_labels = max_ilabel >= kIlabelEscape;
+  std::vector<int32_t> big(big_labels ? std::max<int64_t>(na, 1) : 0, 0);
   std::vector<StateRec> st(num_states);
   std::vector<ArcPacked> ar(std::max<int64_t>(na, 1));
   std::vector<int32_t> ol(std::max<int64_t>(na, 1), 0);
@@ -754,11 +876,13 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
       // what the search would otherwise fetch from the destination's state record)
       const StateRec &d = st[nextstate[a]];
       const uint32_t degs = PackDegs(d.emit_end - d.arc_begin, d.arc_end - d.emit_end);
-      ArcPacked r{static_cast<uint32_t>(ilabel[a]) | degs << kIlabelBits, static_cast<uint32_t>(d.arc_begin),
+      const uint32_t lab20 = static_cast<uint32_t>(ilabel[a] >= kIlabelEscape ? kIlabelEscape : ilabel[a]);
+      ArcPacked r{lab20 | degs << kIlabelBits, static_cast<uint32_t>(d.arc_begin),
                   weight[a], static_cast<uint32_t>(nextstate[a]) | (has_eps[nextstate[a]] ? kHasEps : 0u)};
       const int32_t at = ilabel[a] != 0 ? we++ : wn++;
       ar[at] = r;
       ol[at] = olabel[a];
+      if (big_labels) big[at] = ilabel[a];
     }
   }
   // Label index (kd_label_index.h): per state, the keys (ilabel, offset) of its emitting arcs as an
@@ -800,6 +924,9 @@ int kd_graph_create(int device, int32_t num_states, int32_t start, const int32_t
   if (e == hipSuccess) e = g->arcs.Alloc(ar.size());
   if (e == hipSuccess) e = g->olabels.Alloc(ol.size());
   if (e == hipSuccess) e = g->lab_idx.Alloc(li.size());
+  if (e == hipSuccess && big_labels) e = g->big_ilabel.Alloc(big.size());
+  if (e == hipSuccess && big_labels)
+    e = hipMemcpy(g->big_ilabel.p, big.data(), big.size() * sizeof(int32_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(g->lab_idx.p, li.data(), li.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(g->states.p, st.data(), st.size() * sizeof(StateRec), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(g->arcs.p, ar.data(), ar.size() * sizeof(ArcPacked), hipMemcpyHostToDevice);
@@ -816,7 +943,9 @@ void kd_graph_destroy(kd_graph *g) { delete g; }
 int32_t kd_graph_num_states(const kd_graph *g) { return g ? g->num_states : 0; }
 int64_t kd_graph_num_arcs(const kd_graph *g) { return g ? g->num_arcs : 0; }
 size_t kd_graph_device_bytes(const kd_graph *g) {
-  return g ? g->states.bytes() + g->arcs.bytes() + g->olabels.bytes() + g->lab_idx.bytes() : 0;
+  return g ? g->states.bytes() + g->arcs.bytes() + g->olabels.bytes() + g->lab_idx.bytes() +
+                 (g->big_ilabel.p ? g->big_ilabel.bytes() : 0)
+           : 0;
 }
 
 void kd_faster_options_default(kd_faster_options *o) {
@@ -849,7 +978,30 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device) != hipSuccess || cus <= 0)
     cus = 256;
-  b->workgroups = std::min<int>(max_batch, cus * SearchWorkgroupsPerCu());
+  b->cus = cus;
+  b->wgs_single = std::min<int>(max_batch, cus * SearchWorkgroupsPerCu());
+  b->workgroups = b->wgs_single;
+  // Two kinds of workgroups (kd_device.h SchedCtl): three quarters of the CUs run one large
+  // workgroup each, the rest three small ones each, and an utterance is run by the kind its
+  // frames' sizes ask for.  (KD_SPLIT=0: one kernel as in rounds 1-5.  The knobs are for
+  // tools/ and the tests; SimpleDecoder has no LDS-resident tier and stays unsplit.)
+  if (!simple && EnvInt("KD_SPLIT", 1) != 0 && cus >= 16) {
+    int x = EnvInt("KD_SPLIT_LARGE_CUS", cus * 3 / 4) / 8 * 8;
+    x = std::max(8, std::min(cus - 8, x));
+    if (TakeSplitStreams(g->device, cus, x, &b->split_streams)) {
+      b->split_ok = true;
+      b->large_cus = x;
+      b->wgs_large = std::min<int>(max_batch, x);
+      // (a few more than fit: the dispatcher does not deal them out evenly -- tools/ubench/cumask.hip
+      // -- and one that finds no room starts when the launch is over, and leaves)
+      b->wgs_small = std::min<int>(max_batch, (cus - x) * SearchWorkgroupsPerCuSmall() + (cus - x) / 8);
+      b->workgroups = std::max(b->wgs_single, b->wgs_large + b->wgs_small);
+      b->split_min_batch = std::max(1, EnvInt("KD_SPLIT_MIN_BATCH", KD_SPLIT_MIN_BATCH_DEFAULT(cus)));
+      b->mig_hi = std::max(1, std::min(EnvInt("KD_MIG_HI", SearchT1FrontSmall()), 1 << 20));
+      b->mig_lo = std::max(0, std::min(EnvInt("KD_MIG_LO", b->mig_hi), b->mig_hi));
+      b->prune_small = EnvInt("KD_PRUNE_SMALL", 0) != 0 ? 1 : 0;
+    }
+  }
   // pools: 2^17 token records per utterance to begin with (an HLG decode at beam 15 writes
   // about 10^5 per 10 s utterance), two links per token; both grow on demand
   uint64_t tok = b->o.arena_tokens > 0 ? static_cast<uint64_t>(b->o.arena_tokens)
@@ -886,6 +1038,18 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   b->ctl_bytes = b->off_tops + sizeof(HostTops);
   A(b->bctl.Alloc(1));
   if (e == hipSuccess) e = hipMemset(b->bctl.p, 0, sizeof(BatchCtl));
+  if (b->split_ok) {
+    while (b->ring_cap < max_batch) b->ring_cap *= 2;
+    A(b->sched_ctl.Alloc(1));
+    A(b->sched_ring.Alloc(static_cast<size_t>(kMaxXcd) * 2 * b->ring_cap));
+    A(b->resume.Alloc(max_batch));
+    if (e == hipSuccess) e = hipMemset(b->sched_ctl.p, 0, sizeof(SchedCtl));
+    if (e == hipSuccess) e = hipMemset(b->sched_ring.p, 0, b->sched_ring.bytes());
+    if (e == hipSuccess) e = hipMemset(b->resume.p, 0, b->resume.bytes());
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join_l, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join_s, hipEventDisableTiming);
+  }
   if (e == hipSuccess)
     e = hipHostMalloc(reinterpret_cast<void **>(&b->ctl_host), b->ctl_bytes, hipHostMallocDefault);
   if (e == hipSuccess) std::memset(b->ctl_host, 0, b->ctl_bytes);
@@ -1112,9 +1276,15 @@ static int StageHost(kd_batch *b, const float *const *loglikes, int32_t num_cols
   // -- not for the launch, which is enqueued behind it.
   // (only then -- a call fed pageable matrices returns as soon as HIP's own
   // staging lets it, as before round 4.)
+  // (a handful of driver look-ups per call, not one per utterance -- the first
+  // and last non-empty matrices and two between; callers hand over matrices of one kind)
   bool pinned = false;
-  for (int i = 0; i < b->batch && !pinned; ++i) {
-    if (!count[i]) continue;
+  std::vector<int> rows;
+  for (int i = 0; i < b->batch; ++i)
+    if (count[i]) rows.push_back(i);
+  const size_t nr = rows.size();
+  for (size_t k = 0; k < std::min<size_t>(nr, 4) && !pinned; ++k) {
+    const int i = rows[nr <= 4 ? k : k * (nr - 1) / 3];
     hipPointerAttribute_t at{};
     if (hipPointerGetAttributes(&at, loglikes[i]) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
     else (void)hipGetLastError();  // (plain malloc'ed memory: "invalid value", not an error of ours)

@@ -41,6 +41,13 @@ struct __attribute__((aligned(16))) ArcPacked {
 constexpr int kIlabelBits = 20;
 constexpr int kIdxOffBits = 12;  // label-index keys: ilabel << 12 | offset << 1 | more (kd_label_index.h)
 constexpr int32_t kMaxIlabel = (1 << kIlabelBits) - 1;
+// The largest 20-bit value is not a label but an ESCAPE: the arc's input label is this or
+// larger and stands in a side array of full int32 labels (SearchParams::big_ilabel, parallel to
+// the arcs; allocated only for a graph that holds such a label -- an H over the transition-ids
+// of a large acoustic model, not a CTC token graph).  The reference takes any int32
+// (faster-decoder.cc:204-209).  Such a graph's matrices have more than 2^20 columns, so their
+// rows are never staged in LDS: only the paths that read a row in place look the label up.
+constexpr int32_t kIlabelEscape = kMaxIlabel;
 // degrees that do not fit are stored as these, and looked up in the state record as before
 constexpr uint32_t kEmitDegEscape = 255u, kEpsDegEscape = 15u;
 // the 12 degree bits as one field ("degs": emitting degree | epsilon degree << 8)
@@ -68,7 +75,7 @@ constexpr uint32_t kSrcEps = 0x80000000u;  // back-pointer source is a table slo
 constexpr uint32_t kSrcNone = 0xFFFFFFFFu;
 constexpr unsigned long long kCostDead = 0xFFFFFFFFFFFFFFFFull;
 constexpr int kProfSlots = 24;   // diagnostic cycle buckets (KD_PROFILE builds)
-constexpr int kStatStride = 40;  // KD_NUM_STATS counters + kProfSlots, padded
+constexpr int kStatStride = 48;  // KD_NUM_STATS counters + kProfSlots, padded
 
 // ---- launch control ------------------------------------------------------------
 // No copy engine and no copy kernel takes part in a launch.  The per-utterance inputs
@@ -104,6 +111,55 @@ struct BatchCtl {
 // what the last workgroup of a launch leaves in pinned memory for the host
 struct HostTops {
   unsigned long long tok_top, link_top, out_top, launches;
+};
+
+// ---- two kinds of persistent workgroups in one call (round 6) ---------
+// A call's utterances are decoded by two kernels that run side by side on disjoint sets of
+// CUs (CU-masked streams): "large" workgroups -- one per CU, the whole CU's LDS: the geometry
+// every frame fits -- and "small" ones, three to a CU, whose chains of dependent round trips
+// overlap.  An utterance changes hands at a frame boundary when the size of the frontier its
+// next frame starts from crosses a threshold (hysteresis: mig_lo / mig_hi): the workgroup that
+// has it stores what the frame loop carries in registers and LDS (UttResume; everything else of
+// an utterance already lives in global memory) and pushes the utterance onto a device queue of
+// the other kind.  Queues are per XCD and indexed by the XCD the pushing workgroup RUNS on
+// (HW_REG_XCC_ID): an utterance stays on one XCD for the whole launch, so that what one
+// workgroup stored is in the L2 the next one reads through -- a hand-over needs the storing
+// waves' s_waitcnt vmcnt(0) and an L1 invalidate at the taker, never an L2 write-back.
+constexpr int kMaxXcd = 8;
+constexpr int kKindSmall = 0, kKindLarge = 1;
+struct SchedQueue {
+  uint32_t head, tail;  // consumed / produced, since the launch began
+  uint32_t pad[14];     // (a 64-byte line of its own)
+};
+struct SchedCtl {
+  SchedQueue q[kMaxXcd][2];      // [xcd][kind]
+  uint32_t n_reg[kMaxXcd][2];    // workgroups of each kind that have started, per XCD
+  uint32_t n_finished;           // utterances that have reached their target (or stopped) in this launch
+  uint32_t pad[15];
+};  // all zero between launches: the last workgroup to leave a launch zeroes it
+// what the frame loop carries across a frame boundary
+struct UttResume {
+  const float *ll;                // the utterance's UttCtl, read from pinned host memory once per launch
+  int32_t offset, target;
+  uint32_t flags;
+  int32_t frame;                  // the next frame to decode
+  long long base_in;              // its frontier: an arena block ...
+  int32_t n_in;
+  int32_t prev_q_emit;
+  unsigned long long f_best;      // ... and its best cost (key)
+  int32_t visited;
+  int32_t moves;                  // hand-overs of this utterance in this launch
+};
+struct SchedParams {
+  SchedCtl *ctl;                  // device memory
+  uint32_t *ring;                 // [kMaxXcd][2][ring_cap] entries utt + 1 (0: empty)
+  UttResume *resume;              // [batch]
+  int32_t ring_cap;               // a power of two >= batch
+  int32_t wg_base;                // this kernel's first per-workgroup scratch set
+  int32_t total_wgs;              // workgroups of both kernels of this launch
+  int32_t mig_lo, mig_hi;         // large -> small at n_in <= mig_lo; small -> large at n_in > mig_hi
+  int32_t prune_small;            // 1: periodic pruning is handed to the small kind
+  int32_t split;                  // 0: one kernel, no hand-overs (the kernel of rounds 1-5)
 };
 
 struct UttOut {
@@ -182,6 +238,7 @@ struct SearchParams {
   // (ilabel, offset of the arc in the range) as an implicit 5-ary search tree -- so a token finds
   // its arcs of ONE ilabel in a few dependent 16-byte loads instead of reading all its arcs
   const uint32_t *lab_idx;
+  const int32_t *big_ilabel;  // [arcs] or null: the labels of the arcs whose 20-bit field holds kIlabelEscape
   float emit_w_min;           // the lowest weight of any emitting arc of the graph (NaN: unknown)
   int32_t start;
   // FasterDecoderOptions
@@ -248,14 +305,22 @@ struct SearchParams {
   long long *link_eps_base;      // into frame f itself
   int32_t *link_eps_count;
   LatticeParams lat;
+  SchedParams sched;
 };
 
-// Launcher implemented in kd_search.hip
+// Launchers implemented in kd_search.hip, which is compiled twice into the library: the
+// large geometry (768 threads, the CU's LDS) and, with -DKD_GEOM_SMALL, the small one
+// (256 threads, a third of the LDS, three workgroups to a CU).
 // `workgroups` persistent workgroups take the batch's utterances from the work queue.
 hipError_t LaunchSearch(const SearchParams &p, int workgroups, hipStream_t stream);
+hipError_t LaunchSearchSmall(const SearchParams &p, int workgroups, hipStream_t stream);
 size_t SearchLdsBytes();
-int SearchMaxLdsCols();       // widest row the kernel stages in LDS (wider ones are read in place)
+size_t SearchLdsBytesSmall();
+int SearchMaxLdsCols();       // widest row the kernels stage in LDS (wider ones are read in place)
+int SearchMaxLdsColsSmall();
 int SearchWorkgroupsPerCu();  // resident workgroups a CU holds (build geometry)
+int SearchWorkgroupsPerCuSmall();
+int SearchT1FrontSmall();     // largest frontier the small geometry keeps in LDS
 
 // Order-preserving map double -> uint64 (so integer atomicMin orders costs).
 __host__ __device__ inline unsigned long long CostKey(double d) {

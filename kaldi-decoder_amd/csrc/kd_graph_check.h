@@ -139,7 +139,7 @@ inline bool EpsilonCyclesArePositive(int32_t num_states, const int32_t *row_ptr,
       return false;
     }
     double mu;  // the component's minimum cycle mean
-    if (static_cast<int64_t>(n) * n > (int64_t{1} << 26)) {
+    if (static_cast<int64_t>(n) * n > (int64_t{1} << 22)) {  // (32 MB of doubles at most; components are a handful of states)
       // A component too large for Karp's table (thousands of states on one epsilon cycle
       // structure): the conservative rule of rounds 4 -- a negative arc refuses, and so does a
       // cycle made of zero-weight arcs only (peel the zero-weight arcs' in-degrees).

@@ -24,6 +24,7 @@
 #define KD_LABEL_INDEX_H_
 
 #include <stdint.h>
+#include <algorithm>
 
 #include "kd_device.h"
 
@@ -55,12 +56,22 @@ inline void LabelIndexLayout(const uint32_t *sorted, int32_t n, uint32_t *out) {
 // The index of a range of n < kIdxMaxDeg arcs with the given input labels, into out[0, n).
 inline void LabelIndexBuild(const uint32_t *ilabel, int32_t n, uint32_t *out, uint32_t *scratch /* n */) {
   for (int32_t i = 0; i < n; ++i) scratch[i] = IdxKey(ilabel[i], static_cast<uint32_t>(i));
-  // (insertion sort for the short ranges that make up a graph, std::sort's job otherwise)
-  for (int32_t i = 1; i < n; ++i) {
-    const uint32_t v = scratch[i];
-    int32_t j = i;
-    for (; j > 0 && scratch[j - 1] > v; --j) scratch[j] = scratch[j - 1];
-    scratch[j] = v;
+  // (keys carry their offset: equal labels keep their arc order.  A range that arcsort left
+  // ascending -- the usual case -- is found so in one pass; insertion sort for the short ranges
+  // that make up a graph, std::sort for the history states of a large LM: up to 2047 arcs)
+  bool ascending = true;
+  for (int32_t i = 1; i < n && ascending; ++i) ascending = scratch[i - 1] <= scratch[i];
+  if (!ascending) {
+    if (n > 32) {
+      std::sort(scratch, scratch + n);
+    } else {
+      for (int32_t i = 1; i < n; ++i) {
+        const uint32_t v = scratch[i];
+        int32_t j = i;
+        for (; j > 0 && scratch[j - 1] > v; --j) scratch[j] = scratch[j - 1];
+        scratch[j] = v;
+      }
+    }
   }
   for (int32_t i = 0; i + 1 < n; ++i)
     if (IdxKeyLabel(scratch[i]) == IdxKeyLabel(scratch[i + 1])) scratch[i] |= 1u;

@@ -204,7 +204,7 @@ struct Stage {
   bool on;
 };
 __device__ __forceinline__ Stage TailStage(CParams &p, bool on) {
-  const long long gslots = 1ll << p.g_log2_slots, wg = blockIdx.x;
+  const long long gslots = 1ll << p.g_log2_slots, wg = p.sched.wg_base + blockIdx.x;
   Stage st;
   st.tok_g = ToG(p.g_log_h) + wg * 2 * gslots;
   st.tok_f = ToG(p.g_log_arc) + wg * 2 * gslots;
@@ -858,7 +858,7 @@ __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &
   const long long fb = static_cast<long long>(utt) * (p.max_frames + 1);
   KD_G int32_t *soff = ToG(p.lat.frame_state_off) + fb;
   // scratch: three more of the workgroup's idle queue arrays (2 * table slots words each)
-  const long long gslots = 1ll << p.g_log2_slots, wg = blockIdx.x;
+  const long long gslots = 1ll << p.g_log2_slots, wg = p.sched.wg_base + blockIdx.x;
   KD_G uint32_t *sc_a = reinterpret_cast<KD_G uint32_t *>(ToG(p.g_log_ac) + wg * 2 * gslots);
   KD_G uint32_t *sc_b = reinterpret_cast<KD_G uint32_t *>(ToG(p.g_log_gr) + wg * 2 * gslots);
   KD_G uint32_t *sc_c = ToG(p.g_wl) + wg * 2 * gslots;
@@ -976,7 +976,7 @@ __device__ __forceinline__ uint32_t LatticeExportStaged(CParams &p, TailShared &
     const ArcRec ar = LoadArcRec(p.arcs, static_cast<uint32_t>(arc));
     KD_G unsigned long long *w = o_arc + 3ll * (lo + rank);
     w[0] = pack(static_cast<uint32_t>(sid), static_cast<uint32_t>(ToG(p.lat.tok_newid)[dst]));
-    w[1] = pack(static_cast<uint32_t>(ar.ilabel), static_cast<uint32_t>(ToG(p.arc_olabel)[arc]));
+    w[1] = pack(static_cast<uint32_t>(FullIlabel(p, ar, static_cast<uint32_t>(arc))), static_cast<uint32_t>(ToG(p.arc_olabel)[arc]));
     w[2] = pack(__float_as_uint(gr), __float_as_uint(ac));
     if (two) {
       KD_G unsigned long long *d = d_arc + 3ll * (lo + rank);
@@ -1153,7 +1153,7 @@ __device__ __forceinline__ uint32_t LatticeExport(CParams &p, TailShared &s, int
             w[3] = pack(static_cast<uint32_t>(arc), 0u);  // (what the host orders a source's arcs by)
             w[0] = pack(static_cast<uint32_t>(ToG(p.lat.tok_newid)[ToG(p.link_src)[at]]),
                         static_cast<uint32_t>(ToG(p.lat.tok_newid)[dst[u]]));
-            w[1] = pack(static_cast<uint32_t>(ar.ilabel), static_cast<uint32_t>(ToG(p.arc_olabel)[arc]));
+            w[1] = pack(static_cast<uint32_t>(FullIlabel(p, ar, static_cast<uint32_t>(arc))), static_cast<uint32_t>(ToG(p.arc_olabel)[arc]));
             w[2] = pack(__float_as_uint(ToG(p.link_graph)[at]), __float_as_uint(ToG(p.link_ac)[at]));
           }
           before += __popcll(m);

@@ -167,7 +167,7 @@ __device__ __noinline__ uint32_t PathTail(CParams *pp, int utt, int F, uint32_t 
     const float graph_cost = arc.weight;
     const float ac_cost = p.simple ? __uint_as_float(st.tok_f[k]) : tot_cost - graph_cost;
     KD_G unsigned long long *w = o + 3ll * j;
-    w[0] = pack(static_cast<uint32_t>(arc.ilabel), static_cast<uint32_t>(ToG(p.arc_olabel)[st.tok_g[k]]));
+    w[0] = pack(static_cast<uint32_t>(FullIlabel(p, arc, st.tok_g[k])), static_cast<uint32_t>(ToG(p.arc_olabel)[st.tok_g[k]]));
     w[1] = pack(arc.next & kStateMask, __float_as_uint(graph_cost));
     w[2] = pack(__float_as_uint(ac_cost), 0u);
   }

@@ -90,8 +90,48 @@ __device__ __forceinline__ void KdJitter() {
 __device__ __forceinline__ void KdJitter() {}
 #endif
 
+// This file is compiled twice into the library (kaldi-decoder_amd/Makefile): as it stands -- the
+// LARGE geometry: one 768-thread workgroup per CU with the whole CU's LDS, the geometry every
+// frame fits -- and with -DKD_GEOM_SMALL: 256 threads, a third of the LDS, three workgroups to a
+// CU, whose chains of dependent round trips overlap (round 5 measured 1.7-1.8 x on workloads of
+// small frames, and a loss on frames that want the CU's LDS).  A call launches both kernels side
+// by side on disjoint CUs and utterances change hands at frame boundaries (RunUtterance,
+// SearchKernel; kd_device.h SchedCtl).  Everything below is in an anonymous namespace: the two
+// copies share nothing but the launchers' names, which differ.
+#ifdef KD_GEOM_SMALL
+#define KD_GEOM_KIND 0
+#ifndef KD_BLOCK
+#define KD_BLOCK 256
+#endif
+#ifndef KD_LOG2_SLOTS
+#define KD_LOG2_SLOTS 11
+#endif
+#ifndef KD_T1_FRONT
+#define KD_T1_FRONT 256
+#endif
+#ifndef KD_WG_PER_CU
+#define KD_WG_PER_CU 3
+#endif
+// (the lattice tail's collector keeps its tables in the LDS key array: kd_lattice_tail.h)
+#ifndef KD_MAX_PIECES
+#define KD_MAX_PIECES 1536
+#endif
+#ifndef KD_COLLECT_FRAMES
+#define KD_COLLECT_FRAMES 64
+#endif
+#else
+#define KD_GEOM_KIND 1
+#endif
+
+#ifdef KD_GEOM_SMALL
+#define SearchKernel SearchKernelSmall  // (one name per geometry in traces and code-object listings)
+#endif
+
 namespace kd {
 namespace {
+
+constexpr int kKind = KD_GEOM_KIND;  // kKindSmall / kKindLarge (kd_device.h)
+static_assert(KD_NUM_STATS + kProfSlots <= kStatStride, "a row of counters");
 
 #ifndef KD_BLOCK
 #define KD_BLOCK 768
@@ -125,10 +165,7 @@ constexpr int kLog2Slots = KD_LOG2_SLOTS;
 constexpr int kSlots = 1 << kLog2Slots;
 constexpr int kLdsFillLimit = kSlots * 3 / 4;
 constexpr int kVmax = KD_VMAX;  // log-likelihood row staged in LDS when V <= kVmax
-// the waves a four-wave team leaves idle fetch the next frame's row meanwhile
-constexpr int kNarrowLanes = 256;
-constexpr int kLlLanes = KD_BLOCK - kNarrowLanes, kLlRegs = (kVmax + kLlLanes - 1) / kLlLanes;
-// ... a whole-workgroup team carries it in registers through the emitting filter
+// the next frame's row is carried in registers through the emitting filter
 constexpr int kPfRegs = (kVmax + KD_BLOCK - 1) / KD_BLOCK;
 #ifndef KD_SMALL_DEG
 #define KD_SMALL_DEG 4
@@ -179,25 +216,6 @@ constexpr int kBigGroup = KD_BIG_GROUP;  // ... in the big tiers' filter (BigLoo
 constexpr int kT1Log2 = kLog2Slots - 1;
 constexpr int kT1Slots = 1 << kT1Log2;
 constexpr int kT1Front = KD_T1_FRONT;
-// ... of which frames up to this size are run by FOUR waves, one per SIMD, while the other
-// eight execute nothing but the team's barriers (RunUtterance: the quiet waves' loop).  A frame
-// of a handful of tokens is a chain of two dozen phases that costs 23-25 k cycles whether it
-// holds 3 tokens or 100 (tools/prof_sizes.py) -- and what it is made of is INSTRUCTION ISSUE:
-// every one of the twelve waves walks the frame's whole control path (~1.4 k vector
-// instructions a frame, nearly all of them finding nothing to do), three waves share a SIMD,
-// and a SIMD issues one vector instruction in four cycles: 3 x 1.4 k x 4 = 17 k cycles.  (Round
-// 5 found it by giving the CU more workgroups: three 256-thread workgroups per CU decode a
-// beam-9 workload -- 6 tokens a frame -- 1.8 x as fast as one of 768 threads, and lose at beam
-// 15, where the frames that hold the cycles want the whole CU's LDS.)  With four waves the SIMD
-// issues one wave's instructions; the quiet waves cost it three instructions a barrier.  What
-// did NOT work: ONE wave (round 5: frames of up to 4 / 8 / 16 / 64 tokens on one wave 36.7 /
-// 35.6 / 35.5 / 35.0 M audio frames/s against 38.4 M -- one wave walks the frame's independent
-// gathers one round trip after the other), and (until round 3) four waves that synchronised
-// through an LDS counter and spun on it.
-#ifndef KD_T1_NARROW
-#define KD_T1_NARROW 0
-#endif
-constexpr int kT1Narrow = KD_T1_NARROW;
 constexpr int kQL = kT1Slots / 2;
 #ifndef KD_T1_SOFTQ
 #define KD_T1_SOFTQ (3 * (1 << (KD_LOG2_SLOTS - 2)))  // three times the LDS part of the queue (kQL)
@@ -284,7 +302,6 @@ struct Shared {
   float top_a0[kWaves], top_a1[kWaves];
   int32_t top_i0[kWaves];
   int32_t top_valid;            // ... have been noted for the row in `ll` (0: the frame does without the index)
-  int32_t bar_final;            // a team's frame: the number of its last barrier (0: not known yet)
   int32_t alloc_ok;             // result of the last chunk allocation (0 ok, else a KD_UTT_* bit)
   // what a tier-1 frame leaves for the waves that sat it out, by frame parity:
   // result, new frontier (size, arena base), and what a replay in the big table needs
@@ -405,6 +422,14 @@ __device__ __forceinline__ ArcRec LoadArcRecIf(const ArcPacked *base, uint32_t i
   return LoadArcRec(base, on ? i : safe);
 }
 
+// The input label of arc `aidx` as a column of a row that is read IN PLACE (rows of graphs with
+// escaped labels are never in LDS: kd_device.h kIlabelEscape).
+__device__ __forceinline__ int32_t FullIlabel(CParams &p, const ArcRec &a, uint32_t aidx) {
+  int32_t il = a.ilabel;
+  if (il == kIlabelEscape) il = ToG(p.big_ilabel)[aidx];
+  return il;
+}
+
 // Per-frame, per-lane work counters, folded into LDS at the end of the frame.
 struct Counters {
   int tokens_expanded = 0, eps_exp = 0, arcs_scanned = 0, eps_arcs = 0;
@@ -454,17 +479,14 @@ __device__ __forceinline__ void TableBarrier() {
   if constexpr (LDS) LdsBarrier(); else __syncthreads();
 }
 
-// The threads that run a frame: the whole workgroup, or (a frame of few tokens) its first
-// waves only -- one per SIMD -- while the other waves do nothing but keep the team company at
-// its barriers (QuietWaves below).  Either way a barrier is the hardware's s_barrier; a team
-// counts the barriers it passes, so that the quiet waves know which one is the last.
+// The threads that run a frame: the whole workgroup.  (Rounds 3-5 could hand a frame of few
+// tokens to the first four waves while the other eight executed only its barriers,
+// KD_T1_NARROW: never faster, never shipped -- docs/HISTORY.md, round 6 took it out.)
 struct Team {
-  int nt;    // threads tid < nt take part; a multiple of 64
-  int &gen;  // barriers this wave has passed since the frame began
+  static constexpr int nt = kBlock;
   // LDS traffic only, or (with_global) global stores too
   __device__ __forceinline__ void Sync(bool with_global) const {
     if (with_global) __syncthreads(); else LdsBarrier();
-    ++gen;
   }
 };
 
@@ -1046,7 +1068,7 @@ struct FrameCtx {
 // token's cost, `aux` the lattice decoders' acoustic cost (emitting) / source cost
 // (epsilon).  (SimpleDecoder's emitting arcs are scored in FilterArc.)
 template <bool EPS, int M>
-__device__ __forceinline__ bool ScoreArc(const FrameCtx<M> &c, const ArcRec &a, double csrc,
+__device__ __forceinline__ bool ScoreArc(const FrameCtx<M> &c, const ArcRec &a, uint32_t aidx, double csrc,
                                          unsigned long long seen_min, double &nc, float &aux) {
   aux = 0.f;
   if constexpr (EPS) {
@@ -1060,7 +1082,7 @@ __device__ __forceinline__ bool ScoreArc(const FrameCtx<M> &c, const ArcRec &a, 
     nc = csrc + a.weight;     // faster-decoder.h:134
     return !(nc > c.cutoff);  // faster-decoder.cc:92
   } else {
-    const float ll = c.ll_in_lds ? c.s.ll[a.ilabel - 1] : c.ll_row[a.ilabel - 1];
+    const float ll = c.ll_in_lds ? c.s.ll[a.ilabel - 1] : c.ll_row[FullIlabel(c.p, a, aidx) - 1];
     if (c.lattice) {
       // lattice-simple-decoder.cc:383-390: float, cur + ac + graph
       const float ac_cost = -ll, cur_cost = static_cast<float>(csrc),
@@ -1131,7 +1153,7 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
     // simple-decoder.cc:167-176.  Two passes: the first only finds the minimum
     // total cost, the second queues what is below min + beam.  The token stores
     // prev.cost + (weight + ac) with the float sum first (simple-decoder.h:99).
-    const float ll = c.ll_in_lds ? s.ll[a.ilabel - 1] : c.ll_row[a.ilabel - 1];
+    const float ll = c.ll_in_lds ? s.ll[a.ilabel - 1] : c.ll_row[FullIlabel(c.p, a, aidx) - 1];
     const float acoustic_cost = -ll;
     const double total_cost = csrc + a.weight + acoustic_cost;
     if (c.min_only) {
@@ -1143,7 +1165,7 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
     nc = csrc + (a.weight + acoustic_cost);
     aux = acoustic_cost;
   } else {
-    keep = ScoreArc<EPS>(c, a, csrc, seen_min, nc, aux);
+    keep = ScoreArc<EPS>(c, a, aidx, csrc, seen_min, nc, aux);
   }
   if (keep) {
     const unsigned long long nk = CK<M>(nc);
@@ -1253,7 +1275,7 @@ __device__ __forceinline__ void ScoreBatchBig(const FrameCtx<M> &c, const ArcRec
       aux[g] = 0.f;
       if (on[g]) {
         double nc;
-        keep[g] = ScoreArc<EPS>(c, ar[g], cst[g], seen, nc, aux[g]);
+        keep[g] = ScoreArc<EPS>(c, ar[g], static_cast<uint32_t>(aidx[g]), cst[g], seen, nc, aux[g]);
         nk[g] = CK<M>(nc);
       }
       bal[g] = __ballot(keep[g]);
@@ -1404,7 +1426,7 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
   [[maybe_unused]] int t_l0 = 0;
   [[maybe_unused]] bool idx_on = false;
   if constexpr (!EPS && M != 2 && KD_LABEL_INDEX != 0) {
-    idx_on = c.ll_in_lds && c.adaptive_beam >= 0.0f && Uni(s.top_valid) != 0;
+    idx_on = c.ll_in_lds && c.adaptive_beam > 0.0f && p.emit_w_min == p.emit_w_min && Uni(s.top_valid) != 0;
     if (idx_on) LoadRowTop(s, t_m0, t_m1, t_l0);
   }
   // (the two epsilon worklists -- c.q_cap words, unused until the inserts -- as 16-byte notes)
@@ -1734,13 +1756,10 @@ __device__ __forceinline__ void Insert(const FrameCtx<M> &c, const Table<LDS> &t
 // Out of line (round 5): inlined, its two copies held 50 of the kernel's scratch reloads and
 // their registers in the frame loop of every decode, and it runs only when max_active /
 // min_active bind.  (The LDS block is reached through Lds(): a pointer argument would be flat.)
-constexpr int kSelectKthBarriers = 16;  // (four passes of four: a team's caller counts them)
 template <bool FRONT_LDS>
-__device__ __noinline__ float SelectKth(const double *tok_cost, long long base_in, int n_in, int k,
-                                        int team_threads) {
+__device__ __noinline__ float SelectKth(const double *tok_cost, long long base_in, int n_in, int k) {
   Shared &s = Lds();
-  int gen_here = 0;  // (the caller's count lives in a register: no address of it comes here)
-  const Team tm{team_threads, gen_here};
+  const Team tm{};
   const int tid = threadIdx.x, lane = tid & 63;
   uint32_t prefix = 0, pmask = 0;
   int kk = k;
@@ -1838,8 +1857,7 @@ __device__ __forceinline__ void GetCutoff(FrameCtx<M> &c, const Team &tm) {
   const int n_lt = Uni(s.f_nlt), n_le = Uni(s.f_nle);
   // tmp_array_[k] < x  <=>  #{v < x} >= k+1 ;  tmp_array_[k] > x  <=>  #{v <= x} <= k
   if (c.n_in > p.max_active && static_cast<long long>(n_lt) >= static_cast<long long>(p.max_active) + 1) {
-    const double max_active_cutoff = SelectKth<FRONT_LDS>(p.tok_cost, c.base_in, c.n_in, p.max_active, tm.nt);  // :297-309
-    tm.gen += kSelectKthBarriers;
+    const double max_active_cutoff = SelectKth<FRONT_LDS>(p.tok_cost, c.base_in, c.n_in, p.max_active);  // :297-309
     c.adaptive_beam = max_active_cutoff - best_cost + p.beam_delta;
     c.weight_cutoff = max_active_cutoff;
     return;
@@ -1850,8 +1868,7 @@ __device__ __forceinline__ void GetCutoff(FrameCtx<M> &c, const Team &tm) {
   if (c.n_in > p.min_active) {             // :311-323
     if (p.min_active == 0) min_active_cutoff = best_cost;
     else if (n_le <= p.min_active) {
-      min_active_cutoff = SelectKth<FRONT_LDS>(p.tok_cost, c.base_in, c.n_in, p.min_active, tm.nt);
-      tm.gen += kSelectKthBarriers;
+      min_active_cutoff = SelectKth<FRONT_LDS>(p.tok_cost, c.base_in, c.n_in, p.min_active);
     }
   } else {
     min_active_cutoff = __longlong_as_double(0x7FF0000000000000ll);
@@ -1880,8 +1897,7 @@ __device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
     c.weight_cutoff = __longlong_as_double(0x7FF0000000000000ll);
     c.adaptive_beam = p.beam;
   } else {
-    int whole_gen = 0;
-    GetCutoff<false>(c, Team{kBlock, whole_gen});
+    GetCutoff<false>(c, Team{});
   }
   KD_LAP(s, 1);
   // Bound the next cutoff from the best token's arcs first (:176-189); it only
@@ -1892,7 +1908,8 @@ __device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
     const double bcost = s.best_cost;
     for (int a = tid; a < bdeg; a += kBlock) {
       const ArcRec arc = LoadArcRec(p.arcs, static_cast<uint32_t>(babeg + a));
-      const float ll = c.ll_in_lds ? s.ll[arc.ilabel - 1] : c.ll_row[arc.ilabel - 1];
+      const float ll = c.ll_in_lds ? s.ll[arc.ilabel - 1]
+                                   : c.ll_row[FullIlabel(p, arc, static_cast<uint32_t>(babeg + a)) - 1];
       const float ac_cost = -1 * ll;
       const unsigned long long k =
           c.lattice ? CK<M>(static_cast<double>(static_cast<float>(bcost) + ac_cost + arc.weight))
@@ -2331,9 +2348,9 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
 // A small frame is a chain of dependent round trips -- a handful to memory, a few dozen
 // to LDS -- that most of the workgroup's waves only watch (two thirds of a wave's cycles
 // are barrier waits: profiles/r05_search_counters.json); a large one is bound by the
-// scattered requests it issues.  The frame can be run by a team of four waves (one per
-// SIMD) while the others execute nothing but its barriers (KD_T1_NARROW; measured: no
-// faster, off); the whole workgroup runs it as shipped.
+// scattered requests it issues.  What shortens the chain's share of a CU's time is another
+// utterance on the same CU: the small geometry (KD_GEOM_SMALL) runs these frames three
+// workgroups to a CU.
 //
 // Same results as FrameFront + FrameBack<true>.  Returns 0, 1 (does not fit:
 // the caller replays the queue in the big table), 2 (the queue overflowed: the
@@ -2477,7 +2494,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
           aux[g] = 0.f;
           if (on[g]) {
             double nc;
-            keep[g] = ScoreArc<EPS>(c, ar[g], cst[g], seen, nc, aux[g]);
+            keep[g] = ScoreArc<EPS>(c, ar[g], static_cast<uint32_t>(aidx[g]), cst[g], seen, nc, aux[g]);
             nk[g] = CK<M>(nc);
           }
           bal[g] = __ballot(keep[g]);
@@ -2493,7 +2510,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
         aux[g] = 0.f;
         if (on[g]) {
           double nc;
-          keep[g] = ScoreArc<EPS>(c, ar[g], cst[g], seen, nc, aux[g]);
+          keep[g] = ScoreArc<EPS>(c, ar[g], static_cast<uint32_t>(aidx[g]), cst[g], seen, nc, aux[g]);
           nk[g] = CK<M>(nc);
         }
         bal[g] = __ballot(keep[g]);
@@ -2614,17 +2631,18 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
 #pragma unroll
   for (int k = 0; k < kPfRegs; ++k) {
     const int v = tid + k * kBlock;
-    ll_next[k] = have_next && nt == kBlock && v < p.num_cols ? next_row[v] : 0.0f;
+    ll_next[k] = have_next && v < p.num_cols ? next_row[v] : 0.0f;
   }
 #endif
   for (int w = tid; w < kMaskWords; w += nt) wlmask[w] = 0;  // worklist 0 collects the emitting insert's tokens
   c.run_min = kCostInf<M>;
   GetCutoff<true>(c, tm);
   KD_LAP(s, 1);
-  // (workgroup-uniform; a negative adaptive beam -- beam_delta below zero -- would let a bound
-  // at the cutoff hide the frame's minimum)
+  // (workgroup-uniform; an adaptive beam of zero or less -- beam_delta at or below zero with
+  // max_active binding -- would let a bound at the cutoff hide the frame's minimum; a graph
+  // with a NaN emitting weight has no lowest weight to bound with)
   const bool idx_frame = KD_LABEL_INDEX != 0 && M != 2 && n_in >= kIdxMinFront && c.ll_in_lds &&
-                         c.adaptive_beam >= 0.0f && Uni(s.top_valid) != 0;
+                         c.adaptive_beam > 0.0f && p.emit_w_min == p.emit_w_min && Uni(s.top_valid) != 0;
   // (this frame's lowest and second-lowest acoustic costs, the likeliest label; what each of this
   // lane's tokens found in its state's label index)
   constexpr int kIdxSlots = (kT1Front + kBlock - 1) / kBlock;
@@ -2702,9 +2720,11 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
           const ArcRec ar = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg) + IdxKeyOffset(found));
           double nc;
           float aux;
-          ScoreArc<false>(c, ar, cst, kCostInf<M>, nc, aux);
+          // (only a cost that is a number and below +infinity bounds anything: an arc whose
+          // weight is NaN is never kept by the reference's test either -- faster-decoder.cc:211)
+          const bool is_cost = ScoreArc<false>(c, ar, 0u, cst, kCostInf<M>, nc, aux);  // (an index frame: the row is in LDS)
           const unsigned long long nk = CK<M>(nc);
-          if (nk < c.run_min) c.run_min = nk;
+          if (is_cost && nk < c.run_min) c.run_min = nk;
           cnt.arcs_skipped -= 1;  // (an arc read: `arcs_skipped` is scanned minus read)
         }
       }
@@ -2797,7 +2817,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
 #pragma unroll
   for (int k = 0; k < kPfRegs; ++k) {
     const int v = tid + k * kBlock;
-    ll_next[k] = have_next && nt == kBlock && v < p.num_cols ? next_row[v] : 0.0f;
+    ll_next[k] = have_next && v < p.num_cols ? next_row[v] : 0.0f;
   }
 #endif
   item_loop(EpsNo{});
@@ -2808,7 +2828,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // the emitting filter is done with this frame's log-likelihood row: the next
   // frame's row (fetched into registers when this frame began) takes its place
   const int q_emit = Uni(s.q_n);
-  if (have_next && nt == kBlock) {
+  if (have_next) {
 #pragma unroll
     for (int k = 0; k < kPfRegs; ++k) {
       const int v = tid + k * kBlock;
@@ -3051,7 +3071,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   // The new frontier's state records (at most kNextRecs tokens per lane when the next
   // frame is a tier-1 frame): requested here, used when the frame ends -- the gather
   // overlaps the passes in between.
-  constexpr int kNextRecs = (kT1Front + kBlock - 1) / kBlock;  // (a four-wave team: see the end of the frame)
+  constexpr int kNextRecs = (kT1Front + kBlock - 1) / kBlock;
   ArcRange next_rec[kNextRecs];
   bool next_on[kNextRecs];
   {
@@ -3099,7 +3119,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
           s.it_abeg[i] = static_cast<int32_t>(static_cast<uint32_t>(ck));
           s.it_deg[i] = static_cast<int32_t>(emit);
         } else {
-          s.it_deg[i] = -1;  // (looked up: next_rec, or the four-wave team's pass at the end)
+          s.it_deg[i] = -1;  // (looked up: next_rec)
         }
       }
     }
@@ -3197,17 +3217,6 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       s.it_deg[tid + j * nt] = next_rec[j].emit_end - next_rec[j].arc_begin;
     }
   }
-  if (nt != kBlock && next_small) {
-    // a four-wave team's frontier of more than kNextRecs tokens per lane (rare: such a frame
-    // starts from a handful of tokens): the rest of the records, fetched here
-    for (int i = tid + kNextRecs * nt; i < n_out; i += nt) {
-      if (M != 1 || s.it_deg[i] < 0) {
-        const ArcRange r = LoadArcRange(p.states, s.it_src[i]);
-        s.it_abeg[i] = r.arc_begin;
-        s.it_deg[i] = r.emit_end - r.arc_begin;
-      }
-    }
-  }
   // Everything below that READS the frame's counters (n_emit_fin, n_eps_fin, best_next) and
   // the reset of those counters for the next frame are done by lanes of ONE wave, the first:
   // within a wave LDS operations execute in program order, between waves only a barrier
@@ -3271,7 +3280,7 @@ template <int M>
 __device__ __forceinline__ void InitCtx(FrameCtx<M> &c, CParams &p) {
   // the spill table, the candidate queue, the live list and the worklists belong to the
   // WORKGROUP (they are empty between frames), not to the utterance it is decoding
-  const long long gslots = 1ll << p.g_log2_slots, wg = blockIdx.x;
+  const long long gslots = 1ll << p.g_log2_slots, wg = p.sched.wg_base + blockIdx.x;
   c.wl0 = ToG(p.g_wl) + (2ll * wg) * gslots;
   c.wl1 = ToG(p.g_wl) + (2ll * wg + 1) * gslots;
   c.live = ToG(p.g_used) + wg * gslots;
@@ -3305,7 +3314,7 @@ __device__ __noinline__ uint32_t FrameBackSpill(CParams *pp, int utt, long long 
   Counters cnt;
   cnt.tokens_expanded = n_expanded;
   cnt.arcs_scanned = n_arcs;
-  const long long gslots = 1ll << p.g_log2_slots, wg = blockIdx.x;
+  const long long gslots = 1ll << p.g_log2_slots, wg = p.sched.wg_base + blockIdx.x;
   // The table is as large as the frame needs, not as large as it could be: a frame of
   // 8 k tokens hashes into 32 k slots (512 KiB of key / cost / arc words, which stay in
   // the XCD's L2) instead of scattering its atomics over all 2^17..2^19 slots (2-8 MiB:
@@ -3313,8 +3322,11 @@ __device__ __noinline__ uint32_t FrameBackSpill(CParams *pp, int utt, long long 
   // round clears shrinks with it.  The emitting candidates bound the emitting tokens;
   // the epsilon closure may add more: a frame that outgrows the guess runs again in the
   // whole table.
-  int lg = 14;
-  while ((1ll << lg) * 4 < static_cast<long long>(KD_GT_SIZE_X4) * q_emit && lg < p.g_log2_slots) ++lg;
+  // (the worklist bitmask of a global table lives in the LDS table's cost words: 64 slots a word)
+  constexpr int kMaxLg = kLog2Slots + 6;
+  const int lg_max = p.g_log2_slots < kMaxLg ? p.g_log2_slots : kMaxLg;
+  int lg = 14 < lg_max ? 14 : lg_max;
+  while ((1ll << lg) * 4 < static_cast<long long>(KD_GT_SIZE_X4) * q_emit && lg < lg_max) ++lg;
   uint32_t r;
   while (true) {
     Table<false> tg{s, ToG(p.g_slot) + 4 * wg * gslots, reinterpret_cast<uint32_t *>(s.cost),
@@ -3333,10 +3345,10 @@ __device__ __noinline__ uint32_t FrameBackSpill(CParams *pp, int utt, long long 
                                                                    : static_cast<int>(tg.FillLimit());
       ClearLive<false>(c, tg, used);
     }
-    if (r != kRetry || lg == p.g_log2_slots) break;
+    if (r != kRetry || lg == lg_max) break;
     // once more, in the whole table (the queue's emitting part is intact; its
     // destination words now hold slots of the table just wiped: replay from the arcs)
-    lg = p.g_log2_slots;
+    lg = lg_max;
     if (threadIdx.x == 0) {
       s.q_n = q_emit;
       s.n_live = 0;
@@ -3480,8 +3492,54 @@ __device__ __forceinline__ void NormalizeRow(Shared &s, int V) {
 // the frames up to the utterance's target, then -- lattice decoders, when asked -- the
 // tail: ComputeFinalCosts, FinalizeDecoding's backward prune and GetRawLattice into the
 // output pool (kd_lattice_tail.h), all while the utterance's LDS is still this workgroup's.
+// What a call of RunUtterance ends with: the utterance is where it was sent (or stopped), or it
+// changes hands -- the frame loop's state is in UttResume and the caller queues it for the other
+// kind of workgroup.
+constexpr int kSegFinished = 0, kSegToSmall = 1, kSegToLarge = 2;
+// how the utterance came to this workgroup
+constexpr int kTakeFresh = 0, kTakeResumed = 1, kTakeStolen = 2;  // (stolen: a large workgroup, from the small queue)
+
+__device__ __forceinline__ uint32_t AgentLoad(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the XCD this workgroup runs on (HW_REG_XCC_ID): its queues are that XCD's
+__device__ __forceinline__ int ThisXcd() {
+  return static_cast<int>(Uni(__builtin_amdgcn_s_getreg(20 | (31 << 11)))) & (kMaxXcd - 1);
+}
+__shared__ int kd_work_item, kd_work_take, kd_progressed, kd_decision;
+// Workgroups of the other kind have started on this XCD (they stay until the launch ends).
+// Call from ONE lane: the words read here change under the launch's feet, and a workgroup's
+// waves must not come to different conclusions (Decide).
+__device__ __forceinline__ bool OtherKindRuns(CParams &p) {
+  return AgentLoad(&p.sched.ctl->n_reg[ThisXcd()][1 - kKind]) != 0u;
+}
+// The frontier's size says the next frame is the other kind's: does the utterance go?  Not
+// before this workgroup has run a frame or a prune of it (two workgroups must not pass an
+// utterance back and forth), not when there is nobody to take it, and a large workgroup that
+// took it from the small queue because nothing waited for its own kind keeps it while that is
+// still so.  Call from ONE lane.
+__device__ __forceinline__ bool HandOver(CParams &p) {
+  if (kd_progressed == 0) return false;
+  const int xcd = ThisXcd();
+  if (AgentLoad(&p.sched.ctl->n_reg[xcd][1 - kKind]) == 0u) return false;
+  if (kKind == kKindLarge && kd_work_take == kTakeStolen) {
+    const SchedQueue *q = &p.sched.ctl->q[xcd][kKindLarge];
+    return static_cast<int32_t>(AgentLoad(&q->tail) - AgentLoad(&q->head)) > 0;
+  }
+  return true;
+}
+// One lane's answer for the whole workgroup (every wave calls; two barriers).
+template <class F>
+__device__ __forceinline__ bool Decide(F f) {
+  if (threadIdx.x == 0) kd_decision = f() ? 1 : 0;
+  LdsBarrier();
+  const bool r = Uni(kd_decision) != 0;
+  LdsBarrier();  // (read by every wave before the word is written again)
+  return r;
+}
+
 template <int M>
-__device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int utt) {
+__device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt, const bool resumed) {
   const int tid = threadIdx.x;
   constexpr int KD_BUCKET = kBucketBig;
   (void)KD_BUCKET;
@@ -3491,24 +3549,44 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   InitCtx(c, p);
 
   UttCtl ud;
-  ud.ll = reinterpret_cast<const float *>(Uni(reinterpret_cast<unsigned long long>(ToG(p.utt)[utt].ll)));
-  ud.offset = Uni(ToG(p.utt)[utt].offset);
-  ud.target = Uni(ToG(p.utt)[utt].target);
-  ud.flags = Uni(ToG(p.utt)[utt].flags);
-  const bool do_init = (ud.flags & kUttInit) != 0;
+  int frame, visited;
+  [[maybe_unused]] int prev_q_emit = 0;  // candidates the previous frame's emitting filter queued
+  unsigned long long f_best_in = 0;
+  c.base_in = 0;
+  c.n_in = 0;
+  if (resumed) {
+    // every word the loop needs, from ONE record in device memory, the loads issued together
+    const KD_G UttResume *rs = ToG(p.sched.resume) + utt;
+    ud.ll = reinterpret_cast<const float *>(Uni(reinterpret_cast<unsigned long long>(rs->ll)));
+    ud.offset = Uni(rs->offset);
+    ud.target = Uni(rs->target);
+    ud.flags = Uni(rs->flags);
+    frame = Uni(rs->frame);
+    c.base_in = Uni(rs->base_in);
+    c.n_in = Uni(rs->n_in);
+    prev_q_emit = Uni(rs->prev_q_emit);
+    f_best_in = Uni(rs->f_best);
+    visited = Uni(rs->visited);
+  } else {
+    ud.ll = reinterpret_cast<const float *>(Uni(reinterpret_cast<unsigned long long>(ToG(p.utt)[utt].ll)));
+    ud.offset = Uni(ToG(p.utt)[utt].offset);
+    ud.target = Uni(ToG(p.utt)[utt].target);
+    ud.flags = Uni(ToG(p.utt)[utt].flags);
+    frame = (ud.flags & kUttInit) ? -1 : Uni(ToG(p.frames_decoded)[utt]);
+    visited = (ud.flags & kUttInit) ? -1 : Uni(ToG(p.mem)[utt].visited);
+  }
+  const bool do_init = !resumed && (ud.flags & kUttInit) != 0;
   // (an utterance that stopped for want of capacity is only sent back here after the
   // host has grown what was exhausted: the status word is output, not state)
   uint32_t err = 0u;
-  int frame = do_init ? -1 : Uni(ToG(p.frames_decoded)[utt]);
   const int target = ud.target;
   const bool search = err == 0 && frame < target;  // (otherwise only the tail has work)
-
   if (tid < KD_NUM_STATS) s.stat[tid] = 0;
   if (tid < 4) s.frame_cnt[tid] = 0;
   if (tid == 0) {
-    s.bar_final = 0;
     s.ud_ll = reinterpret_cast<unsigned long long>(ud.ll);
     s.ud_offset = ud.offset;
+    kd_progressed = 0;
   }
 #ifdef KD_PROFILE
   if (tid < kProfSlots) s.cyc[tid] = 0;
@@ -3519,8 +3597,6 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
 #endif
   if (search) FullClear<true>(tl, s);
 
-  c.base_in = 0;
-  c.n_in = 0;
   if (tid == 0) {
     KD_G UttMem *m = ToG(p.mem) + utt;
     if (do_init) {  // no chunk of any pool yet, nothing archived, nothing to recycle
@@ -3536,7 +3612,12 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     s.link_end = do_init ? 0 : m->link_end;
   }
   if (do_init && c.lattice && tid == 0) ToG(p.lat.finalized)[utt] = 0;
-  if (search && frame >= 0) {
+  bool best_stale = false;
+  if (resumed) {
+    // (the best token's arc range is not carried over: the big tiers look it up, FrontierStats)
+    if (tid == 0) s.f_best = f_best_in;
+    best_stale = true;
+  } else if (search && frame >= 0) {
     const long long fi = static_cast<long long>(utt) * (p.max_frames + 1) + frame;
     c.base_in = Uni(static_cast<long long>(ToG(p.frame_base)[fi]));
     c.n_in = Uni(static_cast<int>(ToG(p.frame_count)[fi]));
@@ -3548,8 +3629,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
   // a tier-1 frame), do the upper table halves hold tier-1 data, and is the best
   // token's arc range (the tier-2 prepass input) out of date.
   Table<true> t1{s, nullptr, s.bitmask, kT1Log2, kT1Slots - 1};
-  bool front_lds = false, upper_dirty = false, best_stale = false;
-  int gen = 0;  // team barriers this wave has passed
+  bool front_lds = false, upper_dirty = false;
   auto row_of = [&](int f) {
     return ToG(ud.ll) + static_cast<long long>(f - ud.offset) * p.row_stride;
   };
@@ -3572,17 +3652,31 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     const int w = WaveSumInt(v);
     if ((tid & 63) == 0 && w) atomicAdd(&s.ustat[stat], static_cast<unsigned long long>(w));
   };
-  int visited = do_init ? -1 : Uni(ToG(p.mem)[utt].visited);
-
-  [[maybe_unused]] int prev_q_emit = 0;  // candidates the previous frame's emitting filter queued
+  int seg = kSegFinished;
   while (err == 0 && frame < target) {
+    [[maybe_unused]] bool prune_due = false;
+    if constexpr (M == 1) prune_due = frame > 0 && frame % p.lat.prune_interval == 0 && frame - 1 > visited;
+    // ---- does the utterance change hands here?  (workgroup-uniform; sizes of the decode and the
+    // kinds of workgroups the launch has, never timings: which kind runs a frame changes nothing
+    // of what the frame computes)
+    if (p.sched.split != 0 && frame >= 0) {
+      bool go = false;
+      if constexpr (kKind == kKindLarge) go = c.n_in <= p.sched.mig_lo || (prune_due && p.sched.prune_small != 0);
+      else go = c.n_in > p.sched.mig_hi && !(prune_due && p.sched.prune_small != 0);
+      // (the rest of the decision is off the frames' path: it is reached once per hand-over)
+      if (go && Decide([&]() { return HandOver(p); })) {
+        seg = kKind == kKindLarge ? kSegToSmall : kSegToLarge;
+        break;
+      }
+    }
+    if (tid == 0) kd_progressed = 1;  // (read behind the frame's barriers)
     if constexpr (M == 1) {
       // PruneActiveTokens every prune_interval frames, BEFORE the frame is processed like
       // the reference's (lattice-simple-decoder.cc:57-59) -- so a call that resumes on a
       // multiple of the interval (streaming in chunks of 1, 5, 25, ... frames) performs the
       // prune its predecessor left pending.  Bounds what FinalizeDecoding will have to look
       // at and, with it, memory.
-      if (frame > 0 && frame % p.lat.prune_interval == 0 && frame - 1 > visited) {
+      if (prune_due) {
         __syncthreads();
         KD_LAP(s, 13);
         if (tid == 0) {  // (the collector takes archive chunks through the same cursors' owner)
@@ -3629,69 +3723,20 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     int q_emit = 0;
     bool filtered = false;  // the emitting filter already ran (tier 1 did not fit)
     if (small) {
-      // a small frame of few tokens is run by the first four waves alone
-      const Team tm{kT1Narrow > 0 && c.n_in <= kT1Narrow ? kNarrowLanes : kBlock, gen};
+      const Team tm{};
       const bool have_next = c.ll_in_lds && frame + 1 < target;
-      gen = 0;
-      if (tid < tm.nt) {
+      {
         const KD_G float *ll_next = row_of(have_next ? frame + 1 : frame);
         c.ll_row = row_of(frame);
-        // (a team: the number of its last barrier is not known yet -- written before its first
-        // barrier, read by the quiet waves behind it)
-        if (tm.nt != kBlock && tid == 0) s.bar_final = 0;
         if (!front_lds) LoadFront(c, tm);
         // (two copies of the frame on purpose: in each the compiler knows where the
         // log-likelihood row is, and the copy for rows held in LDS loses the branch --
         // and the wait for outstanding vector-memory operations -- per arc)
         if (c.ll_in_lds) r = SmallFrame(c, t1, frame, cnt, tm, ll_next, have_next);
         else r = SmallFrame(c, t1, frame, cnt, tm, ll_next, have_next);
-        if (tid == 0) {
-          s.ctl[frame & 1].r = r;
-          s.bar_final = gen + 1;  // (the barrier below)
-        }
-        LdsBarrier();  // the whole workgroup again: nobody reads this frame's row any more
-      } else {
-        // The quiet waves: they request the next frame's row, hold it in registers, and keep
-        // the team company at its barriers -- s_barrier counts every wave of the workgroup --
-        // until the barrier the team has announced as its last: three instructions a barrier
-        // instead of the frame's whole control path.
-        float ll_next[kLlRegs];
-        const KD_G float *row = row_of(have_next ? frame + 1 : frame);
-        Top2 top = Top2Empty();
-#pragma unroll
-        for (int k = 0; k < kLlRegs; ++k) {
-          const int v = tid - (kBlock - kLlLanes) + k * kLlLanes;
-          ll_next[k] = have_next && v < p.num_cols ? row[v] : 0.0f;
-          if (have_next && v < p.num_cols) Top2Add(top, ll_next[k], v);
-        }
-        top = WaveTop2(top);
-        int n_bar = 0;
-        do {
-          LdsBarrier();
-          ++n_bar;
-        } while (Uni(__hip_atomic_load(&s.bar_final, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != n_bar);
-        if (have_next) {
-#pragma unroll
-          for (int k = 0; k < kLlRegs; ++k) {
-            const int v = tid - (kBlock - kLlLanes) + k * kLlLanes;
-            if (v < p.num_cols) s.ll[v] = ll_next[k];
-          }
-          // (the new row's likeliest labels, by wave: the team's own share is empty)
-          if ((tid & 63) == 0) {
-            s.top_a0[tid >> 6] = top.a0;
-            s.top_a1[tid >> 6] = top.a1;
-            s.top_i0[tid >> 6] = top.i0;
-          }
-          if (tid == kNarrowLanes) {
-            s.top_valid = 1;
-            const Top2 none = Top2Empty();
-            s.top_a0[0] = none.a0;
-            s.top_a1[0] = none.a1;
-            s.top_i0[0] = none.i0;
-          }
-        }
+        if (tid == 0) s.ctl[frame & 1].r = r;
+        LdsBarrier();  // nobody reads this frame's row any more
       }
-      if (tm.nt != kBlock) LdsBarrier();  // the next frame's row is in place
       r = Uni(s.ctl[frame & 1].r);
       // (logits: the row the frame swapped in for the next one; a frame that is run again
       // below stages its rows afresh)
@@ -3776,7 +3821,18 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       row_to_lds(frame + 1);
       __syncthreads();
     }
-    if (r != 0) { err |= r; break; }
+    if (r != 0) {
+      if constexpr (kKind == kKindSmall) {
+        // A frame that outgrew what this geometry's tables hold (its global table's worklist mask
+        // lives in a third of the LDS) was not committed: it is a large workgroup's.
+        if (p.sched.split != 0 && r == KD_UTT_TABLE_FULL && Decide([&]() { return OtherKindRuns(p); })) {
+          seg = kSegToLarge;
+          break;
+        }
+      }
+      err |= r;
+      break;
+    }
 #ifdef KD_PROF_SIZE
     if (tid == 0) {
       int cls = 0;
@@ -3785,6 +3841,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
       s.cyc[12 + cls] += 1;
     }
 #endif
+    if (kKind == kKindSmall && frame >= 0 && tid == 0) s.stat[KD_STAT_SMALL_WG_FRAMES] += 1;
     frame++;
   }
 
@@ -3799,7 +3856,24 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     m->link_next = s.link_next;
     m->link_end = s.link_end;
     m->visited = visited;
+    if (seg != kSegFinished) {
+      // what the frame loop carries from frame to frame (everything else of the utterance is
+      // in global memory already); the utterance's UttCtl goes along so that the taker does
+      // not read pinned host memory again
+      KD_G UttResume *rs = ToG(p.sched.resume) + utt;
+      rs->ll = ud.ll;
+      rs->offset = ud.offset;
+      rs->target = ud.target;
+      rs->flags = ud.flags & ~kUttInit;
+      rs->frame = frame;
+      rs->base_in = c.base_in;
+      rs->n_in = c.n_in;
+      rs->prev_q_emit = prev_q_emit;
+      rs->f_best = s.f_best;
+      rs->visited = visited;
+    }
   }
+  if (tid == KD_STAT_HANDOVERS && seg != kSegFinished) s.stat[tid] += 1;
   if (tid < KD_NUM_STATS) {
     KD_G long long *st = ToG(p.stats) + static_cast<long long>(utt) * kStatStride;
     const long long was = do_init ? 0 : st[tid];
@@ -3812,6 +3886,7 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     cy[tid] = (do_init ? 0 : cy[tid]) + s.cyc[tid];
   }
 #endif
+  if (seg != kSegFinished) return seg;
   // ---- the tail (lattice decoders): the searching is done, the LDS is free
   UttOut o;
   o.frames_decoded = frames_done;
@@ -3852,9 +3927,36 @@ __device__ __forceinline__ void RunUtterance(CParams &p, Shared &s, const int ut
     }
   }
   if (tid == 0) p.out[utt] = o;
+  return kSegFinished;
 }
 
-__shared__ int kd_work_item;
+// ---- the queues of utterances that wait for a workgroup of one kind (kd_device.h, SchedCtl) ----
+// Rings of `ring_cap` words (utterance + 1; 0: empty), one per XCD and kind; an utterance is in
+// at most one of them, so a ring never holds more than `batch` entries.  Call from one lane.
+__device__ __forceinline__ uint32_t *SchedRing(CParams &p, int xcd, int kind) {
+  return p.sched.ring + static_cast<long long>(xcd * 2 + kind) * p.sched.ring_cap;
+}
+__device__ __forceinline__ void QueuePush(CParams &p, int xcd, int kind, int utt) {
+  const uint32_t pos = atomicAdd(&p.sched.ctl->q[xcd][kind].tail, 1u);
+  uint32_t *slot = SchedRing(p, xcd, kind) + (pos & static_cast<uint32_t>(p.sched.ring_cap - 1));
+  // (the slot's previous entry, a lap ago, has been taken long since: the loop is a formality)
+  while (atomicCAS(slot, 0u, static_cast<uint32_t>(utt) + 1u) != 0u) __builtin_amdgcn_s_sleep(2);
+}
+__device__ __forceinline__ int QueuePop(CParams &p, int xcd, int kind) {  // -1: nothing waits
+  SchedQueue *q = &p.sched.ctl->q[xcd][kind];
+  uint32_t h = AgentLoad(&q->head);
+  while (true) {
+    if (static_cast<int32_t>(AgentLoad(&q->tail) - h) <= 0) return -1;
+    const uint32_t seen = atomicCAS(&q->head, h, h + 1u);
+    if (seen == h) break;
+    h = seen;
+  }
+  uint32_t *slot = SchedRing(p, xcd, kind) + (h & static_cast<uint32_t>(p.sched.ring_cap - 1));
+  uint32_t v;
+  // (position h is this lane's alone; its entry may still be on its way)
+  while ((v = atomicExch(slot, 0u)) == 0u) __builtin_amdgcn_s_sleep(2);
+  return static_cast<int>(v) - 1;
+}
 
 template <int M>
 // (HIP's second bound is waves per SIMD: the workgroups sharing a CU spread over four)
@@ -3865,25 +3967,71 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
   Shared &s = Lds();
   (void)p_by_value;  // the only argument: it is the kernel-argument segment
   CParams &p = *(CParams *)__builtin_amdgcn_kernarg_segment_ptr();
-  // Persistent workgroups and a work queue: the launch has at most one workgroup per CU;
-  // each takes the next utterance of `order` (longest first) until none is left, so a CU
-  // that finishes a short utterance goes on with another one -- of any size of batch --
-  // instead of idling until the launch's slowest utterance is done.
+  // Persistent workgroups and a work queue: each takes the next utterance of `order` (longest
+  // first) until none is left, so a CU that finishes a short utterance goes on with another one
+  // -- of any size of batch -- instead of idling until the launch's slowest utterance is done.
+  // With two kinds of workgroups in the launch (sched.split) an utterance may leave a workgroup
+  // at a frame boundary for a queue of the other kind, and a workgroup first looks for an
+  // utterance that waits for its kind; the launch is over when every utterance is where it
+  // was sent.  The queues are per XCD (kd_device.h): this workgroup's is the one it RUNS on.
+  const bool split = p.sched.split != 0;
+  const int xcd = ThisXcd();
+  if (split && threadIdx.x == 0) atomicAdd(&p.sched.ctl->n_reg[xcd][kKind], 1u);
+  bool fresh_left = true;  // (lane 0's: positions of `order` may still be had)
   while (true) {
     __syncthreads();  // the previous utterance is finished by every wave
-    if (threadIdx.x == 0)
-      kd_work_item = static_cast<int>(atomicAdd(&p.ctl->work_ctr, 1u) - p.work_base);
+    if (threadIdx.x == 0) {
+      int item = -1, take = kTakeFresh;
+      while (true) {
+        if (split) {
+          int u = QueuePop(p, xcd, kKind);
+          if (u >= 0) { item = u; take = kTakeResumed; break; }
+        }
+        if (fresh_left) {
+          const int i = static_cast<int>(atomicAdd(&p.ctl->work_ctr, 1u) - p.work_base);
+          if (i < p.batch) { item = ToG(p.order)[i]; break; }
+          fresh_left = false;  // (one failed attempt per workgroup: the host counts on it)
+          if (!split) break;
+          continue;
+        }
+        if constexpr (kKind == kKindLarge) {
+          // nothing waits for a large workgroup: better a small frame on a whole CU than an idle CU
+          const int u = QueuePop(p, xcd, kKindSmall);
+          if (u >= 0) { item = u; take = kTakeStolen; break; }
+        }
+        if (AgentLoad(&p.sched.ctl->n_finished) >= static_cast<uint32_t>(p.batch)) break;
+        __builtin_amdgcn_s_sleep(64);
+      }
+      kd_work_item = item;
+      kd_work_take = take;
+      // what the utterance's previous workgroup stored is in this XCD's L2; this CU's L1 may
+      // hold older contents of those lines
+      if (take != kTakeFresh) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     __syncthreads();
-    const int item = Uni(kd_work_item);
-    if (item >= p.batch) break;
-    RunUtterance<M>(p, s, Uni(ToG(p.order)[item]));
+    const int item = Uni(kd_work_item), take = Uni(kd_work_take);
+    if (item < 0) break;
+    const int seg = RunUtterance<M>(p, s, item, take != kTakeFresh);
+    if (split) {
+      __syncthreads();  // every wave's stores of this utterance have left the CU (vmcnt(0))
+      if (threadIdx.x == 0) {
+        if (seg == kSegFinished) atomicAdd(&p.sched.ctl->n_finished, 1u);
+        else QueuePush(p, xcd, seg == kSegToSmall ? kKindSmall : kKindLarge, item);
+      }
+    }
   }
   // The last workgroup to leave tells the host where the pools' cursors stand (every
-  // other workgroup's allocations are behind its n_done increment).
+  // other workgroup's allocations are behind its n_done increment) and leaves the
+  // scheduler's words zero for the next launch.
   if (threadIdx.x == 0) {
     __threadfence_system();
     const uint32_t left = atomicAdd(&p.ctl->n_done, 1u) - p.done_base;
-    if (left == gridDim.x - 1) {
+    if (left == static_cast<uint32_t>(p.sched.total_wgs) - 1u) {
+      if (split) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(p.sched.ctl);
+        for (size_t i = 0; i < sizeof(SchedCtl) / 4; ++i)
+          __hip_atomic_store(w + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       HostTops t;
       t.tok_top = atomicAdd(&p.ctl->tok_top, 0ull);
       t.link_top = atomicAdd(&p.ctl->link_top, 0ull);
@@ -3897,9 +4045,17 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
 
 }  // namespace
 
-size_t SearchLdsBytes() { return sizeof(Shared); }
-int SearchMaxLdsCols() { return kVmax; }
-int SearchWorkgroupsPerCu() { return KD_WG_PER_CU; }
+#ifdef KD_GEOM_SMALL
+#define KD_EXPORT(name) name##Small
+#else
+#define KD_EXPORT(name) name
+#endif
+size_t KD_EXPORT(SearchLdsBytes)() { return sizeof(Shared); }
+int KD_EXPORT(SearchMaxLdsCols)() { return kVmax; }
+int KD_EXPORT(SearchWorkgroupsPerCu)() { return KD_WG_PER_CU; }
+#ifdef KD_GEOM_SMALL
+int SearchT1FrontSmall() { return kT1Front; }
+#endif
 
 namespace {
 template <int M>
@@ -3909,10 +4065,14 @@ hipError_t LaunchMode(const SearchParams &p, int workgroups, hipStream_t stream)
 }
 }  // namespace
 
-hipError_t LaunchSearch(const SearchParams &p, int workgroups, hipStream_t stream) {
+hipError_t KD_EXPORT(LaunchSearch)(const SearchParams &p, int workgroups, hipStream_t stream) {
   if (p.lattice) return LaunchMode<1>(p, workgroups, stream);
+#ifndef KD_ONLY_LATTICE  // (tools: a build of the lattice decoders' kernel alone compiles in a third of the time)
   if (p.simple) return LaunchMode<2>(p, workgroups, stream);
   return LaunchMode<0>(p, workgroups, stream);
+#else
+  return hipErrorNotSupported;
+#endif
 }
 
 }  // namespace kd

@@ -22,7 +22,7 @@ CAPACITY_NAMES = ("arena_tokens", "arena_links", "table_slots", "max_frames", "t
                   "links_used", "grow_events", "workgroups")
 STAT_NAMES = ("frames", "tokens_in", "tokens_expanded", "arcs_scanned", "arcs_kept",
               "tokens_out", "eps_arcs_scanned", "eps_expansions", "max_tokens", "spill_frames",
-              "links", "small_frames", "arcs_skipped", "index_probes")
+              "links", "small_frames", "arcs_skipped", "index_probes", "handovers", "small_wg_frames")
 
 # every symbol include/kd_hip.h declares
 SYMBOLS = (

@@ -339,6 +339,38 @@ def test_host_async_from_pinned_rows_that_are_refilled_at_once(oracle):
             _assert_same_path(paths[i], want[i], i)
 
 
+def test_host_async_from_pageable_rows_that_are_refilled_at_once(oracle):
+    """The same promise for PAGEABLE rows (plain numpy arrays), which the library does not
+    wait for itself (ADVICE rounds 4-5): HIP's copy out of pageable memory has read the rows
+    when it returns.  One matrix of the batch is pinned and sits where the library's few
+    pointer look-ups do not necessarily probe first: a call that holds ANY pinned matrix among
+    the probed ones must wait."""
+    import torch
+    g = synth.hl_graph(V=40, n_words=400, seed=3)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    B, T, V = 16, 400, 40
+    lps = [synth.make_logprobs(T, V, 190 + i, peak=6.0, lexicon=g["lexicon"]) for i in range(B)]
+    want = []
+    for lp in lps:
+        d = oracle.FasterDecoder(OG, beam=8.0, policy=1)
+        d.decode(lp)
+        want.append(d.get_best_path())
+    bt = cabi.Batch(G, max_batch=B, beam=8.0)
+    last_pinned = torch.from_numpy(lps[B - 1].copy()).pin_memory()
+    for rep in range(3):
+        rows = [lp.copy() for lp in lps]
+        if rep == 2:
+            last_pinned.copy_(torch.from_numpy(lps[B - 1]))
+            rows[B - 1] = last_pinned.numpy()
+        bt.decode_host(rows, sync=False)
+        for r in rows:
+            r.fill(-1e30)
+        bt.sync()
+        paths = bt.best_paths()
+        for i in range(B):
+            _assert_same_path(paths[i], want[i], i)
+
+
 def test_best_path_longer_than_the_staging_queue_grows_the_queue(oracle):
     """GetBestPath stages the path in the workgroup's candidate queue (2 x table_slots entries).
     A path of 1000 + 40 x 1001 arcs -- a chain of a thousand epsilon arcs walked by InitDecoding

@@ -137,6 +137,39 @@ FASTER_CASES = [
 ]
 
 # ---------------------------------------------------------------------------------------
+# Graph A with input labels that do not fit 20 bits (round 6).  The reference's loop takes any
+# int32 `arc.ilabel` (faster-decoder.cc:204-209); the GPU's arc record packs the label into 20
+# bits, whose largest value is an escape code into a side array of full labels
+# (kd_device.h kIlabelEscape).  Label 1 becomes 2^20 - 1 (the escape value itself: it must
+# go through the side array too), label 2 becomes 2^20 + 5; the matrix has 2^20 + 5 columns,
+# the two that matter holding graph A's log-likelihoods.  Tokens, costs and paths are graph
+# A's, the derivation above word for word; only the path's input labels change.
+BIG1, BIG2 = (1 << 20) - 1, (1 << 20) + 5
+
+
+def graph_a_big(finals=None):
+    relabel = {0: 0, 1: BIG1, 2: BIG2}
+    arcs = [(0, 1, 1, 10, 0.5), (0, 2, 2, 20, 1.0), (1, 3, 0, 30, 0.25), (1, 1, 1, 0, 0.125),
+            (2, 3, 1, 0, 0.0), (3, 3, 2, 40, 0.25)]
+    return synth.graph_from_arcs(4, 0, [(s, d, relabel[i], o, w) for s, d, i, o, w in arcs],
+                                 {3: 0.5} if finals is None else finals)
+
+
+def lp_a_big():
+    lp = np.full((2, BIG2), -100.0, np.float32)
+    lp[:, BIG1 - 1] = LP_A[:, 0]
+    lp[:, BIG2 - 1] = LP_A[:, 1]
+    return lp
+
+
+PATH_A_BIG = dict(PATH_A, ilabel=[BIG1, BIG1, 0])
+LAT_ARCS_BIG = {k: v[:4] + ({0: 0, 1: BIG1, 2: BIG2}[v[4]],) + v[5:] for k, v in {
+    "L0": (0, 0, 1, 1, 1, 10, 0.5, 1.0), "L1": (0, 0, 1, 2, 2, 20, 1.0, 2.0),
+    "L2": (1, 1, 1, 3, 0, 30, 0.25, 0.0), "L3": (1, 1, 2, 1, 1, 0, 0.125, 0.5),
+    "L4": (1, 2, 2, 3, 1, 0, 0.0, 0.5), "L5": (1, 3, 2, 3, 2, 40, 0.25, 4.0),
+    "L6": (2, 1, 2, 3, 0, 30, 0.25, 0.0)}.items()}
+
+# ---------------------------------------------------------------------------------------
 # LatticeSimpleDecoder on graph A, beam 16 (float costs, tot = cur + ac + graph,
 # lattice-simple-decoder.cc:383-385; epsilon tot = cur + graph, :170-172).  The tokens are
 # the FasterDecoder's above; every scored arc below the cutoff is a ForwardLink (:393-398,
@@ -251,6 +284,50 @@ def test_gpu_lattice_decoder_kat(lattice_beam, want):
     lat = lb.raw_lattices()[0]
     assert lat.arc_set() == {LAT_ARCS[k] for k in want}
     assert lat.final_set() == {(3, 0.5)}
+
+
+@pytest.mark.parametrize("policy", [0, 1])
+def test_oracle_input_labels_beyond_20_bits(oracle, policy):
+    lp = lp_a_big()
+    d = oracle.FasterDecoder(oracle.Graph(graph_a_big()), policy=policy, beam=16.0, min_active=0)
+    d.decode(lp)
+    s, c = d.tokens()
+    assert dict(zip(s.tolist(), c.tolist())) == FRONTIERS_A[2]
+    _check_path(d.get_best_path(True), PATH_A_BIG, (0.5, 0.0), policy)
+
+
+@pytest.mark.gpu
+def test_gpu_input_labels_beyond_20_bits():
+    """kd_graph_create refuses nothing the reference decodes except epsilon cycles of total
+    weight zero or less: labels of 2^20 - 1 and more."""
+    from kaldi_decoder import cabi
+    lp = lp_a_big()
+    G = cabi.Graph(graph_a_big())
+    bt = cabi.Batch(G, max_batch=1, beam=16.0, min_active=0)
+    bt.init_decoding()
+    for f, want in enumerate(FRONTIERS_A):
+        if f:
+            bt.advance_host([lp], max_num_frames=1)
+        s, c = bt.frame_tokens(0, f)
+        assert dict(zip(s.tolist(), c.tolist())) == want, f
+    assert bool(bt.reached_final()[0])
+    _check_path(bt.best_paths(True)[0], PATH_A_BIG, (0.5, 0.0), "big")
+    for lattice_beam, want in LATTICE_CASES:
+        lb = cabi.LatticeBatch(G, max_batch=1, beam=16.0, lattice_beam=lattice_beam, min_active=0)
+        lb.init_decoding()
+        lb.advance_host([lp])
+        assert lb.raw_lattices()[0].arc_set() == set(LAT_ARCS_BIG.values())
+        lb.finalize_decoding()
+        assert lb.final_relative_cost().tolist() == [0.75]
+        assert lb.raw_lattices()[0].arc_set() == {LAT_ARCS_BIG[k] for k in want}
+    sb = cabi.SimpleBatch(G, max_batch=1, beam=16.0)
+    sb.init_decoding()
+    sb.advance_host([lp])
+    _check_path(sb.best_paths(True)[0], PATH_A_BIG, (0.5, 0.0), "simple")
+    # a matrix one column short of the largest label is refused, as for any graph
+    with pytest.raises(RuntimeError, match="largest ilabel"):
+        bt.init_decoding()
+        bt.advance_host([lp[:, :BIG2 - 1].copy()])
 
 
 @pytest.mark.gpu
