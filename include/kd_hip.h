@@ -367,6 +367,29 @@ size_t kd_batch_device_bytes(const kd_batch *b);
  * was grown since creation, persistent workgroups per launch. */
 int kd_batch_capacity(const kd_batch *b, int64_t *out);
 
+/* How a call's utterances are dealt out on the chip (round 6).  A call of at least
+ * `min_batch` utterances is run by TWO kernels side by side on disjoint sets of CUs: "large"
+ * workgroups (one per CU, the CU's whole LDS) and "small" ones (three per CU); an utterance is
+ * handed from one kind to the other at a frame boundary when the frontier its next frame starts
+ * from crosses a threshold -- to a small workgroup at `mig_lo` tokens or fewer, to a large one
+ * above `mig_hi` (0 <= mig_lo <= mig_hi) -- and, with `prune_small`, PruneActiveTokens runs on the
+ * small kind.  Results do not depend on any of this (the reference runs every frame of an
+ * utterance in one thread: lattice-simple-decoder.cc:53-66, faster-decoder.cc:126-152).
+ * kd_batch_split_info: out[0..7] = split available (0: one kernel, as before round 6; the other
+ * values are then 0), CUs of the large kind, large workgroups, small workgroups, mig_lo, mig_hi,
+ * prune_small, min_batch.  kd_batch_set_split: a negative argument leaves that setting as it is;
+ * enable = 0 makes every later call of this batch a one-kernel call. */
+int kd_batch_split_info(const kd_batch *b, int32_t *out);
+/* Diagnostic: where the two kinds of workgroups spent their time, summed over this batch's split
+ * launches so far (shader-clock cycles of one lane per workgroup).  out[0..15], each a pair
+ * {small kind, large kind}: cycles looking for an utterance, taking one up (until its first
+ * frame starts), running frames / pruning / tail, in the queue operation that found it;
+ * utterances taken up fresh, resumed from a queue, taken from the other kind's queue; workgroups
+ * that ran. */
+int kd_batch_sched_profile(kd_batch *b, int64_t *out);
+int kd_batch_set_split(kd_batch *b, int32_t enable, int32_t min_batch, int32_t mig_lo, int32_t mig_hi,
+                       int32_t prune_small);
+
 #ifdef __cplusplus
 }
 #endif

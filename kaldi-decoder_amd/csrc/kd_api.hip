@@ -165,7 +165,8 @@ struct kd_batch {
   DevBuf<float> g_log_ac, g_log_gr;
   // ---- the two kinds of workgroups (kd_device.h SchedCtl): queues, the frame loop's state of an
   // utterance that changes hands, the CU-masked streams the two kernels run on
-  bool split_ok = false;          // the batch can run split launches
+  bool split_ok = false;          // the batch can run split launches ...
+  bool split_on = false;          // ... and does (kd_batch_set_split)
   int split_min_batch = 0;        // ... and does for calls of at least this many utterances
   int cus = 0, large_cus = 0;
   int wgs_single = 1, wgs_large = 0, wgs_small = 0;  // workgroups of an unsplit launch / of a split one, at most
@@ -173,6 +174,7 @@ struct kd_batch {
   SplitStreams split_streams;
   hipEvent_t ev_fork = nullptr, ev_join_l = nullptr, ev_join_s = nullptr;
   DevBuf<SchedCtl> sched_ctl;
+  DevBuf<SchedProf> sched_prof;
   DevBuf<uint32_t> sched_ring;
   DevBuf<UttResume> resume;
   int ring_cap = 1;
@@ -320,6 +322,7 @@ struct kd_batch {
     p.lat.out2 = out_ext;
     p.lat.out_cap = out_ext ? std::min<uint64_t>(out_cap, out_ext_cap) : out_cap;
     p.sched.ctl = sched_ctl.p;
+    p.sched.prof = sched_prof.p;
     p.sched.ring = sched_ring.p;
     p.sched.resume = resume.p;
     p.sched.ring_cap = ring_cap;
@@ -546,7 +549,7 @@ int Enqueue(kd_batch *b) {
                               std::to_string(SearchMaxLdsColsSmall()) + " columns");
   int wgs = 0;
   KD_HIP_TRY(hipEventRecord(b->ev0, b->stream));
-  if (b->split_ok && b->batch >= b->split_min_batch) {
+  if (b->split_ok && b->split_on && b->batch >= b->split_min_batch) {
     // Both kernels, each on its CU-masked stream, between a fork and a join on the batch's own
     // stream.  Either kernel can finish the call alone (a large workgroup runs any frame; a
     // small one hands a large frame over only to large workgroups that have started), so the
@@ -990,6 +993,7 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
     x = std::max(8, std::min(cus - 8, x));
     if (TakeSplitStreams(g->device, cus, x, &b->split_streams)) {
       b->split_ok = true;
+      b->split_on = true;
       b->large_cus = x;
       b->wgs_large = std::min<int>(max_batch, x);
       // (a few more than fit: the dispatcher does not deal them out evenly -- tools/ubench/cumask.hip
@@ -1041,6 +1045,8 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   if (b->split_ok) {
     while (b->ring_cap < max_batch) b->ring_cap *= 2;
     A(b->sched_ctl.Alloc(1));
+    A(b->sched_prof.Alloc(1));
+    if (e == hipSuccess) e = hipMemset(b->sched_prof.p, 0, sizeof(SchedProf));
     A(b->sched_ring.Alloc(static_cast<size_t>(kMaxXcd) * 2 * b->ring_cap));
     A(b->resume.Alloc(max_batch));
     if (e == hipSuccess) e = hipMemset(b->sched_ctl.p, 0, sizeof(SchedCtl));
@@ -1728,6 +1734,52 @@ int kd_batch_capacity(const kd_batch *b, int64_t *out) {
   out[5] = static_cast<int64_t>(std::min<uint64_t>(b->h_link_top, b->link_cap));
   out[6] = b->grow_events;
   out[7] = b->workgroups;
+  return KD_OK;
+}
+
+int kd_batch_split_info(const kd_batch *b, int32_t *out) {
+  if (!b || !out) return Fail(KD_E_INVALID, "bad argument");
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  if (!b->split_ok) return KD_OK;
+  out[0] = b->split_on ? 1 : 0;
+  out[1] = b->large_cus;
+  out[2] = b->wgs_large;
+  out[3] = b->wgs_small;
+  out[4] = b->mig_lo;
+  out[5] = b->mig_hi;
+  out[6] = b->prune_small;
+  out[7] = b->split_min_batch;
+  return KD_OK;
+}
+
+int kd_batch_sched_profile(kd_batch *b, int64_t *out) {
+  if (!b || !out) return Fail(KD_E_INVALID, "bad argument");
+  for (int i = 0; i < 16; ++i) out[i] = 0;
+  if (!b->split_ok) return KD_OK;
+  if (b->pending) {
+    if (int r = ReadBack(b)) return r;
+  }
+  static_assert(sizeof(SchedProf) == 16 * sizeof(int64_t), "sixteen counters");
+  KD_HIP_TRY(hipMemcpy(out, b->sched_prof.p, sizeof(SchedProf), hipMemcpyDeviceToHost));
+  return KD_OK;
+}
+
+int kd_batch_set_split(kd_batch *b, int32_t enable, int32_t min_batch, int32_t mig_lo, int32_t mig_hi,
+                       int32_t prune_small) {
+  if (!b) return Fail(KD_E_INVALID, "bad argument");
+  if (!b->split_ok) {
+    if (enable > 0) return Fail(KD_E_STATE, "this batch has no second kernel (SimpleDecoder, KD_SPLIT=0, or "
+                                            "CU-masked streams are not available)");
+    return KD_OK;
+  }
+  if (b->pending) (void)ReadBack(b);
+  const int hi = mig_hi >= 0 ? mig_hi : b->mig_hi, lo = mig_lo >= 0 ? mig_lo : std::min(b->mig_lo, hi);
+  if (hi < 1 || lo > hi) return Fail(KD_E_INVALID, "need 0 <= mig_lo <= mig_hi, mig_hi >= 1");
+  b->mig_hi = hi;
+  b->mig_lo = lo;
+  if (enable >= 0) b->split_on = enable != 0;
+  if (min_batch >= 1) b->split_min_batch = min_batch;
+  if (prune_small >= 0) b->prune_small = prune_small != 0 ? 1 : 0;
   return KD_OK;
 }
 

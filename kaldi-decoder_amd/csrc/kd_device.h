@@ -137,6 +137,14 @@ struct SchedCtl {
   uint32_t n_finished;           // utterances that have reached their target (or stopped) in this launch
   uint32_t pad[15];
 };  // all zero between launches: the last workgroup to leave a launch zeroes it
+// Where the workgroups' time went, summed over the launches of a batch (never reset; shader-clock
+// cycles of lane 0; kd_batch_sched_profile): per kind -- looking for an utterance / taking one
+// up (RunUtterance's entry to its first frame) / running its frames and tail, and the numbers of
+// utterances taken up fresh, resumed, stolen.
+struct SchedProf {
+  unsigned long long idle[2], setup[2], busy[2], wait_pop[2];
+  unsigned long long n_fresh[2], n_resumed[2], n_stolen[2], n_workgroups[2];
+};
 // what the frame loop carries across a frame boundary
 struct UttResume {
   const float *ll;                // the utterance's UttCtl, read from pinned host memory once per launch
@@ -152,6 +160,7 @@ struct UttResume {
 };
 struct SchedParams {
   SchedCtl *ctl;                  // device memory
+  SchedProf *prof;                // device memory
   uint32_t *ring;                 // [kMaxXcd][2][ring_cap] entries utt + 1 (0: empty)
   UttResume *resume;              // [batch]
   int32_t ring_cap;               // a power of two >= batch

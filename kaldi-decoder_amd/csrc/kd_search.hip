@@ -341,7 +341,7 @@ struct Shared {
   int lap_on, lap_pad;  // (KD_PROF_NMIN / KD_PROF_NMAX: only frames of that frontier size are timed)
 #endif
 };
-static_assert(sizeof(Shared) + 16 <= 163840 / KD_WG_PER_CU, "LDS budget (the block and the work-item word)");
+static_assert(sizeof(Shared) + 128 <= 163840 / KD_WG_PER_CU, "LDS budget (the block and the scheduler's words)");
 
 // The workgroup's LDS block.  Functions that are not inlined into the kernel reach
 // it through this (an LDS pointer passed as an argument would become a flat one).
@@ -1036,7 +1036,8 @@ template <int MODE>
 struct FrameCtx {
   static constexpr bool lattice = MODE == 1;
   static constexpr bool simple = MODE == 2;  // SimpleDecoder semantics
-  CParams &p;
+  CParams *pp;  // the launch parameters (kernel-argument segment); see KD_PHASE
+  __device__ __forceinline__ CParams &P() const { return *pp; }
   Shared &s;
   int utt;
   long long base_in;
@@ -1062,6 +1063,17 @@ struct FrameCtx {
   bool min_only;  // simple: first filter pass only finds the minimum total cost
 };
 
+// A phase boundary of a tier-1 frame: the launch parameters' pointer is made opaque, so that what
+// the compiler loads through it (scalar loads from the kernel-argument segment: pointers, options)
+// is loaded again in the phase that uses it instead of once per frame and held -- and spilled --
+// across all of them.
+#define KD_PHASE(c)                                                                          \
+  do {                                                                                       \
+    unsigned long long pv_ = reinterpret_cast<unsigned long long>((c).pp);                   \
+    asm volatile("" : "+v"(pv_));                                                            \
+    (c).pp = reinterpret_cast<CParams *>(Uni(pv_));                                           \
+  } while (0)
+
 // Scores one arc out of a token with cost `csrc`: the reference's test at
 // faster-decoder.cc:208-211 (emitting; `seen_min` is the lowest new cost seen so
 // far) or :90-95 (epsilon).  Returns whether the arc survives; `nc` is the new
@@ -1082,7 +1094,7 @@ __device__ __forceinline__ bool ScoreArc(const FrameCtx<M> &c, const ArcRec &a, 
     nc = csrc + a.weight;     // faster-decoder.h:134
     return !(nc > c.cutoff);  // faster-decoder.cc:92
   } else {
-    const float ll = c.ll_in_lds ? c.s.ll[a.ilabel - 1] : c.ll_row[FullIlabel(c.p, a, aidx) - 1];
+    const float ll = c.ll_in_lds ? c.s.ll[a.ilabel - 1] : c.ll_row[FullIlabel(c.P(), a, aidx) - 1];
     if (c.lattice) {
       // lattice-simple-decoder.cc:383-390: float, cur + ac + graph
       const float ac_cost = -ll, cur_cost = static_cast<float>(csrc),
@@ -1153,7 +1165,7 @@ __device__ __forceinline__ void FilterArc(const FrameCtx<M> &c, const ArcRec &a,
     // simple-decoder.cc:167-176.  Two passes: the first only finds the minimum
     // total cost, the second queues what is below min + beam.  The token stores
     // prev.cost + (weight + ac) with the float sum first (simple-decoder.h:99).
-    const float ll = c.ll_in_lds ? s.ll[a.ilabel - 1] : c.ll_row[FullIlabel(c.p, a, aidx) - 1];
+    const float ll = c.ll_in_lds ? s.ll[a.ilabel - 1] : c.ll_row[FullIlabel(c.P(), a, aidx) - 1];
     const float acoustic_cost = -ll;
     const double total_cost = csrc + a.weight + acoustic_cost;
     if (c.min_only) {
@@ -1316,7 +1328,7 @@ __device__ __forceinline__ void BigLoop(const FrameCtx<M> &c, int32_t *next, int
                                         Source source) {
   static_assert(W == 64 || W == 32, "one token per row, or two of at most 32 arcs");
   constexpr int kPer = 64 / W;
-  CParams &p = c.p;
+  CParams &p = c.P();
   Shared &s = c.s;
   const int lane = threadIdx.x & 63;
   while (true) {
@@ -1406,7 +1418,7 @@ __device__ __forceinline__ void Filter(const FrameCtx<M> &c, const Table<LDS> &t
                                        const KD_G uint32_t *wl_in, Counters &cnt) {
   constexpr int KD_BUCKET = LDS ? kBucketBig : kBucketSpill;
   (void)KD_BUCKET;
-  CParams &p = c.p;
+  CParams &p = c.P();
   Shared &s = c.s;
   const int tid = threadIdx.x, lane = tid & 63;
   int par = 0;
@@ -1703,7 +1715,7 @@ __device__ __forceinline__ void Insert(const FrameCtx<M> &c, const Table<LDS> &t
   for (int i = q_begin + threadIdx.x; i < q_end; i += kBlock) {
     // A retry in a larger table replays emitting entries whose destination word the
     // aborted attempt already replaced by a slot: take the state from the arc again.
-    const uint32_t k = (!EPS && c.replay) ? LoadArcRec(c.p.arcs, c.q_arc[i]).next : c.q_h[i];
+    const uint32_t k = (!EPS && c.replay) ? LoadArcRec(c.P().arcs, c.q_arc[i]).next : c.q_h[i];
     const unsigned long long nk = c.q_nk[i];
     uint32_t h = kKeyEmpty;
     // emitting entries were queued under the running cutoff: apply the final one (:211);
@@ -1798,7 +1810,7 @@ __device__ __noinline__ float SelectKth(const double *tok_cost, long long base_i
 // launch; later frames get them from the previous frame's compaction).
 template <int M>
 __device__ __forceinline__ void FrontierStats(const FrameCtx<M> &c) {
-  CParams &p = c.p;
+  CParams &p = c.P();
   Shared &s = c.s;
   const int tid = threadIdx.x;
   unsigned long long mk = kCostDead;
@@ -1822,7 +1834,7 @@ __device__ __forceinline__ void FrontierStats(const FrameCtx<M> &c) {
 // GetCutoff, faster-decoder.cc:244-336, by value.
 template <bool FRONT_LDS, int M>
 __device__ __forceinline__ void GetCutoff(FrameCtx<M> &c, const Team &tm) {
-  CParams &p = c.p;
+  CParams &p = c.P();
   Shared &s = c.s;
   const int tid = threadIdx.x;
   const double best_cost = Uni(KC<M>(s.f_best));
@@ -1889,7 +1901,7 @@ template <int M>
 __device__ __forceinline__ void FrameFront(FrameCtx<M> &c, Counters &cnt) {
   constexpr int KD_BUCKET = kBucketBig;
   (void)KD_BUCKET;
-  CParams &p = c.p;
+  CParams &p = c.P();
   Shared &s = c.s;
   const int tid = threadIdx.x;
   if (c.simple) {
@@ -1987,7 +1999,7 @@ __device__ __forceinline__ uint32_t FrameBack(FrameCtx<M> &c, const Table<LDS> &
                                               int q_emit, Counters &cnt) {
   constexpr int KD_BUCKET = LDS ? kBucketBig : kBucketSpill;
   (void)KD_BUCKET;
-  CParams &p = c.p;
+  CParams &p = c.P();
   Shared &s = c.s;
   const int tid = threadIdx.x;
   // simple mode queued exactly what is below the cutoff (on the total cost)
@@ -2362,7 +2374,6 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
                                                const KD_G float *next_row, bool have_next) {
   constexpr int KD_BUCKET = kBucketSmall;
   (void)KD_BUCKET;
-  CParams &p = c.p;
   Shared &s = c.s;
   // The thread index is made opaque once per frame: otherwise every address the
   // frame derives from it (tid * 4 + array base, tid + kBlock, ...) is hoisted out of
@@ -2407,7 +2418,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       ArcRec ar[kSmallDeg];
 #pragma unroll
       for (int a = 0; a < kSmallDeg; ++a)
-        ar[a] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg + a0 + a), a0 + a < deg, 0u);
+        ar[a] = LoadArcRecIf(c.P().arcs, static_cast<uint32_t>(abeg + a0 + a), a0 + a < deg, 0u);
 #pragma unroll
       for (int a = 0; a < kSmallDeg; ++a)
         if (a0 + a < deg)
@@ -2572,7 +2583,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       }
 #pragma unroll
       for (int g = 0; g < kGroup; ++g)
-        ar[g] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(aidx[g]), on[g], 0u);
+        ar[g] = LoadArcRecIf(c.P().arcs, static_cast<uint32_t>(aidx[g]), on[g], 0u);
       double cst[kGroup];
       uint32_t src[kGroup];
 #pragma unroll
@@ -2596,7 +2607,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
             ArcRec tr[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              tr[u] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg + a0 + 64 * u),
+              tr[u] = LoadArcRecIf(c.P().arcs, static_cast<uint32_t>(abeg + a0 + 64 * u),
                                    a0 + 64 * u < deg, static_cast<uint32_t>(abeg));
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -2631,18 +2642,19 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
 #pragma unroll
   for (int k = 0; k < kPfRegs; ++k) {
     const int v = tid + k * kBlock;
-    ll_next[k] = have_next && v < p.num_cols ? next_row[v] : 0.0f;
+    ll_next[k] = have_next && v < c.P().num_cols ? next_row[v] : 0.0f;
   }
 #endif
   for (int w = tid; w < kMaskWords; w += nt) wlmask[w] = 0;  // worklist 0 collects the emitting insert's tokens
   c.run_min = kCostInf<M>;
   GetCutoff<true>(c, tm);
   KD_LAP(s, 1);
+  KD_PHASE(c);
   // (workgroup-uniform; an adaptive beam of zero or less -- beam_delta at or below zero with
   // max_active binding -- would let a bound at the cutoff hide the frame's minimum; a graph
   // with a NaN emitting weight has no lowest weight to bound with)
   const bool idx_frame = KD_LABEL_INDEX != 0 && M != 2 && n_in >= kIdxMinFront && c.ll_in_lds &&
-                         c.adaptive_beam > 0.0f && p.emit_w_min == p.emit_w_min && Uni(s.top_valid) != 0;
+                         c.adaptive_beam > 0.0f && c.P().emit_w_min == c.P().emit_w_min && Uni(s.top_valid) != 0;
   // (this frame's lowest and second-lowest acoustic costs, the likeliest label; what each of this
   // lane's tokens found in its state's label index)
   constexpr int kIdxSlots = (kT1Front + kBlock - 1) / kBlock;
@@ -2691,7 +2703,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       aidx1[0] = b_abeg + lane;
       cst1[0] = b_cst;
       src1[0] = static_cast<uint32_t>(b_i);
-      ar1[0] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(aidx1[0]), on1[0], 0u);
+      ar1[0] = LoadArcRecIf(c.P().arcs, static_cast<uint32_t>(aidx1[0]), on1[0], 0u);
       score_batch(EpsNo{}, std::integral_constant<int, 1>{}, ar1, aidx1, on1, cst1, src1);
       LaneMin(&s.min_new, c.run_min, c.run_min != kCostInf<M>);
     }
@@ -2707,7 +2719,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
       int probes = 0;
       uint32_t found = kIdxNone;
       if (ok && lane != leader && deg > kSmallDeg && deg < kIdxMaxDeg) {
-        found = IndexFind(p, abeg, deg, IdxKey(static_cast<uint32_t>(idx_l0 + 1), 0), probes);
+        found = IndexFind(c.P(), abeg, deg, IdxKey(static_cast<uint32_t>(idx_l0 + 1), 0), probes);
         // ... and what that arc costs, for the BOUND only: nothing is queued here (the arc is
         // fetched and scored again in the second pass, by the index or with the token's row), but
         // its cost is a real candidate's, so it may lower the running minimum -- and the second
@@ -2717,7 +2729,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
         // large LM -- let a quarter of its tokens fall back to reading all their arcs: bench
         // 38.2 -> 40.0 M, hlg-large 7.4-7.7 -> 8.0 M; candidates queued per frame 894 -> 615.)
         if (found != kIdxNone && IdxKeyLabel(found) == static_cast<uint32_t>(idx_l0 + 1)) {
-          const ArcRec ar = LoadArcRec(p.arcs, static_cast<uint32_t>(abeg) + IdxKeyOffset(found));
+          const ArcRec ar = LoadArcRec(c.P().arcs, static_cast<uint32_t>(abeg) + IdxKeyOffset(found));
           double nc;
           float aux;
           // (only a cost that is a number and below +infinity bounds anything: an arc whose
@@ -2738,6 +2750,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   PublishMin(c);
   tm.Sync(false);
   KD_LAP(s, 3);
+  KD_PHASE(c);
   if (idx_frame) {
     // ---- the tokens of more than kSmallDeg arcs, now that the best token's arcs have bounded
     // the cutoff.  94 % of the arcs a frame used to score died at the cutoff: with peaky CTC
@@ -2754,7 +2767,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     // are below the final cutoff, and the minimum that defines it, do not.
     const float t_m0 = idx_m0, t_m1 = idx_m1;
     const int t_l0 = idx_l0;
-    const float w_min = p.emit_w_min;
+    const float w_min = c.P().emit_w_min;
     for (int i0 = 0; i0 < n_in; i0 += nt) {
       const int i = i0 + tid;
       int abeg = 0, deg = 0;
@@ -2792,7 +2805,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
           for (int k = 0; k < kIdxSlots; ++k)
             if (k == i0 / nt) found = idx_found[k];
           if (best_in)
-            IndexedArcsFrom(p, abeg, deg, static_cast<uint32_t>(t_l0 + 1), found, probes, fetched,
+            IndexedArcsFrom(c.P(), abeg, deg, static_cast<uint32_t>(t_l0 + 1), found, probes, fetched,
                             [&](uint32_t aidx, const ArcRec &ar) {
                               FilterArc<false, true>(c, ar, aidx, cst, static_cast<uint32_t>(i));
                             });
@@ -2806,6 +2819,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     PublishMin(c);
     tm.Sync(false);
     KD_LAP(s, 2);
+  KD_PHASE(c);
   }
   // The next frame's log-likelihood row is requested HERE, next to the work items' arc
   // gathers, and stored when the emitting filter is done with this frame's row.  (Requested
@@ -2817,12 +2831,13 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
 #pragma unroll
   for (int k = 0; k < kPfRegs; ++k) {
     const int v = tid + k * kBlock;
-    ll_next[k] = have_next && v < p.num_cols ? next_row[v] : 0.0f;
+    ll_next[k] = have_next && v < c.P().num_cols ? next_row[v] : 0.0f;
   }
 #endif
   item_loop(EpsNo{});
   queue_sync();
   KD_LAP(s, 4);
+  KD_PHASE(c);
   // (the epsilon rounds' work-item lists start empty: reset here, published by the insert's barrier)
   if (tid < kItemWords) (&s.it_count[0])[tid] = 0;
   // the emitting filter is done with this frame's log-likelihood row: the next
@@ -2832,7 +2847,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
 #pragma unroll
     for (int k = 0; k < kPfRegs; ++k) {
       const int v = tid + k * kBlock;
-      if (v < p.num_cols) s.ll[v] = ll_next[k];
+      if (v < c.P().num_cols) s.ll[v] = ll_next[k];
     }
     // ... and this wave's share of the new row's two likeliest labels (LoadRowTop; read by the
     // next frame, behind the frame-end barrier) -- if the next frame can be one that uses the
@@ -2845,7 +2860,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
 #pragma unroll
       for (int k = 0; k < kPfRegs; ++k) {
         const int v = tid + k * kBlock;
-        if (v < p.num_cols) Top2Add(top, ll_next[k], v);
+        if (v < c.P().num_cols) Top2Add(top, ll_next[k], v);
       }
       top = WaveTop2(top);
       if (lane == 0) {
@@ -2912,6 +2927,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   insert(EpsNo{}, 0, q_emit, 0);
   tm.Sync(false);
   KD_LAP(s, 5);
+  KD_PHASE(c);
   if (Uni(s.overflow)) return kRetry;
 
   // ---- ProcessNonemitting to a fixpoint (:59-119)
@@ -2965,14 +2981,14 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
           }
           if (lookup) {  // (a degree that does not fit its field: the state record, as ever)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) r[j] = LoadState(p.states, s.key[h[j]] & kStateMask);
+            for (int j = 0; j < 2; ++j) r[j] = LoadState(c.P().states, s.key[h[j]] & kStateMask);
           }
         } else {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             cst[j] = KC<M>(s.cost[h[j]]);
             ok[j] = (j == 0 || two) && !(cst[j] > c.cutoff);  // :74
-            r[j] = LoadState(p.states, s.key[h[j]] & kStateMask);
+            r[j] = LoadState(c.P().states, s.key[h[j]] & kStateMask);
           }
         }
 #pragma unroll
@@ -3002,7 +3018,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int a = 0; a < kSmallDeg; ++a)
-            ar[j][a] = LoadArcRecIf(p.arcs, static_cast<uint32_t>(abeg[j] + a), own[j] && a < deg[j], 0u);
+            ar[j][a] = LoadArcRecIf(c.P().arcs, static_cast<uint32_t>(abeg[j] + a), own[j] && a < deg[j], 0u);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -3018,6 +3034,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     }
     tm.Sync(false);
     KD_LAP(s, 7);
+  KD_PHASE(c);
     if (Uni(s.it_count[0] | s.it_n32 | s.it_n16) != 0) {
       item_loop(EpsYes{});
       queue_sync();
@@ -3029,11 +3046,13 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     // two barriers from here, raise it again)
     if (tid == 0) s.wl_count[cur] = 0;
     KD_LAP(s, 8);
+  KD_PHASE(c);
     const int q_end = Uni(s.q_n);
     if (q_end > c.q_cap) return kRetry;
     insert(EpsYes{}, q_begin, q_end, cur ^ 1);
     tm.Sync(false);
     KD_LAP(s, 9);
+  KD_PHASE(c);
     if (Uni(s.overflow)) return kRetry;
     q_begin = q_end;
     cur ^= 1;
@@ -3058,7 +3077,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   if (Uni(s.arena_next) + n_out > Uni(s.arena_end) ||
       (c.lattice && Uni(s.link_next) + link_room > Uni(s.link_end))) {
     tm.Sync(false);
-    if (tid == 0) s.alloc_ok = static_cast<int32_t>(TakeChunks(p, s, c.utt, frame + 1, n_out, link_room));
+    if (tid == 0) s.alloc_ok = static_cast<int32_t>(TakeChunks(c.P(), s, c.utt, frame + 1, n_out, link_room));
     tm.Sync(false);
     const uint32_t e = static_cast<uint32_t>(Uni(s.alloc_ok));
     if (e) return e;
@@ -3091,7 +3110,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     for (int j = 0; j < kNextRecs; ++j) any_on |= next_on[j];
     if (M != 1 || __ballot(any_on)) {
 #pragma unroll
-      for (int j = 0; j < kNextRecs; ++j) next_rec[j] = LoadArcRange(p.states, st_next[j]);
+      for (int j = 0; j < kNextRecs; ++j) next_rec[j] = LoadArcRange(c.P().states, st_next[j]);
     } else {
 #pragma unroll
       for (int j = 0; j < kNextRecs; ++j) next_rec[j] = ArcRange{0, 0};
@@ -3102,9 +3121,9 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
     const unsigned long long ck = s.cost[h];
     const uint32_t st = s.key[h] & kStateMask;
     const long long g = base_out + i;
-    ToG(p.tok_state)[g] = static_cast<int32_t>(st);
-    ToG(p.tok_cost)[g] = KC<M>(ck);
-    if (c.lattice) ToG(p.tok_extra)[g] = 0.0f;  // lattice-simple-decoder.cc:91-95
+    ToG(c.P().tok_state)[g] = static_cast<int32_t>(st);
+    ToG(c.P().tok_cost)[g] = KC<M>(ck);
+    if (c.lattice) ToG(c.P().tok_extra)[g] = 0.0f;  // lattice-simple-decoder.cc:91-95
     // (lattice: the key without the arc index that rides in its low word -- the next frame
     // looks for its best token by this value)
     const unsigned long long ckc = M == 1 ? ck & 0xFFFFFFFF00000000ull : ck;
@@ -3127,11 +3146,13 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   if (my_min != kCostDead && my_min < s.f_best_next) atomicMin(&s.f_best_next, my_min);
   tm.Sync(false);  // R1's arc words and the slots' index words are final
   KD_LAP(s, 10);
+  KD_PHASE(c);
   if (tid == 0) {
     s.base_out = base_out;
     s.arena_next = base_out + n_out;
   }
   KD_LAP(s, 11);
+  KD_PHASE(c);
   // ---- R2: the winning entry of each slot writes the back-pointer
   if constexpr (M != 1) {
     split(0, n_q, [&](auto w, int lo, int hi) {
@@ -3143,13 +3164,14 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
           const long long g = base_out + s.key[h];
           const uint32_t sr = q_src(w, i);
           const long long prev = (sr & kSrcEps) ? base_out + s.key[sr & ~kSrcEps] : c.base_in + sr;
-          ToG(p.tok_prev)[g] = static_cast<int32_t>(prev);
-          ToG(p.tok_arc)[g] = static_cast<int32_t>(aidx);
+          ToG(c.P().tok_prev)[g] = static_cast<int32_t>(prev);
+          ToG(c.P().tok_arc)[g] = static_cast<int32_t>(aidx);
         }
       }
     });
   }
   KD_LAP(s, 16);
+  KD_PHASE(c);
   // ---- forward links (see FrameBack)
   if (c.lattice) {
     const long long lbase = Uni(s.link_next);  // (room was taken with the token block)
@@ -3188,18 +3210,20 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
           ac = 0.0f;
           at = lbase + n_emit + AggInc(&s.n_eps_links);
         }
-        ToG(p.link_src)[at] = static_cast<int32_t>(src_tok);
-        ToG(p.link_dst)[at] = static_cast<int32_t>(base_out + kd);
-        ToG(p.link_arc)[at] = static_cast<int32_t>(aidx);
-        ToG(p.link_ac)[at] = ac;
-        ToG(p.link_graph)[at] = qg;
-        ToG(p.link_delta)[at] = KCf<M>(nk) - cdf;
+        ToG(c.P().link_src)[at] = static_cast<int32_t>(src_tok);
+        ToG(c.P().link_dst)[at] = static_cast<int32_t>(base_out + kd);
+        ToG(c.P().link_arc)[at] = static_cast<int32_t>(aidx);
+        ToG(c.P().link_ac)[at] = ac;
+        ToG(c.P().link_graph)[at] = qg;
+        ToG(c.P().link_delta)[at] = KCf<M>(nk) - cdf;
       }
     });
   }
   KD_LAP(s, 17);
+  KD_PHASE(c);
   tm.Sync(false);
   KD_LAP(s, 12);
+  KD_PHASE(c);
   // (final now; read by every lane before they are reset for the next frame)
   const int n_emit_fin = Uni(s.n_emit_links), n_eps_fin = Uni(s.n_eps_links);
   const unsigned long long best_next = Uni(s.f_best_next);
@@ -3239,16 +3263,16 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
   }
   if (tid == 0) {
     // frame index and the next frame's start state
-    const long long fi = static_cast<long long>(c.utt) * (p.max_frames + 1) + (frame + 1);
-    ToG(p.frame_base)[fi] = base_out;
-    ToG(p.frame_count)[fi] = n_out;
+    const long long fi = static_cast<long long>(c.utt) * (c.P().max_frames + 1) + (frame + 1);
+    ToG(c.P().frame_base)[fi] = base_out;
+    ToG(c.P().frame_count)[fi] = n_out;
     if (c.lattice) {
       const long long lbase = s.link_next;
-      const long long fb = static_cast<long long>(c.utt) * (p.max_frames + 1);
-      ToG(p.link_emit_base)[fb + frame] = lbase;
-      ToG(p.link_emit_count)[fb + frame] = n_emit_fin;
-      ToG(p.link_eps_base)[fb + frame + 1] = lbase + n_emit_fin;
-      ToG(p.link_eps_count)[fb + frame + 1] = n_eps_fin;
+      const long long fb = static_cast<long long>(c.utt) * (c.P().max_frames + 1);
+      ToG(c.P().link_emit_base)[fb + frame] = lbase;
+      ToG(c.P().link_emit_count)[fb + frame] = n_emit_fin;
+      ToG(c.P().link_eps_base)[fb + frame + 1] = lbase + n_emit_fin;
+      ToG(c.P().link_eps_count)[fb + frame + 1] = n_eps_fin;
       s.link_next = lbase + n_emit_fin + n_eps_fin;
     }
     s.f_best = best_next;
@@ -3263,7 +3287,7 @@ __device__ __forceinline__ uint32_t SmallFrame(FrameCtx<M> &c, const Table<true>
 // of a launch): arena -> LDS.
 template <int M>
 __device__ __forceinline__ void LoadFront(const FrameCtx<M> &c, const Team &tm) {
-  CParams &p = c.p;
+  CParams &p = c.P();
   Shared &s = c.s;
   for (int i = threadIdx.x; i < c.n_in; i += tm.nt) {
     const uint32_t st = static_cast<uint32_t>(ToG(p.tok_state)[c.base_in + i]);
@@ -3305,7 +3329,7 @@ __device__ __noinline__ uint32_t FrameBackSpill(CParams *pp, int utt, long long 
                                                 int n_expanded, int n_arcs, bool replay) {
   CParams &p = *pp;
   Shared &s = Lds();
-  FrameCtx<M> c{p, s, utt};
+  FrameCtx<M> c{&p, s, utt};
   InitCtx(c, p);
   c.base_in = base_in;
   c.n_in = n_in;
@@ -3384,7 +3408,7 @@ __device__ __noinline__ uint32_t BigFrame(CParams *pp, int utt, int frame, long 
   const int tid = threadIdx.x;
   const bool filtered = flags & 1, upper_dirty = flags & 2, best_stale = flags & 4;
   Table<true> tl{s, nullptr, s.bitmask, kLog2Slots, kSlots - 1};
-  FrameCtx<M> c{p, s, utt};
+  FrameCtx<M> c{&p, s, utt};
   InitCtx(c, p);
   c.base_in = base_in;
   c.n_in = n_in;
@@ -3507,6 +3531,8 @@ __device__ __forceinline__ int ThisXcd() {
   return static_cast<int>(Uni(__builtin_amdgcn_s_getreg(20 | (31 << 11)))) & (kMaxXcd - 1);
 }
 __shared__ int kd_work_item, kd_work_take, kd_progressed, kd_decision;
+__shared__ long long kd_t_setup;  // (lane 0: cycles between taking an utterance up and its first frame)
+__shared__ long long kd_prof[8];   // (lane 0: idle, pop, setup, busy, taken fresh / resumed / stolen, stamp)
 // Workgroups of the other kind have started on this XCD (they stay until the launch ends).
 // Call from ONE lane: the words read here change under the launch's feet, and a workgroup's
 // waves must not come to different conclusions (Decide).
@@ -3545,7 +3571,7 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
   (void)KD_BUCKET;
 
   Table<true> tl{s, nullptr, s.bitmask, kLog2Slots, kSlots - 1};
-  FrameCtx<M> c{p, s, utt};
+  FrameCtx<M> c{&p, s, utt};
   InitCtx(c, p);
 
   UttCtl ud;
@@ -3556,7 +3582,7 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
   c.n_in = 0;
   if (resumed) {
     // every word the loop needs, from ONE record in device memory, the loads issued together
-    const KD_G UttResume *rs = ToG(p.sched.resume) + utt;
+    const KD_G UttResume *rs = ToG(c.P().sched.resume) + utt;
     ud.ll = reinterpret_cast<const float *>(Uni(reinterpret_cast<unsigned long long>(rs->ll)));
     ud.offset = Uni(rs->offset);
     ud.target = Uni(rs->target);
@@ -3568,12 +3594,12 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
     f_best_in = Uni(rs->f_best);
     visited = Uni(rs->visited);
   } else {
-    ud.ll = reinterpret_cast<const float *>(Uni(reinterpret_cast<unsigned long long>(ToG(p.utt)[utt].ll)));
-    ud.offset = Uni(ToG(p.utt)[utt].offset);
-    ud.target = Uni(ToG(p.utt)[utt].target);
-    ud.flags = Uni(ToG(p.utt)[utt].flags);
-    frame = (ud.flags & kUttInit) ? -1 : Uni(ToG(p.frames_decoded)[utt]);
-    visited = (ud.flags & kUttInit) ? -1 : Uni(ToG(p.mem)[utt].visited);
+    ud.ll = reinterpret_cast<const float *>(Uni(reinterpret_cast<unsigned long long>(ToG(c.P().utt)[utt].ll)));
+    ud.offset = Uni(ToG(c.P().utt)[utt].offset);
+    ud.target = Uni(ToG(c.P().utt)[utt].target);
+    ud.flags = Uni(ToG(c.P().utt)[utt].flags);
+    frame = (ud.flags & kUttInit) ? -1 : Uni(ToG(c.P().frames_decoded)[utt]);
+    visited = (ud.flags & kUttInit) ? -1 : Uni(ToG(c.P().mem)[utt].visited);
   }
   const bool do_init = !resumed && (ud.flags & kUttInit) != 0;
   // (an utterance that stopped for want of capacity is only sent back here after the
@@ -3598,7 +3624,7 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
   if (search) FullClear<true>(tl, s);
 
   if (tid == 0) {
-    KD_G UttMem *m = ToG(p.mem) + utt;
+    KD_G UttMem *m = ToG(c.P().mem) + utt;
     if (do_init) {  // no chunk of any pool yet, nothing archived, nothing to recycle
       m->atok_next = 0; m->atok_end = 0; m->alink_next = 0; m->alink_end = 0;
       m->arena_chunk = -1; m->link_chunk = -1; m->arena_chunk_len = 0; m->link_chunk_len = 0;
@@ -3611,16 +3637,16 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
     s.link_next = do_init ? 0 : m->link_next;
     s.link_end = do_init ? 0 : m->link_end;
   }
-  if (do_init && c.lattice && tid == 0) ToG(p.lat.finalized)[utt] = 0;
+  if (do_init && c.lattice && tid == 0) ToG(c.P().lat.finalized)[utt] = 0;
   bool best_stale = false;
   if (resumed) {
     // (the best token's arc range is not carried over: the big tiers look it up, FrontierStats)
     if (tid == 0) s.f_best = f_best_in;
     best_stale = true;
   } else if (search && frame >= 0) {
-    const long long fi = static_cast<long long>(utt) * (p.max_frames + 1) + frame;
-    c.base_in = Uni(static_cast<long long>(ToG(p.frame_base)[fi]));
-    c.n_in = Uni(static_cast<int>(ToG(p.frame_count)[fi]));
+    const long long fi = static_cast<long long>(utt) * (c.P().max_frames + 1) + frame;
+    c.base_in = Uni(static_cast<long long>(ToG(c.P().frame_base)[fi]));
+    c.n_in = Uni(static_cast<int>(ToG(c.P().frame_count)[fi]));
     FrontierStats(c);
   }
   __syncthreads();
@@ -3631,15 +3657,15 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
   Table<true> t1{s, nullptr, s.bitmask, kT1Log2, kT1Slots - 1};
   bool front_lds = false, upper_dirty = false;
   auto row_of = [&](int f) {
-    return ToG(ud.ll) + static_cast<long long>(f - ud.offset) * p.row_stride;
+    return ToG(ud.ll) + static_cast<long long>(f - ud.offset) * c.P().row_stride;
   };
   auto row_to_lds = [&](int f) {  // whole workgroup; the caller synchronises
     if (!c.ll_in_lds || f < 0 || f >= target) return;
     const KD_G float *row = row_of(f);
-    for (int v = tid; v < p.num_cols; v += kBlock) s.ll[v] = row[v];
+    for (int v = tid; v < c.P().num_cols; v += kBlock) s.ll[v] = row[v];
     LdsBarrier();
-    if (p.log_softmax) NormalizeRow(s, p.num_cols);  // (logits: normalised here, once per staging)
-    StoreRowTop(s, p.num_cols);  // (the label index's view of the row)
+    if (c.P().log_softmax) NormalizeRow(s, c.P().num_cols);  // (logits: normalised here, once per staging)
+    StoreRowTop(s, c.P().num_cols);  // (the label index's view of the row)
     if (tid == 0) s.top_valid = 1;
   };
   // At the top of the loop the per-frame counters are reset and s.ll holds the
@@ -3652,19 +3678,21 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
     const int w = WaveSumInt(v);
     if ((tid & 63) == 0 && w) atomicAdd(&s.ustat[stat], static_cast<unsigned long long>(w));
   };
+  if (tid == 0) kd_t_setup = static_cast<long long>(__builtin_amdgcn_s_memtime()) - kd_t_setup;
   int seg = kSegFinished;
   while (err == 0 && frame < target) {
+    KD_PHASE(c);  // (nothing loaded through the parameters lives across a frame)
     [[maybe_unused]] bool prune_due = false;
-    if constexpr (M == 1) prune_due = frame > 0 && frame % p.lat.prune_interval == 0 && frame - 1 > visited;
+    if constexpr (M == 1) prune_due = frame > 0 && frame % c.P().lat.prune_interval == 0 && frame - 1 > visited;
     // ---- does the utterance change hands here?  (workgroup-uniform; sizes of the decode and the
     // kinds of workgroups the launch has, never timings: which kind runs a frame changes nothing
     // of what the frame computes)
-    if (p.sched.split != 0 && frame >= 0) {
+    if (c.P().sched.split != 0 && frame >= 0) {
       bool go = false;
-      if constexpr (kKind == kKindLarge) go = c.n_in <= p.sched.mig_lo || (prune_due && p.sched.prune_small != 0);
-      else go = c.n_in > p.sched.mig_hi && !(prune_due && p.sched.prune_small != 0);
+      if constexpr (kKind == kKindLarge) go = c.n_in <= c.P().sched.mig_lo || (prune_due && c.P().sched.prune_small != 0);
+      else go = c.n_in > c.P().sched.mig_hi && !(prune_due && c.P().sched.prune_small != 0);
       // (the rest of the decision is off the frames' path: it is reached once per hand-over)
-      if (go && Decide([&]() { return HandOver(p); })) {
+      if (go && Decide([&]() { return HandOver(c.P()); })) {
         seg = kKind == kKindLarge ? kSegToSmall : kSegToLarge;
         break;
       }
@@ -3680,12 +3708,12 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
         __syncthreads();
         KD_LAP(s, 13);
         if (tid == 0) {  // (the collector takes archive chunks through the same cursors' owner)
-          KD_G UttMem *m = ToG(p.mem) + utt;
+          KD_G UttMem *m = ToG(c.P().mem) + utt;
           m->arena_next = s.arena_next; m->arena_end = s.arena_end;
           m->link_next = s.link_next; m->link_end = s.link_end;
         }
         __syncthreads();
-        const uint32_t pe = Uni(PeriodicPrune(&p, utt, frame, visited));
+        const uint32_t pe = Uni(PeriodicPrune(c.pp, utt, frame, visited));
         visited = frame - 1;
         __syncthreads();
         // the sweep used the LDS block: the table is cleared again, the frontier comes
@@ -3740,9 +3768,9 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
       r = Uni(s.ctl[frame & 1].r);
       // (logits: the row the frame swapped in for the next one; a frame that is run again
       // below stages its rows afresh)
-      if (p.log_softmax && r == 0 && have_next) {
-        NormalizeRow(s, p.num_cols);
-        StoreRowTop(s, p.num_cols);  // (the frame noted the top of the logits)
+      if (c.P().log_softmax && r == 0 && have_next) {
+        NormalizeRow(s, c.P().num_cols);
+        StoreRowTop(s, c.P().num_cols);  // (the frame noted the top of the logits)
         if (tid == 0) s.top_valid = 1;
         LdsBarrier();
       }
@@ -3801,7 +3829,7 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
     }
     if (r == kRetry) {
       // frames that need the big tables run in a function of their own
-      r = BigFrame<M>(&p, utt, frame, c.base_in, c.n_in, c.cutoff, q_emit,
+      r = BigFrame<M>(c.pp, utt, frame, c.base_in, c.n_in, c.cutoff, q_emit,
                       (filtered ? 1 : 0) | (upper_dirty ? 2 : 0) | (best_stale ? 4 : 0),
                       cnt.tokens_expanded, cnt.arcs_scanned);
       front_lds = false;
@@ -3825,7 +3853,7 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
       if constexpr (kKind == kKindSmall) {
         // A frame that outgrew what this geometry's tables hold (its global table's worklist mask
         // lives in a third of the LDS) was not committed: it is a large workgroup's.
-        if (p.sched.split != 0 && r == KD_UTT_TABLE_FULL && Decide([&]() { return OtherKindRuns(p); })) {
+        if (c.P().sched.split != 0 && r == KD_UTT_TABLE_FULL && Decide([&]() { return OtherKindRuns(c.P()); })) {
           seg = kSegToLarge;
           break;
         }
@@ -3848,9 +3876,9 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
   __syncthreads();
   const int frames_done = frame < 0 ? -1 : frame;
   if (tid == 0) {
-    ToG(p.frames_decoded)[utt] = frames_done;
-    ToG(p.status)[utt] = err;
-    KD_G UttMem *m = ToG(p.mem) + utt;
+    ToG(c.P().frames_decoded)[utt] = frames_done;
+    ToG(c.P().status)[utt] = err;
+    KD_G UttMem *m = ToG(c.P().mem) + utt;
     m->arena_next = s.arena_next;
     m->arena_end = s.arena_end;
     m->link_next = s.link_next;
@@ -3860,7 +3888,7 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
       // what the frame loop carries from frame to frame (everything else of the utterance is
       // in global memory already); the utterance's UttCtl goes along so that the taker does
       // not read pinned host memory again
-      KD_G UttResume *rs = ToG(p.sched.resume) + utt;
+      KD_G UttResume *rs = ToG(c.P().sched.resume) + utt;
       rs->ll = ud.ll;
       rs->offset = ud.offset;
       rs->target = ud.target;
@@ -3875,14 +3903,14 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
   }
   if (tid == KD_STAT_HANDOVERS && seg != kSegFinished) s.stat[tid] += 1;
   if (tid < KD_NUM_STATS) {
-    KD_G long long *st = ToG(p.stats) + static_cast<long long>(utt) * kStatStride;
+    KD_G long long *st = ToG(c.P().stats) + static_cast<long long>(utt) * kStatStride;
     const long long was = do_init ? 0 : st[tid];
     if (tid == KD_STAT_MAX_TOKENS) st[tid] = s.stat[tid] > was ? s.stat[tid] : was;
     else st[tid] = was + s.stat[tid];
   }
 #ifdef KD_PROFILE
   if (tid < kProfSlots) {
-    KD_G long long *cy = ToG(p.stats) + static_cast<long long>(utt) * kStatStride + KD_NUM_STATS;
+    KD_G long long *cy = ToG(c.P().stats) + static_cast<long long>(utt) * kStatStride + KD_NUM_STATS;
     cy[tid] = (do_init ? 0 : cy[tid]) + s.cyc[tid];
   }
 #endif
@@ -3899,9 +3927,9 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
     if (err == 0 && frame == target && frame >= 0 &&
         (ud.flags & (kUttFinalStats | kUttFinalize | kUttExport | kUttExportNoFinal))) {
       __syncthreads();  // (every wave is done with the search's LDS)
-      const uint32_t e = Uni(LatticeTail(&p, utt, frame, ud.flags));
+      const uint32_t e = Uni(LatticeTail(c.pp, utt, frame, ud.flags));
       __syncthreads();
-      if (e && tid == 0) ToG(p.status)[utt] = e;
+      if (e && tid == 0) ToG(c.P().status)[utt] = e;
       const TailShared &ts = TailLds();
       o.status = e;
       o.sizes[0] = ts.r_sizes[0]; o.sizes[1] = ts.r_sizes[1];
@@ -3910,14 +3938,14 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
       o.final_rel = ts.r_final_rel;
       if (ts.r_arena_order) o.phase |= kPhaseArenaOrder;
     }
-    if (Uni(ToG(p.lat.finalized)[utt]) != 0) o.phase |= kPhaseFinalized;
+    if (Uni(ToG(c.P().lat.finalized)[utt]) != 0) o.phase |= kPhaseFinalized;
   } else {
     // 1-best decoders: ReachedFinal and GetBestPath of what has been decoded so far
     if (err == 0 && frame == target && frame >= 0 && (ud.flags & kUttBestPath)) {
       __syncthreads();
-      const uint32_t e = Uni(PathTail(&p, utt, frame, ud.flags));
+      const uint32_t e = Uni(PathTail(c.pp, utt, frame, ud.flags));
       __syncthreads();
-      if (e && tid == 0) ToG(p.status)[utt] = e;
+      if (e && tid == 0) ToG(c.P().status)[utt] = e;
       const TailShared &ts = TailLds();
       o.status = e;
       o.sizes[0] = ts.r_sizes[0]; o.sizes[1] = ts.r_sizes[1];
@@ -3926,7 +3954,7 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
       o.final_rel = ts.r_final_rel;
     }
   }
-  if (tid == 0) p.out[utt] = o;
+  if (tid == 0) c.P().out[utt] = o;
   return kSegFinished;
 }
 
@@ -3978,11 +4006,16 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
   const int xcd = ThisXcd();
   if (split && threadIdx.x == 0) atomicAdd(&p.sched.ctl->n_reg[xcd][kKind], 1u);
   bool fresh_left = true;  // (lane 0's: positions of `order` may still be had)
+  // (lane 0's clocks: kd_device.h SchedProf)
+  if (threadIdx.x < 8) kd_prof[threadIdx.x] = 0;
   while (true) {
     __syncthreads();  // the previous utterance is finished by every wave
     if (threadIdx.x == 0) {
+      const long long t0 = static_cast<long long>(__builtin_amdgcn_s_memtime());
+      long long t_found = t0;
       int item = -1, take = kTakeFresh;
       while (true) {
+        t_found = static_cast<long long>(__builtin_amdgcn_s_memtime());
         if (split) {
           int u = QueuePop(p, xcd, kKind);
           if (u >= 0) { item = u; take = kTakeResumed; break; }
@@ -4007,11 +4040,25 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
       // what the utterance's previous workgroup stored is in this XCD's L2; this CU's L1 may
       // hold older contents of those lines
       if (take != kTakeFresh) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const long long t1 = static_cast<long long>(__builtin_amdgcn_s_memtime());
+      kd_prof[0] += t_found - t0;
+      kd_prof[1] += t1 - t_found;
+      if (item >= 0) kd_prof[4 + take] += 1;
+      kd_t_setup = t1;
+      kd_prof[7] = t1;
     }
     __syncthreads();
     const int item = Uni(kd_work_item), take = Uni(kd_work_take);
     if (item < 0) break;
     const int seg = RunUtterance<M>(p, s, item, take != kTakeFresh);
+    if (threadIdx.x == 0) {
+      const long long t2 = static_cast<long long>(__builtin_amdgcn_s_memtime());
+      // (kd_t_setup: the stamp until the utterance's first frame, the difference from there on;
+      // an utterance with no frame to run leaves the stamp)
+      const long long su = kd_t_setup == kd_prof[7] ? 0 : kd_t_setup;
+      kd_prof[2] += su;
+      kd_prof[3] += t2 - kd_prof[7] - su;
+    }
     if (split) {
       __syncthreads();  // every wave's stores of this utterance have left the CU (vmcnt(0))
       if (threadIdx.x == 0) {
@@ -4019,6 +4066,17 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
         else QueuePush(p, xcd, seg == kSegToSmall ? kKindSmall : kKindLarge, item);
       }
     }
+  }
+  if (split && threadIdx.x == 0) {
+    SchedProf *pf = p.sched.prof;
+    atomicAdd(&pf->idle[kKind], static_cast<unsigned long long>(kd_prof[0]));
+    atomicAdd(&pf->setup[kKind], static_cast<unsigned long long>(kd_prof[2]));
+    atomicAdd(&pf->busy[kKind], static_cast<unsigned long long>(kd_prof[3]));
+    atomicAdd(&pf->wait_pop[kKind], static_cast<unsigned long long>(kd_prof[1]));
+    atomicAdd(&pf->n_fresh[kKind], static_cast<unsigned long long>(kd_prof[4 + kTakeFresh]));
+    atomicAdd(&pf->n_resumed[kKind], static_cast<unsigned long long>(kd_prof[4 + kTakeResumed]));
+    atomicAdd(&pf->n_stolen[kKind], static_cast<unsigned long long>(kd_prof[4 + kTakeStolen]));
+    atomicAdd(&pf->n_workgroups[kKind], 1ull);
   }
   // The last workgroup to leave tells the host where the pools' cursors stand (every
   // other workgroup's allocations are behind its n_done increment) and leaves the

@@ -38,7 +38,10 @@ SYMBOLS = (
     "kd_batch_final_relative_cost", "kd_batch_raw_lattice_prepare", "kd_batch_raw_lattice_copy",
     "kd_batch_create_simple", "kd_batch_decode_async", "kd_batch_decode", "kd_batch_capacity",
     "kd_batch_set_output_buffer", "kd_batch_raw_lattice_table", "kd_batch_set_log_softmax",
+    "kd_batch_split_info", "kd_batch_set_split", "kd_batch_sched_profile",
 )
+SPLIT_NAMES = ("split", "large_cus", "large_workgroups", "small_workgroups", "mig_lo", "mig_hi",
+               "prune_small", "min_batch")
 
 
 class FasterOptions(C.Structure):
@@ -107,6 +110,9 @@ def lib():
     L.kd_batch_decode_host_async.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), _i32p,
                                              C.c_void_p, C.c_int32, C.c_int64, C.c_int32]
     L.kd_batch_capacity.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int64)]
+    L.kd_batch_split_info.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int32)]
+    L.kd_batch_sched_profile.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int64)]
+    L.kd_batch_set_split.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.kd_batch_num_frames_decoded.argtypes = [C.c_void_p, _i32p]
     L.kd_batch_status.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.uint32)]
     L.kd_batch_reached_final.argtypes = [C.c_void_p, _i32p]
@@ -377,6 +383,22 @@ class Batch:
         out = np.zeros(8, np.int64)
         _check(lib().kd_batch_capacity(self.h, out))
         return dict(zip(CAPACITY_NAMES, out.tolist()))
+
+    def split_info(self):
+        """How calls of this batch are dealt out over the two kinds of workgroups (kd_hip.h)."""
+        out = np.zeros(8, np.int32)
+        _check(lib().kd_batch_split_info(self.h, out))
+        return dict(zip(SPLIT_NAMES, out.tolist()))
+
+    def sched_profile(self):
+        """Cycles and counts per kind of workgroup (kd_hip.h kd_batch_sched_profile)."""
+        out = np.zeros(16, np.int64)
+        _check(lib().kd_batch_sched_profile(self.h, out))
+        names = ("idle", "setup", "busy", "pop", "fresh", "resumed", "stolen", "workgroups")
+        return {n: dict(small=int(out[2 * i]), large=int(out[2 * i + 1])) for i, n in enumerate(names)}
+
+    def set_split(self, enable=-1, min_batch=-1, mig_lo=-1, mig_hi=-1, prune_small=-1):
+        _check(lib().kd_batch_set_split(self.h, int(enable), min_batch, mig_lo, mig_hi, int(prune_small)))
 
     def num_frames_decoded(self):
         out = np.zeros(self.batch, np.int32)
