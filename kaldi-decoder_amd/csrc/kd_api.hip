@@ -165,7 +165,8 @@ struct kd_batch {
   DevBuf<float> g_log_ac, g_log_gr;
   // ---- the two kinds of workgroups (kd_device.h SchedCtl): queues, the frame loop's state of an
   // utterance that changes hands, the CU-masked streams the two kernels run on
-  bool split_ok = false;          // the batch can run split launches ...
+  bool split_possible = false;    // not SimpleDecoder, a device of at least 16 CUs
+  bool split_ok = false;          // the batch is prepared for split launches (PrepareSplit) ...
   bool split_on = false;          // ... and does (kd_batch_set_split)
   int split_min_batch = 0;        // ... and does for calls of at least this many utterances
   int cus = 0, large_cus = 0;
@@ -349,6 +350,9 @@ constexpr int kMaxLog2Slots = 19;  // the spill table's worklist bitmask lives i
 #define KD_SPLIT_MIN_BATCH_DEFAULT(cus) (cus)
 #else
 #define KD_SPLIT_MIN_BATCH_DEFAULT(cus) (KD_SPLIT_MIN_BATCH)
+#endif
+#ifndef KD_SPLIT_DEFAULT
+#define KD_SPLIT_DEFAULT 0  // (1 in the test builds: every batch is split unless told otherwise)
 #endif
 
 int CheckOptions(const kd_faster_options &o) {
@@ -964,6 +968,60 @@ void kd_faster_options_default(kd_faster_options *o) {
   o->no_grow = 0;
 }
 
+// Two kinds of workgroups (kd_device.h SchedCtl): most CUs run one large workgroup each, the
+// rest three small ones each, and an utterance is run by the kind its frames' sizes ask for.
+// A batch is prepared for it -- CU-masked streams, queues, scratch sets for both kernels'
+// workgroups -- when it is first asked to (kd_batch_set_split, KD_SPLIT=1): calls are NOT dealt
+// out that way by default.  Measured on the bench workload a split call that runs alone is
+// 10-12 % shorter, but two calls kept in flight (how the throughput figure is reached: one call's
+// tail is the other's middle) are 30 % slower split than not -- DESIGN section 5.  SimpleDecoder
+// has no LDS-resident tier and is never split.  Returns KD_OK with split_ok false when the device
+// gives no CU-masked streams.
+static int PrepareSplit(kd_batch *b) {
+  if (b->split_ok || !b->split_possible) return KD_OK;
+  const int cus = b->cus, max_batch = b->max_batch;
+  int x = EnvInt("KD_SPLIT_LARGE_CUS", cus * 7 / 8) / 8 * 8;
+  x = std::max(8, std::min(cus - 8, x));
+  if (!TakeSplitStreams(b->g->device, cus, x, &b->split_streams)) return KD_OK;
+  const int wl = std::min<int>(max_batch, x);
+  // (a few more than fit: the dispatcher does not deal them out evenly -- tools/ubench/cumask.hip
+  // -- and one that finds no room starts when the launch is over, and leaves)
+  const int ws = std::min<int>(max_batch, (cus - x) * SearchWorkgroupsPerCuSmall() + (cus - x) / 8);
+  if (b->pending) (void)ReadBack(b);
+  if (wl + ws > b->workgroups) {  // (the tables are empty between launches: nothing to carry over)
+    const int was = b->workgroups;
+    b->workgroups = wl + ws;
+    if (hipError_t e = AllocTables(b, b->g_log2_slots); e != hipSuccess) {
+      b->workgroups = was;
+      return Fail(KD_E_CAPACITY, std::string("scratch sets for the second kernel's workgroups: ") + hipGetErrorString(e));
+    }
+  }
+  while (b->ring_cap < max_batch) b->ring_cap *= 2;
+  hipError_t e = hipSuccess;
+  auto A = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+  A(b->sched_ctl.Alloc(1));
+  A(b->sched_prof.Alloc(1));
+  A(b->sched_ring.Alloc(static_cast<size_t>(kMaxXcd) * 2 * b->ring_cap));
+  A(b->resume.Alloc(max_batch));
+  if (e == hipSuccess) e = hipMemset(b->sched_prof.p, 0, sizeof(SchedProf));
+  if (e == hipSuccess) e = hipMemset(b->sched_ctl.p, 0, sizeof(SchedCtl));
+  if (e == hipSuccess) e = hipMemset(b->sched_ring.p, 0, b->sched_ring.bytes());
+  if (e == hipSuccess) e = hipMemset(b->resume.p, 0, b->resume.bytes());
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join_l, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join_s, hipEventDisableTiming);
+  if (e != hipSuccess) return Fail(KD_E_HIP, std::string("preparing the second kernel: ") + hipGetErrorString(e));
+  b->large_cus = x;
+  b->wgs_large = wl;
+  b->wgs_small = ws;
+  b->split_min_batch = std::max(1, EnvInt("KD_SPLIT_MIN_BATCH", KD_SPLIT_MIN_BATCH_DEFAULT(cus)));
+  b->mig_hi = std::max(1, std::min(EnvInt("KD_MIG_HI", std::min(64, SearchT1FrontSmall())), 1 << 20));
+  b->mig_lo = std::max(0, std::min(EnvInt("KD_MIG_LO", std::min(32, b->mig_hi)), b->mig_hi));
+  b->prune_small = EnvInt("KD_PRUNE_SMALL", 0) != 0 ? 1 : 0;
+  b->split_ok = true;
+  return KD_OK;
+}
+
 static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
                        const kd_lattice_options *lopts, bool simple, int32_t max_batch,
                        void *stream, kd_batch **out) {
@@ -984,28 +1042,7 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   b->cus = cus;
   b->wgs_single = std::min<int>(max_batch, cus * SearchWorkgroupsPerCu());
   b->workgroups = b->wgs_single;
-  // Two kinds of workgroups (kd_device.h SchedCtl): three quarters of the CUs run one large
-  // workgroup each, the rest three small ones each, and an utterance is run by the kind its
-  // frames' sizes ask for.  (KD_SPLIT=0: one kernel as in rounds 1-5.  The knobs are for
-  // tools/ and the tests; SimpleDecoder has no LDS-resident tier and stays unsplit.)
-  if (!simple && EnvInt("KD_SPLIT", 1) != 0 && cus >= 16) {
-    int x = EnvInt("KD_SPLIT_LARGE_CUS", cus * 3 / 4) / 8 * 8;
-    x = std::max(8, std::min(cus - 8, x));
-    if (TakeSplitStreams(g->device, cus, x, &b->split_streams)) {
-      b->split_ok = true;
-      b->split_on = true;
-      b->large_cus = x;
-      b->wgs_large = std::min<int>(max_batch, x);
-      // (a few more than fit: the dispatcher does not deal them out evenly -- tools/ubench/cumask.hip
-      // -- and one that finds no room starts when the launch is over, and leaves)
-      b->wgs_small = std::min<int>(max_batch, (cus - x) * SearchWorkgroupsPerCuSmall() + (cus - x) / 8);
-      b->workgroups = std::max(b->wgs_single, b->wgs_large + b->wgs_small);
-      b->split_min_batch = std::max(1, EnvInt("KD_SPLIT_MIN_BATCH", KD_SPLIT_MIN_BATCH_DEFAULT(cus)));
-      b->mig_hi = std::max(1, std::min(EnvInt("KD_MIG_HI", SearchT1FrontSmall()), 1 << 20));
-      b->mig_lo = std::max(0, std::min(EnvInt("KD_MIG_LO", b->mig_hi), b->mig_hi));
-      b->prune_small = EnvInt("KD_PRUNE_SMALL", 0) != 0 ? 1 : 0;
-    }
-  }
+  b->split_possible = !simple && cus >= 16;
   // pools: 2^17 token records per utterance to begin with (an HLG decode at beam 15 writes
   // about 10^5 per 10 s utterance), two links per token; both grow on demand
   uint64_t tok = b->o.arena_tokens > 0 ? static_cast<uint64_t>(b->o.arena_tokens)
@@ -1042,20 +1079,6 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   b->ctl_bytes = b->off_tops + sizeof(HostTops);
   A(b->bctl.Alloc(1));
   if (e == hipSuccess) e = hipMemset(b->bctl.p, 0, sizeof(BatchCtl));
-  if (b->split_ok) {
-    while (b->ring_cap < max_batch) b->ring_cap *= 2;
-    A(b->sched_ctl.Alloc(1));
-    A(b->sched_prof.Alloc(1));
-    if (e == hipSuccess) e = hipMemset(b->sched_prof.p, 0, sizeof(SchedProf));
-    A(b->sched_ring.Alloc(static_cast<size_t>(kMaxXcd) * 2 * b->ring_cap));
-    A(b->resume.Alloc(max_batch));
-    if (e == hipSuccess) e = hipMemset(b->sched_ctl.p, 0, sizeof(SchedCtl));
-    if (e == hipSuccess) e = hipMemset(b->sched_ring.p, 0, b->sched_ring.bytes());
-    if (e == hipSuccess) e = hipMemset(b->resume.p, 0, b->resume.bytes());
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join_l, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ev_join_s, hipEventDisableTiming);
-  }
   if (e == hipSuccess)
     e = hipHostMalloc(reinterpret_cast<void **>(&b->ctl_host), b->ctl_bytes, hipHostMallocDefault);
   if (e == hipSuccess) std::memset(b->ctl_host, 0, b->ctl_bytes);
@@ -1130,6 +1153,15 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   b->h_final_weight.assign(2 * static_cast<size_t>(max_batch), 0.f);
   b->h_path_final_rel.assign(max_batch, 0.f);
   b->h_final_rel.assign(max_batch, 0.f);
+  // (KD_SPLIT=1: every batch deals its calls out over the two kinds of workgroups, as if
+  // kd_batch_set_split(b, 1, ...) had been called; the test builds do by default)
+  if (b->split_possible && EnvInt("KD_SPLIT", KD_SPLIT_DEFAULT) > 0) {
+    if (int r = PrepareSplit(b)) {
+      delete b;
+      return r;
+    }
+    b->split_on = b->split_ok;
+  }
   *out = b;
   return KD_OK;
 }
@@ -1767,12 +1799,16 @@ int kd_batch_sched_profile(kd_batch *b, int64_t *out) {
 int kd_batch_set_split(kd_batch *b, int32_t enable, int32_t min_batch, int32_t mig_lo, int32_t mig_hi,
                        int32_t prune_small) {
   if (!b) return Fail(KD_E_INVALID, "bad argument");
+  if (b->pending) (void)ReadBack(b);
+  if (!b->split_ok && enable > 0) {
+    KD_HIP_TRY(hipSetDevice(b->g->device));
+    if (int r = PrepareSplit(b)) return r;
+  }
   if (!b->split_ok) {
-    if (enable > 0) return Fail(KD_E_STATE, "this batch has no second kernel (SimpleDecoder, KD_SPLIT=0, or "
-                                            "CU-masked streams are not available)");
+    if (enable > 0) return Fail(KD_E_STATE, "this batch has no second kernel (SimpleDecoder, or CU-masked "
+                                            "streams are not available)");
     return KD_OK;
   }
-  if (b->pending) (void)ReadBack(b);
   const int hi = mig_hi >= 0 ? mig_hi : b->mig_hi, lo = mig_lo >= 0 ? mig_lo : std::min(b->mig_lo, hi);
   if (hi < 1 || lo > hi) return Fail(KD_E_INVALID, "need 0 <= mig_lo <= mig_hi, mig_hi >= 1");
   b->mig_hi = hi;

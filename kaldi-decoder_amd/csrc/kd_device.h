@@ -133,7 +133,13 @@ struct SchedQueue {
 };
 struct SchedCtl {
   SchedQueue q[kMaxXcd][2];      // [xcd][kind]
-  uint32_t n_reg[kMaxXcd][2];    // workgroups of each kind that have started, per XCD
+  uint32_t n_reg[kMaxXcd][2];    // workgroups of each kind that are at work, per XCD
+  // per XCD: workgroups at work << 32 | utterances bound to the XCD that are not finished.  A
+  // workgroup that finds nothing to do leaves the launch for good once the XCD has more
+  // workgroups than unfinished utterances (one compare-and-swap on this word decides it, so the
+  // last utterances always keep a workgroup each): the CUs it held go to the next call's kernels
+  // instead of idling through this call's tail.
+  unsigned long long live[kMaxXcd];
   uint32_t n_finished;           // utterances that have reached their target (or stopped) in this launch
   uint32_t pad[15];
 };  // all zero between launches: the last workgroup to leave a launch zeroes it

@@ -226,7 +226,7 @@ static_assert(KD_T1_SOFTQ == 0 || KD_T1_SOFTQ >= 2 * kQL, "the soft limit is a m
 constexpr int kT1W16 = 512;    // tokens of at most 16 arcs (in Shared::hist)
 constexpr int kSecondPart = 0x8000;  // 16-lane list entry: arcs 32..47 of a token of 33..48 arcs
 static_assert(KD_T1_FRONT <= kSecondPart, "work-list entries are frontier indices below the flag");
-static_assert(kBlock >= 256 && kT1Front >= kBlock && kSlots == 2 * kT1Slots && 2 * kQL == kT1Slots,
+static_assert(kBlock >= 128 && kT1Front >= kBlock && kSlots == 2 * kT1Slots && 2 * kQL == kT1Slots,
               "tier-1 LDS overlay");
 // Cost keys: order-preserving 64-bit images of costs, so that one integer atomicMin
 // relaxes a state.  FasterDecoder / SimpleDecoder costs are doubles (CostKey).  The
@@ -4004,7 +4004,10 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
   // was sent.  The queues are per XCD (kd_device.h): this workgroup's is the one it RUNS on.
   const bool split = p.sched.split != 0;
   const int xcd = ThisXcd();
-  if (split && threadIdx.x == 0) atomicAdd(&p.sched.ctl->n_reg[xcd][kKind], 1u);
+  if (split && threadIdx.x == 0) {
+    atomicAdd(&p.sched.ctl->live[xcd], 1ull << 32);
+    atomicAdd(&p.sched.ctl->n_reg[xcd][kKind], 1u);
+  }
   bool fresh_left = true;  // (lane 0's: positions of `order` may still be had)
   // (lane 0's clocks: kd_device.h SchedProf)
   if (threadIdx.x < 8) kd_prof[threadIdx.x] = 0;
@@ -4022,17 +4025,38 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
         }
         if (fresh_left) {
           const int i = static_cast<int>(atomicAdd(&p.ctl->work_ctr, 1u) - p.work_base);
-          if (i < p.batch) { item = ToG(p.order)[i]; break; }
+          if (i < p.batch) {
+            item = ToG(p.order)[i];
+            if (split) atomicAdd(&p.sched.ctl->live[xcd], 1ull);  // (this XCD's from now on)
+            break;
+          }
           fresh_left = false;  // (one failed attempt per workgroup: the host counts on it)
           if (!split) break;
           continue;
         }
-        if constexpr (kKind == kKindLarge) {
-          // nothing waits for a large workgroup: better a small frame on a whole CU than an idle CU
-          const int u = QueuePop(p, xcd, kKindSmall);
+        if (kKind == kKindLarge || AgentLoad(&p.sched.ctl->n_reg[xcd][kKindLarge]) == 0u) {
+          // Nothing waits for this kind: a large workgroup takes what waits for a small one
+          // (better a small frame on a whole CU than an idle CU); a small one takes what waits for
+          // a large one only when the XCD's large workgroups have all left (below).
+          const int u = QueuePop(p, xcd, 1 - kKind);
           if (u >= 0) { item = u; take = kTakeStolen; break; }
         }
         if (AgentLoad(&p.sched.ctl->n_finished) >= static_cast<uint32_t>(p.batch)) break;
+        // More workgroups than unfinished utterances on this XCD: this one leaves (SchedCtl::live).
+        {
+          unsigned long long *lw = &p.sched.ctl->live[xcd];
+          unsigned long long w = __hip_atomic_load(lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bool left = false;
+          while ((w >> 32) > (w & 0xFFFFFFFFull)) {
+            const unsigned long long seen = atomicCAS(lw, w, w - (1ull << 32));
+            if (seen == w) { left = true; break; }
+            w = seen;
+          }
+          if (left) {
+            atomicSub(&p.sched.ctl->n_reg[xcd][kKind], 1u);
+            break;
+          }
+        }
         __builtin_amdgcn_s_sleep(64);
       }
       kd_work_item = item;
@@ -4062,7 +4086,10 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
     if (split) {
       __syncthreads();  // every wave's stores of this utterance have left the CU (vmcnt(0))
       if (threadIdx.x == 0) {
-        if (seg == kSegFinished) atomicAdd(&p.sched.ctl->n_finished, 1u);
+        if (seg == kSegFinished) {
+          atomicAdd(&p.sched.ctl->live[xcd], ~0ull);  // (one utterance fewer is bound to this XCD)
+          atomicAdd(&p.sched.ctl->n_finished, 1u);
+        }
         else QueuePush(p, xcd, seg == kSegToSmall ? kKindSmall : kKindLarge, item);
       }
     }

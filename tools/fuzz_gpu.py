@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity runs of the GPU decoders against the oracle's canonical decoders:
 random graphs, options (beams, max/min_active, prune_interval), batch sizes, pool sizes
-(small ones grow), one-launch Decode or chunked AdvanceDecoding.
+(small ones grow), one-launch Decode or chunked AdvanceDecoding, and -- round 6 -- the call dealt
+out over the two kinds of workgroups or run by one kernel, with random hand-over thresholds
+(frontiers of a handful of tokens change hands every few frames) and pruning on either kind.
 
     python tools/fuzz_gpu.py [seconds] [seed]
 """
@@ -87,8 +89,25 @@ def main():
                    table_slots=1 << 14) if small else {}
         one_launch = rng.random() < 0.5
         chunk = int(rng.integers(1, 25))
+        # two kinds of workgroups: two calls in three are split, at thresholds that fuzz-sized
+        # frontiers cross (KD_FUZZ_SPLIT=0/1 forces it off / on)
+        fs = os.environ.get("KD_FUZZ_SPLIT")
+        split = rng.random() < 0.67 if fs is None else fs == "1"
+        hi = int(rng.choice([1, 2, 4, 8, 16, 64, 256]))
+        lo = int(rng.integers(0, hi + 1))
+        psm = int(rng.integers(0, 2))
+
+        def deal(b):
+            try:
+                if split:
+                    b.set_split(enable=1, min_batch=1, mig_lo=lo, mig_hi=hi, prune_small=psm)
+                else:
+                    b.set_split(enable=0)
+            except RuntimeError as e:
+                if "second kernel" not in str(e):
+                    raise
         tag = dict(B=B, T=T, V=V, beam=beam, ma=ma, mi=mi, small=small, one=one_launch, chunk=chunk,
-                   states=g["num_states"])
+                   states=g["num_states"], split=split, lo=lo, hi=hi, psm=psm)
         if rng.random() < 0.6:
             lbeam = float(rng.uniform(1, 8))
             pi = int(rng.integers(1, 30)) if rng.random() < 0.7 else 10**6
@@ -96,6 +115,7 @@ def main():
             if small:
                 cap["arena_links"] = int(rng.integers(256, 4096))
             lb = cabi.LatticeBatch(G, max_batch=B, prune_interval=pi, **opts, **cap)
+            deal(lb)
             if one_launch:
                 lb.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V)
             else:
@@ -118,6 +138,7 @@ def main():
         else:
             opts = dict(beam=beam, max_active=ma, min_active=mi)
             bt = cabi.Batch(G, max_batch=B, **opts, **cap)
+            deal(bt)
             if one_launch:
                 bt.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V)
             else:
