@@ -354,6 +354,10 @@ def main():
     ap.add_argument("--prune-interval", type=int, default=0,
                     help="lattice workloads: PruneActiveTokens every this many frames (0: the "
                          "workload's setting)")
+    ap.add_argument("--min-active", type=int, default=-1,
+                    help="lattice workloads: the headline at this min_active instead of the workload's "
+                         "(200 = LatticeFasterDecoderConfig's default: what tools/profile_round.sh rNN_min200 "
+                         "profiles; the default bench line carries that configuration as a side run)")
     ap.add_argument("--search-only", action="store_true",
                     help="diagnostic: time InitDecoding + AdvanceDecoding only (not a bench line)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -435,6 +439,8 @@ def main():
     opts = dict(wl["opts"])
     if wl["lattice"] and args.prune_interval:
         opts["prune_interval"] = args.prune_interval
+    if wl["lattice"] and args.min_active >= 0:
+        opts["min_active"] = args.min_active
     bts = [cls(Gr, max_batch=per_slot, max_frames=T, stream=st.cuda_stream, **opts)
            for st in streams]
     setup_s = time.time() - t0
@@ -615,7 +621,7 @@ def main():
     # utterance length (no periodic sweeps, no collector; the lattices are the same either
     # way -- the knob trades time for memory, and a 10 s utterance needs 5 MB) is reported
     # next to the headline as `value_prune_interval_off`.
-    def side_value(extra, label):
+    def side_value(extra, label, lazy_prune=None):
         """The headline's pipeline with other decoder options (batch objects of its own, the
         same streams, utterances and lent buffers): audio frames/s, and the counters of one call."""
         nonlocal bts
@@ -626,6 +632,9 @@ def main():
             if out_bufs is not None:
                 for bt_, buf_ in zip(bts, out_bufs):
                     bt_.set_output_buffer(buf_)
+            if lazy_prune is not None:
+                for bt_ in bts:
+                    bt_.set_lazy_prune(lazy_prune)
             run_steps(2 * n_fly * G)
             fence()
             # (as long a timed region as the headline's: the pipeline's fill and drain -- one call's
@@ -637,10 +646,21 @@ def main():
             v = world * B * T * n_side * SUBSAMPLING / (time.perf_counter() - t_side)
             st_ = bts[0].stats()
             sm = st_.sum(axis=0)
+            # (the call's own launch, by the library's HIP events, and the same roofline
+            # arithmetic as the headline's -- VERDICT round 5, item 5)
+            k_ms_ = float(bts[0].last_kernel_ms())
+            ab_, pf_, _ = algorithmic_bytes(st_, V)
             return dict(value=v, unit="audio_frames/s", options=label,
                         tokens_in_per_frame=float(sm[1]) / max(float(sm[0]), 1.0),
                         tokens_expanded_per_frame=float(sm[2]) / max(float(sm[0]), 1.0),
-                        max_tokens=int(st_[:, 8].max()))
+                        max_tokens=int(st_[:, 8].max()),
+                        kernel_ms=k_ms_,
+                        roofline=dict(bound="hbm", achieved=ab_ / (k_ms_ * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                                      unit="GB/s", frac=ab_ / (k_ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      algorithmic_bytes_per_launch=ab_),
+                        arcs_scanned_per_frame=pf_["arcs_scanned_per_frame"],
+                        arcs_read_per_frame=pf_["arcs_read_per_frame"],
+                        links_per_frame=pf_["links_per_frame"], spill_frames=pf_["spill_frames"])
         finally:
             bts = keep
 
@@ -650,9 +670,17 @@ def main():
     # utterance length (no periodic sweeps, no collector; the lattices are the same either
     # way -- the knob trades time for memory, and a 10 s utterance needs 5 MB) is reported
     # next to the headline as `value_prune_interval_off`.
-    value_pi_off = side_min200 = side_max10k = None
+    value_pi_off = side_min200 = side_max10k = side_eager = None
     if wl["lattice"] and not args.search_only and not args.prune_interval and not args.headline_only:
         value_pi_off = side_value({"prune_interval": 1 << 20}, "prune_interval off")["value"]
+        # The headline runs at the reference's prune_interval (25) with the library's default
+        # policy: PruneActiveTokens is OWED when its frame comes and run when it shows -- an
+        # export of the un-finalized lattice, a pool that is full (kd_batch_set_lazy_prune,
+        # DESIGN section 4): a Decode() of a 10 s utterance in the default pools never pays.  The
+        # same pipeline with every prune run when its frame comes, like the reference's loop
+        # (lattice-simple-decoder.cc:57-59; rounds 1-5's headline):
+        side_eager = side_value({}, "PruneActiveTokens run every prune_interval frames (kd_batch_set_lazy_prune(0))",
+                                lazy_prune=0)
         # ... and at the options of the decoder the workload is named after: the reference
         # DECLARES LatticeFasterDecoder (config only: lattice-faster-decoder.h:48-55 defaults
         # min_active = 200, max_active = INT_MAX) and implements LatticeSimpleDecoder, whose
@@ -787,9 +815,10 @@ def main():
             "ms_per_step": elapsed / steps_timed * 1e3,
             "timed_seconds": elapsed,
             "value_prune_interval_off": value_pi_off,
+            "value_prune_eager": side_eager["value"] if side_eager else None,
             "value_min_active_200": side_min200["value"] if side_min200 else None,
             "value_max_active_10000": side_max10k["value"] if side_max10k else None,
-            "side_runs": [x for x in (side_min200, side_max10k) if x],
+            "side_runs": [x for x in (side_eager, side_min200, side_max10k) if x],
             "large_lm": large_lm,
             "host_input": host_input,
             "single_batch_ms": single_batch_ms,
@@ -803,6 +832,9 @@ def main():
             "config": {"workload": wl["desc"], "graph_states": info["states"],
                        "graph_arcs": info["arcs"], "batch_per_gpu": B, "frames": T,
                        "prune_interval": (args.prune_interval or wl["opts"].get("prune_interval")),
+                       "prune_policy": ("owed: run on un-finalized export or when a pool is full "
+                                        "(library default; prunes run in the timed region: %d)"
+                                        % int(stats[:, len(cabi.STAT_NAMES) - 1].sum())) if wl["lattice"] else None,
                        "steps_per_call": G, "utterances_per_launch": n_last * B,
                        "calls_in_flight": n_fly, "workgroups_per_launch": cap["workgroups"],
                        "device_mb_per_call": bt.device_bytes / 2**20,

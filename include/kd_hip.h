@@ -232,6 +232,7 @@ enum {
   KD_STAT_INDEX_PROBES,     /* 4-byte label-index entries read to find the arcs that were fetched */
   KD_STAT_HANDOVERS,        /* times the utterance changed hands between the two kinds of workgroups */
   KD_STAT_SMALL_WG_FRAMES,  /* frames run by a workgroup of the small kind (three to a CU) */
+  KD_STAT_PRUNES,           /* PruneActiveTokens sweeps run (lattice decoders; owed ones are not counted until run) */
   KD_NUM_STATS
 };
 int kd_batch_stats(kd_batch *b, int64_t *out /* [batch][KD_NUM_STATS] */);
@@ -367,6 +368,18 @@ size_t kd_batch_device_bytes(const kd_batch *b);
  * was grown since creation, persistent workgroups per launch. */
 int kd_batch_capacity(const kd_batch *b, int64_t *out);
 
+/* PruneActiveTokens, owed or run (lattice decoders; round 6).  The reference prunes every
+ * prune_interval frames (lattice-simple-decoder.cc:57-59), to bound memory; what FinalizeDecoding
+ * leaves does not depend on it.  With lazy != 0 (the default) a prune is only OWED when its frame
+ * comes and is run later -- the owed ones in order, each exactly as it would have run then: a prune
+ * at frame m touches nothing above m -- when something can tell the difference: GetRawLattice of
+ * the un-finalized lattice (kd_batch_raw_lattice_prepare before kd_batch_finalize_decoding), or a
+ * frame that finds no room in the token or link pool (the collector behind a prune returns the
+ * utterance's old chunks: the pools are garbage-collected before they are grown).  lazy = 0: every
+ * prune runs when its frame comes, as in the reference.  Results are the same either way; memory
+ * follows the utterance's length instead of its pruned lattice until a pool fills. */
+int kd_batch_set_lazy_prune(kd_batch *b, int32_t lazy);
+
 /* How a call's utterances are dealt out on the chip (round 6).  A call of at least
  * `min_batch` utterances is run by TWO kernels side by side on disjoint sets of CUs: "large"
  * workgroups (one per CU, the CU's whole LDS) and "small" ones (three per CU); an utterance is
@@ -377,8 +390,12 @@ int kd_batch_capacity(const kd_batch *b, int64_t *out);
  * utterance in one thread: lattice-simple-decoder.cc:53-66, faster-decoder.cc:126-152).
  * kd_batch_split_info: out[0..7] = split available (0: one kernel, as before round 6; the other
  * values are then 0), CUs of the large kind, large workgroups, small workgroups, mig_lo, mig_hi,
- * prune_small, min_batch.  kd_batch_set_split: a negative argument leaves that setting as it is;
- * enable = 0 makes every later call of this batch a one-kernel call. */
+ * prune_small | stay << 1, min_batch.  kd_batch_set_split: a negative argument leaves that setting
+ * as it is; enable = 0 makes every later call of this batch a one-kernel call.  `stay`: a
+ * workgroup that finds nothing to do normally leaves the call once its XCD has more workgroups
+ * than unfinished utterances (its CUs go to the next call's kernels); with stay = 1 every
+ * workgroup stays until the call's last utterance is done -- for tests: a call of a few
+ * utterances then keeps workgroups of both kinds to change hands between. */
 int kd_batch_split_info(const kd_batch *b, int32_t *out);
 /* Diagnostic: where the two kinds of workgroups spent their time, summed over this batch's split
  * launches so far (shader-clock cycles of one lane per workgroup).  out[0..15], each a pair
@@ -388,7 +405,7 @@ int kd_batch_split_info(const kd_batch *b, int32_t *out);
  * that ran. */
 int kd_batch_sched_profile(kd_batch *b, int64_t *out);
 int kd_batch_set_split(kd_batch *b, int32_t enable, int32_t min_batch, int32_t mig_lo, int32_t mig_hi,
-                       int32_t prune_small);
+                       int32_t prune_small, int32_t stay);
 
 #ifdef __cplusplus
 }

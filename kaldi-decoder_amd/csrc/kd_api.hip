@@ -171,7 +171,7 @@ struct kd_batch {
   int split_min_batch = 0;        // ... and does for calls of at least this many utterances
   int cus = 0, large_cus = 0;
   int wgs_single = 1, wgs_large = 0, wgs_small = 0;  // workgroups of an unsplit launch / of a split one, at most
-  int mig_lo = 0, mig_hi = 0, prune_small = 0;
+  int mig_lo = 0, mig_hi = 0, prune_small = 0, stay = 0;
   SplitStreams split_streams;
   hipEvent_t ev_fork = nullptr, ev_join_l = nullptr, ev_join_s = nullptr;
   DevBuf<SchedCtl> sched_ctl;
@@ -200,6 +200,7 @@ struct kd_batch {
   // lattice state
   bool lattice = false, finalized = false, simple = false, log_softmax = false;
   bool lat_stats_valid = false;  // h_final_rel is current
+  bool lazy_prune = true;        // PruneActiveTokens owed, not run, until it shows (kd_batch_set_lazy_prune)
   int32_t exported_use_final = -1;  // the output pool holds GetRawLattice(use_final_probs = this)
   kd_lattice_options lo{};
   std::vector<float> h_final_rel;
@@ -310,6 +311,7 @@ struct kd_batch {
     p.lat.lattice_beam = lo.lattice_beam;
     p.lat.prune_interval = lattice && lo.prune_interval > 0 ? lo.prune_interval : 0x7FFFFFFF;
     p.lat.prune_scale = lo.prune_scale;
+    p.lat.prune_lazy = lazy_prune ? 1 : 0;
     p.lat.tok_extra = tok_extra.p;
     p.lat.tok_newid = tok_newid.p;
     p.lat.scratch = lat_scratch.p;
@@ -332,6 +334,7 @@ struct kd_batch {
     p.sched.mig_lo = mig_lo;
     p.sched.mig_hi = mig_hi;
     p.sched.prune_small = prune_small;
+    p.sched.stay = stay;
     p.sched.split = 0;
     return p;
   }
@@ -1018,6 +1021,7 @@ static int PrepareSplit(kd_batch *b) {
   b->mig_hi = std::max(1, std::min(EnvInt("KD_MIG_HI", std::min(64, SearchT1FrontSmall())), 1 << 20));
   b->mig_lo = std::max(0, std::min(EnvInt("KD_MIG_LO", std::min(32, b->mig_hi)), b->mig_hi));
   b->prune_small = EnvInt("KD_PRUNE_SMALL", 0) != 0 ? 1 : 0;
+  b->stay = EnvInt("KD_SPLIT_STAY", 0) != 0 ? 1 : 0;
   b->split_ok = true;
   return KD_OK;
 }
@@ -1043,6 +1047,7 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   b->wgs_single = std::min<int>(max_batch, cus * SearchWorkgroupsPerCu());
   b->workgroups = b->wgs_single;
   b->split_possible = !simple && cus >= 16;
+  b->lazy_prune = EnvInt("KD_PRUNE_LAZY", 1) != 0;
   // pools: 2^17 token records per utterance to begin with (an HLG decode at beam 15 writes
   // about 10^5 per 10 s utterance), two links per token; both grow on demand
   uint64_t tok = b->o.arena_tokens > 0 ? static_cast<uint64_t>(b->o.arena_tokens)
@@ -1769,6 +1774,13 @@ int kd_batch_capacity(const kd_batch *b, int64_t *out) {
   return KD_OK;
 }
 
+int kd_batch_set_lazy_prune(kd_batch *b, int32_t lazy) {
+  if (!b) return Fail(KD_E_INVALID, "bad argument");
+  if (b->pending) (void)ReadBack(b);
+  b->lazy_prune = lazy != 0;
+  return KD_OK;
+}
+
 int kd_batch_split_info(const kd_batch *b, int32_t *out) {
   if (!b || !out) return Fail(KD_E_INVALID, "bad argument");
   for (int i = 0; i < 8; ++i) out[i] = 0;
@@ -1779,7 +1791,7 @@ int kd_batch_split_info(const kd_batch *b, int32_t *out) {
   out[3] = b->wgs_small;
   out[4] = b->mig_lo;
   out[5] = b->mig_hi;
-  out[6] = b->prune_small;
+  out[6] = b->prune_small | (b->stay << 1);
   out[7] = b->split_min_batch;
   return KD_OK;
 }
@@ -1797,7 +1809,7 @@ int kd_batch_sched_profile(kd_batch *b, int64_t *out) {
 }
 
 int kd_batch_set_split(kd_batch *b, int32_t enable, int32_t min_batch, int32_t mig_lo, int32_t mig_hi,
-                       int32_t prune_small) {
+                       int32_t prune_small, int32_t stay) {
   if (!b) return Fail(KD_E_INVALID, "bad argument");
   if (b->pending) (void)ReadBack(b);
   if (!b->split_ok && enable > 0) {
@@ -1816,6 +1828,7 @@ int kd_batch_set_split(kd_batch *b, int32_t enable, int32_t min_batch, int32_t m
   if (enable >= 0) b->split_on = enable != 0;
   if (min_batch >= 1) b->split_min_batch = min_batch;
   if (prune_small >= 0) b->prune_small = prune_small != 0 ? 1 : 0;
+  if (stay >= 0) b->stay = stay != 0 ? 1 : 0;
   return KD_OK;
 }
 

@@ -174,6 +174,7 @@ struct SchedParams {
   int32_t total_wgs;              // workgroups of both kernels of this launch
   int32_t mig_lo, mig_hi;         // large -> small at n_in <= mig_lo; small -> large at n_in > mig_hi
   int32_t prune_small;            // 1: periodic pruning is handed to the small kind
+  int32_t stay;                   // 1: no workgroup leaves before the call's last utterance is done
   int32_t split;                  // 0: one kernel, no hand-overs (the kernel of rounds 1-5)
 };
 
@@ -221,6 +222,9 @@ struct LatticeParams {
   float lattice_beam;
   int32_t prune_interval;    // PruneActiveTokens every this many frames (lattice-simple-decoder.cc:57-59)
   float prune_scale;         // ... with delta = lattice_beam * prune_scale
+  int32_t prune_lazy;        // 1: a prune is only OWED when its frame comes, and run -- in order, with the
+                             // same result -- when the un-finalized lattice is exported or a frame
+                             // finds no room in the pools (kd_search.hip run_prunes)
   float *tok_extra;
   int32_t *tok_newid;        // [token pool] state id in the exported lattice, -1 if pruned
   uint32_t *scratch;         // [token pool] per-frame extra-cost keys beyond LDS

@@ -3678,19 +3678,65 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
     const int w = WaveSumInt(v);
     if ((tid & 63) == 0 && w) atomicAdd(&s.ustat[stat], static_cast<unsigned long long>(w));
   };
+  // ---- PruneActiveTokens, owed and paid (lattice decoders).  The reference prunes every
+  // prune_interval frames (lattice-simple-decoder.cc:57-59) to bound memory and the work of later
+  // prunes; what FinalizeDecoding leaves does not depend on it (the exact final
+  // pass recomputes every frame).  A prune at frame m reads and writes nothing of the frames
+  // above m -- their tokens do not exist yet when the reference runs it -- so it can be run at any
+  // LATER time with the same result, as long as the prunes run in order.  With prune_lazy the
+  // frame loop only notes that a prune is owed (the owed prunes are the multiples m of the
+  // interval with m - 1 > visited: no state of their own), and they are run, in order, when
+  // something can tell the difference: an export of the un-finalized lattice, or a frame that
+  // cannot get its token or link block -- the collector behind each prune frees the utterance's
+  // old chunks, so the owed prunes are this decoder's garbage collection.
+  [[maybe_unused]] auto first_owed = [&]() {  // (the interval is INT_MAX when pruning is off)
+    const int iv = c.P().lat.prune_interval;
+    return (visited + 1) / iv >= 0x7FFFFFFF / iv ? 0x7FFFFFFF : ((visited + 1) / iv + 1) * iv;
+  };
+  [[maybe_unused]] auto run_prunes = [&](int upto) -> uint32_t {  // every wave; prunes m <= upto
+    uint32_t pe = 0;
+    while (pe == 0) {
+      const int m = first_owed();
+      if (m > upto) break;
+      __syncthreads();
+      KD_LAP(s, 13);
+      if (tid == 0) {  // (the collector takes archive chunks through the same cursors' owner)
+        KD_G UttMem *um = ToG(c.P().mem) + utt;
+        um->arena_next = s.arena_next; um->arena_end = s.arena_end;
+        um->link_next = s.link_next; um->link_end = s.link_end;
+        s.stat[KD_STAT_PRUNES] += 1;
+      }
+      __syncthreads();
+      pe = Uni(PeriodicPrune(c.pp, utt, m, visited));
+      visited = m - 1;
+      __syncthreads();
+      // the sweep used the LDS block: the table is cleared again, the frontier comes
+      // back from the arena (this frame's log-likelihood row and the frame counters
+      // lie beyond what the sweep touches)
+      FullClear<true>(tl, s);
+      front_lds = false;
+      upper_dirty = false;
+      KD_LAP(s, 23);
+    }
+    return pe;
+  };
   if (tid == 0) kd_t_setup = static_cast<long long>(__builtin_amdgcn_s_memtime()) - kd_t_setup;
   int seg = kSegFinished;
+  [[maybe_unused]] bool gc_retry = false;  // this frame found no room in a pool: the owed prunes first
   while (err == 0 && frame < target) {
     KD_PHASE(c);  // (nothing loaded through the parameters lives across a frame)
-    [[maybe_unused]] bool prune_due = false;
-    if constexpr (M == 1) prune_due = frame > 0 && frame % c.P().lat.prune_interval == 0 && frame - 1 > visited;
+    [[maybe_unused]] bool prune_due = false, prune_now = false;
+    if constexpr (M == 1) {
+      prune_due = frame > 0 && frame % c.P().lat.prune_interval == 0 && frame - 1 > visited;
+      prune_now = prune_due && c.P().lat.prune_lazy == 0;
+    }
     // ---- does the utterance change hands here?  (workgroup-uniform; sizes of the decode and the
     // kinds of workgroups the launch has, never timings: which kind runs a frame changes nothing
     // of what the frame computes)
-    if (c.P().sched.split != 0 && frame >= 0) {
+    if (c.P().sched.split != 0 && frame >= 0 && !gc_retry) {
       bool go = false;
-      if constexpr (kKind == kKindLarge) go = c.n_in <= c.P().sched.mig_lo || (prune_due && c.P().sched.prune_small != 0);
-      else go = c.n_in > c.P().sched.mig_hi && !(prune_due && c.P().sched.prune_small != 0);
+      if constexpr (kKind == kKindLarge) go = c.n_in <= c.P().sched.mig_lo || (prune_now && c.P().sched.prune_small != 0);
+      else go = c.n_in > c.P().sched.mig_hi && !(prune_now && c.P().sched.prune_small != 0);
       // (the rest of the decision is off the frames' path: it is reached once per hand-over)
       if (go && Decide([&]() { return HandOver(c.P()); })) {
         seg = kKind == kKindLarge ? kSegToSmall : kSegToLarge;
@@ -3702,28 +3748,20 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
       // PruneActiveTokens every prune_interval frames, BEFORE the frame is processed like
       // the reference's (lattice-simple-decoder.cc:57-59) -- so a call that resumes on a
       // multiple of the interval (streaming in chunks of 1, 5, 25, ... frames) performs the
-      // prune its predecessor left pending.  Bounds what FinalizeDecoding will have to look
-      // at and, with it, memory.
-      if (prune_due) {
-        __syncthreads();
-        KD_LAP(s, 13);
-        if (tid == 0) {  // (the collector takes archive chunks through the same cursors' owner)
-          KD_G UttMem *m = ToG(c.P().mem) + utt;
-          m->arena_next = s.arena_next; m->arena_end = s.arena_end;
-          m->link_next = s.link_next; m->link_end = s.link_end;
-        }
-        __syncthreads();
-        const uint32_t pe = Uni(PeriodicPrune(c.pp, utt, frame, visited));
-        visited = frame - 1;
-        __syncthreads();
-        // the sweep used the LDS block: the table is cleared again, the frontier comes
-        // back from the arena (this frame's log-likelihood row and the frame counters
-        // lie beyond what the sweep touches)
-        FullClear<true>(tl, s);
-        front_lds = false;
-        upper_dirty = false;
-        KD_LAP(s, 23);
+      // prune its predecessor left pending.  Lazily (the default: LatticeParams::prune_lazy)
+      // the prune is only OWED here and performed when something can tell the difference
+      // (run_prunes below).
+      if (prune_now || gc_retry) {
+        const uint32_t pe = run_prunes(frame);
         if (pe) { err |= pe; break; }
+        if (gc_retry) {  // (the frame that found no room starts again from the arena)
+          gc_retry = false;
+          ResetFrame<M>(s);
+          if (tid < 4) s.frame_cnt[tid] = 0;
+          row_to_lds(frame);
+          __syncthreads();
+          best_stale = true;
+        }
       }
     }
     KD_LAP(s, 13);
@@ -3850,6 +3888,15 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
       __syncthreads();
     }
     if (r != 0) {
+      if constexpr (M == 1) {
+        // No room for this frame's tokens or links, and prunes are owed: they are run now -- the
+        // collector gives the utterance its old chunks back -- and the frame, which was not
+        // committed, starts again from the arena.
+        if ((r & (KD_UTT_ARENA_FULL | KD_UTT_LINKS_FULL)) != 0 && first_owed() <= frame) {
+          gc_retry = true;  // (at the top of the loop, where the prunes are run)
+          continue;
+        }
+      }
       if constexpr (kKind == kKindSmall) {
         // A frame that outgrew what this geometry's tables hold (its global table's worklist mask
         // lives in a third of the LDS) was not committed: it is a large workgroup's.
@@ -3871,6 +3918,17 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
 #endif
     if (kKind == kKindSmall && frame >= 0 && tid == 0) s.stat[KD_STAT_SMALL_WG_FRAMES] += 1;
     frame++;
+  }
+  if constexpr (M == 1) {
+    // GetRawLattice of the un-finalized lattice shows what the prunes the reference has run by
+    // now left: those at frames m < frame (the one at m == frame runs at the top of the NEXT
+    // frame's iteration, :57-59).  FinalizeDecoding needs none of them.
+    if (err == 0 && seg == kSegFinished && frame == target && frame > 0 &&
+        (ud.flags & (kUttExport | kUttExportNoFinal)) != 0 && (ud.flags & kUttFinalize) == 0 &&
+        Uni(ToG(c.P().lat.finalized)[utt]) == 0) {
+      const uint32_t pe = run_prunes(frame - 1);
+      if (pe) err |= pe;
+    }
   }
 
   __syncthreads();
@@ -4043,7 +4101,7 @@ __global__ __launch_bounds__(kBlock, (KD_WG_PER_CU * (KD_BLOCK / 64) + 3) / 4) v
         }
         if (AgentLoad(&p.sched.ctl->n_finished) >= static_cast<uint32_t>(p.batch)) break;
         // More workgroups than unfinished utterances on this XCD: this one leaves (SchedCtl::live).
-        {
+        if (p.sched.stay == 0) {
           unsigned long long *lw = &p.sched.ctl->live[xcd];
           unsigned long long w = __hip_atomic_load(lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           bool left = false;

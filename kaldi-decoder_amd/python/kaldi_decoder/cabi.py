@@ -22,7 +22,7 @@ CAPACITY_NAMES = ("arena_tokens", "arena_links", "table_slots", "max_frames", "t
                   "links_used", "grow_events", "workgroups")
 STAT_NAMES = ("frames", "tokens_in", "tokens_expanded", "arcs_scanned", "arcs_kept",
               "tokens_out", "eps_arcs_scanned", "eps_expansions", "max_tokens", "spill_frames",
-              "links", "small_frames", "arcs_skipped", "index_probes", "handovers", "small_wg_frames")
+              "links", "small_frames", "arcs_skipped", "index_probes", "handovers", "small_wg_frames", "prunes")
 
 # every symbol include/kd_hip.h declares
 SYMBOLS = (
@@ -38,7 +38,7 @@ SYMBOLS = (
     "kd_batch_final_relative_cost", "kd_batch_raw_lattice_prepare", "kd_batch_raw_lattice_copy",
     "kd_batch_create_simple", "kd_batch_decode_async", "kd_batch_decode", "kd_batch_capacity",
     "kd_batch_set_output_buffer", "kd_batch_raw_lattice_table", "kd_batch_set_log_softmax",
-    "kd_batch_split_info", "kd_batch_set_split", "kd_batch_sched_profile",
+    "kd_batch_split_info", "kd_batch_set_split", "kd_batch_sched_profile", "kd_batch_set_lazy_prune",
 )
 SPLIT_NAMES = ("split", "large_cus", "large_workgroups", "small_workgroups", "mig_lo", "mig_hi",
                "prune_small", "min_batch")
@@ -111,8 +111,9 @@ def lib():
                                              C.c_void_p, C.c_int32, C.c_int64, C.c_int32]
     L.kd_batch_capacity.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int64)]
     L.kd_batch_split_info.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int32)]
+    L.kd_batch_set_lazy_prune.argtypes = [C.c_void_p, C.c_int32]
     L.kd_batch_sched_profile.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.int64)]
-    L.kd_batch_set_split.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.kd_batch_set_split.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.kd_batch_num_frames_decoded.argtypes = [C.c_void_p, _i32p]
     L.kd_batch_status.argtypes = [C.c_void_p, np.ctypeslib.ndpointer(np.uint32)]
     L.kd_batch_reached_final.argtypes = [C.c_void_p, _i32p]
@@ -390,6 +391,11 @@ class Batch:
         _check(lib().kd_batch_split_info(self.h, out))
         return dict(zip(SPLIT_NAMES, out.tolist()))
 
+    def set_lazy_prune(self, lazy):
+        """PruneActiveTokens owed (run on un-finalized export or when a pool fills) or run when
+        its frame comes, like the reference (kd_hip.h kd_batch_set_lazy_prune)."""
+        _check(lib().kd_batch_set_lazy_prune(self.h, int(bool(lazy))))
+
     def sched_profile(self):
         """Cycles and counts per kind of workgroup (kd_hip.h kd_batch_sched_profile)."""
         out = np.zeros(16, np.int64)
@@ -397,8 +403,9 @@ class Batch:
         names = ("idle", "setup", "busy", "pop", "fresh", "resumed", "stolen", "workgroups")
         return {n: dict(small=int(out[2 * i]), large=int(out[2 * i + 1])) for i, n in enumerate(names)}
 
-    def set_split(self, enable=-1, min_batch=-1, mig_lo=-1, mig_hi=-1, prune_small=-1):
-        _check(lib().kd_batch_set_split(self.h, int(enable), min_batch, mig_lo, mig_hi, int(prune_small)))
+    def set_split(self, enable=-1, min_batch=-1, mig_lo=-1, mig_hi=-1, prune_small=-1, stay=-1):
+        _check(lib().kd_batch_set_split(self.h, int(enable), min_batch, mig_lo, mig_hi, int(prune_small),
+                                        int(stay)))
 
     def num_frames_decoded(self):
         out = np.zeros(self.batch, np.int32)

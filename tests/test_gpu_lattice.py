@@ -358,9 +358,10 @@ def test_more_utterances_than_workgroups_and_table_growth_mid_launch(oracle):
             _assert_same_lattice(gl, cl, i)
 
 
+@pytest.mark.parametrize("lazy", [0, 1], ids=["run", "owed"])
 @pytest.mark.parametrize("prune_interval", [1, 2, 7])
 @pytest.mark.parametrize("case", list(_cases()), ids=lambda c: c[0])
-def test_periodic_pruning_and_collection_leave_the_lattice_unchanged(oracle, case, prune_interval):
+def test_periodic_pruning_and_collection_leave_the_lattice_unchanged(oracle, case, prune_interval, lazy):
     """PruneActiveTokens every prune_interval frames (lattice-simple-decoder.cc:57-59) and
     the collector that moves the survivors of older frames into the archive: whatever the
     interval, the finalized lattice is the canonical oracle's; so is the lattice exported
@@ -378,7 +379,10 @@ def test_periodic_pruning_and_collection_leave_the_lattice_unchanged(oracle, cas
         can.decode(lp)
         want.append((can.get_raw_lattice(), can.final_relative_cost()))
     # one launch
+    # (lazy = 0: every prune when its frame comes, like the reference; 1: owed until it shows --
+    # here at the un-finalized export in the middle of the chunked decode)
     lb = cabi.LatticeBatch(G, max_batch=B, prune_interval=prune_interval, **opts)
+    lb.set_lazy_prune(lazy)
     lb.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V)
     for i, lat in enumerate(lb.raw_lattices()):
         _assert_same_lattice(lat, want[i][0], (name, prune_interval, i))
@@ -386,6 +390,7 @@ def test_periodic_pruning_and_collection_leave_the_lattice_unchanged(oracle, cas
     # in chunks of 11 frames (sweeps and collections fall on and between launch boundaries),
     # un-finalized export in the middle, then FinalizeDecoding as a call of its own
     st = cabi.LatticeBatch(G, max_batch=B, prune_interval=prune_interval, **opts)
+    st.set_lazy_prune(lazy)
     st.init_decoding(B)
     for t0 in range(0, T, 11):
         st.advance_host(lps, max_num_frames=11)
@@ -414,6 +419,7 @@ def test_periodic_pruning_bounds_memory(oracle):
     with pytest.raises(RuntimeError, match="pool full"):
         off.decode_device([dev.data_ptr()], [T], V)
     on = cabi.LatticeBatch(G, max_batch=1, prune_interval=25, **kw, **opts)
+    on.set_lazy_prune(0)  # (every prune when its frame comes, like the reference: tests/test_gpu_lazy_prune.py has the other way)
     on.decode_device([dev.data_ptr()], [T], V)
     assert on.num_frames_decoded().tolist() == [T]
     can = oracle.CanonLatticeDecoder(OG, **opts)
@@ -440,6 +446,7 @@ def test_streaming_in_chunks_of_prune_interval_still_prunes(oracle):
     kw = dict(arena_tokens=1 << 16, arena_links=1 << 18, max_frames=T, no_grow=1)
     for chunk in (25, 5, 50):
         lb = cabi.LatticeBatch(G, max_batch=1, prune_interval=25, **kw, **opts)
+        lb.set_lazy_prune(0)  # (the footprint bound asserted below is the eager prunes')
         lb.init_decoding()
         while lb.num_frames_decoded()[0] < T:
             lb.advance_device([dev.data_ptr()], [T], V, max_num_frames=chunk)

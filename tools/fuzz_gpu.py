@@ -62,7 +62,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     t_end = time.time() + budget
-    n_cases = n_lat = n_1b = n_bad = 0
+    n_cases = n_lat = n_1b = n_bad = n_split = n_hand = 0
     keep_going = os.environ.get("KD_FUZZ_KEEP_GOING") == "1"  # (diagnosis: count mismatches, do not stop)
     while time.time() < t_end:
         g, lex, V = graph(rng)
@@ -96,18 +96,20 @@ def main():
         hi = int(rng.choice([1, 2, 4, 8, 16, 64, 256]))
         lo = int(rng.integers(0, hi + 1))
         psm = int(rng.integers(0, 2))
+        stay = int(rng.random() < 0.75)  # (else surplus workgroups leave a call of a few utterances at once)
+        lazy = int(rng.integers(0, 2))   # PruneActiveTokens owed (run when a pool fills) or run when its frame comes
 
         def deal(b):
             try:
                 if split:
-                    b.set_split(enable=1, min_batch=1, mig_lo=lo, mig_hi=hi, prune_small=psm)
+                    b.set_split(enable=1, min_batch=1, mig_lo=lo, mig_hi=hi, prune_small=psm, stay=stay)
                 else:
                     b.set_split(enable=0)
             except RuntimeError as e:
                 if "second kernel" not in str(e):
                     raise
         tag = dict(B=B, T=T, V=V, beam=beam, ma=ma, mi=mi, small=small, one=one_launch, chunk=chunk,
-                   states=g["num_states"], split=split, lo=lo, hi=hi, psm=psm)
+                   states=g["num_states"], split=split, lo=lo, hi=hi, psm=psm, stay=stay, lazy=lazy)
         if rng.random() < 0.6:
             lbeam = float(rng.uniform(1, 8))
             pi = int(rng.integers(1, 30)) if rng.random() < 0.7 else 10**6
@@ -116,6 +118,7 @@ def main():
                 cap["arena_links"] = int(rng.integers(256, 4096))
             lb = cabi.LatticeBatch(G, max_batch=B, prune_interval=pi, **opts, **cap)
             deal(lb)
+            lb.set_lazy_prune(lazy)
             if one_launch:
                 lb.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V)
             else:
@@ -124,6 +127,7 @@ def main():
                     lb.advance_host(lps, max_num_frames=chunk)
                 lb.finalize_decoding()
             lats, frc = lb.raw_lattices(), lb.final_relative_cost()
+            n_hand += int(lb.stats()[:, cabi.STAT_NAMES.index("handovers")].sum())
             for i, lp in enumerate(lps):
                 can = oracle.CanonLatticeDecoder(OG, **opts)
                 can.decode(lp)
@@ -147,6 +151,7 @@ def main():
                     bt.advance_host(lps, max_num_frames=chunk)
             uf = bool(rng.integers(0, 2))
             paths, rf = bt.best_paths(uf), bt.reached_final()
+            n_hand += int(bt.stats()[:, cabi.STAT_NAMES.index("handovers")].sum())
             for i, lp in enumerate(lps):
                 d = oracle.FasterDecoder(OG, policy=1, **opts)
                 d.decode(lp)
@@ -161,10 +166,15 @@ def main():
                         sys.exit(1)
             n_1b += 1
         n_cases += 1
+        n_split += int(split)
     if n_bad:
         print(f"fuzz FAILED: {n_bad} mismatching utterances in {n_cases} cases")
         sys.exit(1)
-    print(f"fuzz ok: {n_cases} cases ({n_lat} lattice, {n_1b} 1-best) in {budget:.0f} s")
+    if n_split >= 50 and n_hand == 0:
+        print(f"fuzz FAILED: {n_split} cases dealt out over two kinds of workgroups and not one hand-over")
+        sys.exit(1)
+    print(f"fuzz ok: {n_cases} cases ({n_lat} lattice, {n_1b} 1-best; {n_split} over two kinds of "
+          f"workgroups, {n_hand} hand-overs) in {budget:.0f} s")
 
 
 if __name__ == "__main__":

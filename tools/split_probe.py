@@ -27,7 +27,7 @@ for st in settings:
     if f[1] == "off":
         bt.set_split(enable=0)
     else:
-        bt.set_split(enable=1, min_batch=1, mig_lo=int(f[1]), mig_hi=int(f[2]), prune_small=int(f[3]))
+        bt.set_split(enable=1, min_batch=1, mig_lo=int(f[1]), mig_hi=int(f[2]), prune_small=int(f[3]), stay=int(f[4]) if len(f) > 4 else 0)
     ms = []
     for it in range(4):
         bt.decode_device(ptrs, [T] * N, V)
