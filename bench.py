@@ -91,7 +91,7 @@ def algorithmic_bytes(stats, V):
         max_tokens=int(stats[:, 8].max()), spill_frames=int(s[9])), (16 * a_scan + rest)
 
 
-def profiled_traffic(workload_desc, utt_frames_per_launch, prune_interval):
+def profiled_traffic(workload_desc, utt_frames_per_launch, prune_interval, min_active=0):
     """HBM bytes per launch from the newest committed rocprofv3 PMC summary
     (profiles/rNN_summary.json, written by tools/summarize_profile.py from separate
     --pmc FETCH_SIZE / WRITE_SIZE passes of this same command); None if there is
@@ -109,6 +109,8 @@ def profiled_traffic(workload_desc, utt_frames_per_launch, prune_interval):
         line = d.get("bench_line_under_profiler", {})
         cfg = line.get("config", {})
         if cfg.get("workload") != workload_desc or cfg.get("prune_interval") != prune_interval:
+            continue
+        if (cfg.get("min_active") or 0) != (min_active or 0):  # (rNN_min200: another configuration)
             continue
         if "hbm_bytes_per_launch" not in d:  # (a trace-only summary: no counter passes)
             continue
@@ -790,7 +792,7 @@ def main():
     elif rank == 0:
         alg_bytes, per_frame, alg_bytes_all_arcs = algorithmic_bytes(stats, V)  # of one full launch (n_last steps)
         k_ms = float(np.mean([k for k, n in launches if n == n_last] or [k for k, _ in launches]))
-        traffic = profiled_traffic(wl["desc"], n_last * B * T, opts.get("prune_interval"))
+        traffic = profiled_traffic(wl["desc"], n_last * B * T, opts.get("prune_interval"), opts.get("min_active", 0))
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         frames_total = world * B * T * steps_timed
         cap = bt.capacity()
@@ -832,6 +834,7 @@ def main():
             "config": {"workload": wl["desc"], "graph_states": info["states"],
                        "graph_arcs": info["arcs"], "batch_per_gpu": B, "frames": T,
                        "prune_interval": (args.prune_interval or wl["opts"].get("prune_interval")),
+                       "min_active": opts.get("min_active", 0),
                        "prune_policy": ("owed: run on un-finalized export or when a pool is full "
                                         "(library default; prunes run in the timed region: %d)"
                                         % int(stats[:, len(cabi.STAT_NAMES) - 1].sum())) if wl["lattice"] else None,

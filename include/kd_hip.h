@@ -373,9 +373,11 @@ int kd_batch_capacity(const kd_batch *b, int64_t *out);
  * leaves does not depend on it.  With lazy != 0 (the default) a prune is only OWED when its frame
  * comes and is run later -- the owed ones in order, each exactly as it would have run then: a prune
  * at frame m touches nothing above m -- when something can tell the difference: GetRawLattice of
- * the un-finalized lattice (kd_batch_raw_lattice_prepare before kd_batch_finalize_decoding), or a
- * frame that finds no room in the token or link pool (the collector behind a prune returns the
- * utterance's old chunks: the pools are garbage-collected before they are grown).  lazy = 0: every
+ * the un-finalized lattice (kd_batch_raw_lattice_prepare before kd_batch_finalize_decoding), or
+ * memory: once three quarters of the token or link pool have been handed out prunes are paid when
+ * their frames come, and a frame that finds no room runs what it owes and starts again (the
+ * collector behind a prune returns the utterance's old chunks: the pools are garbage-collected
+ * before they are grown).  lazy = 0: every
  * prune runs when its frame comes, as in the reference.  Results are the same either way; memory
  * follows the utterance's length instead of its pruned lattice until a pool fills. */
 int kd_batch_set_lazy_prune(kd_batch *b, int32_t lazy);

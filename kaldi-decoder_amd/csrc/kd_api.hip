@@ -746,9 +746,13 @@ int ReadBack(kd_batch *b) {
     }
     if (any & KD_UTT_OUT_FULL) {
       if (int r = GrowOut(b)) return r;
-      b->out_base = b->out_raw;  // every utterance exports again, into the larger pool
-      b->h_out_top = 0;
     }
+    // every utterance's tail runs again in the launch that resumes the stopped ones, and exports
+    // again: from the start of the output pool (grown or not), not behind what this launch
+    // exported -- a call that is resumed three times must not need four times the pool (round 6:
+    // a lent buffer sized for one export of the call was "full" after two resumptions)
+    b->out_base = b->out_raw;
+    b->h_out_top = 0;
     // resume: utterances that never got past InitDecoding start over, the others go on
     // from their last committed frame
     UttCtl *uc = b->h_ctl();

@@ -3728,7 +3728,18 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
     [[maybe_unused]] bool prune_due = false, prune_now = false;
     if constexpr (M == 1) {
       prune_due = frame > 0 && frame % c.P().lat.prune_interval == 0 && frame - 1 > visited;
-      prune_now = prune_due && c.P().lat.prune_lazy == 0;
+      // (owed prunes are paid when their frame comes after all once three quarters of a pool
+      // have been handed out: the collector behind a prune needs room for the archive copies it
+      // makes, and every other utterance of the batch goes on allocating until its own next
+      // prune, so the garbage collection must not wait for the pool to be exhausted -- one lane
+      // looks at the cursors, every prune_interval frames)
+      prune_now = prune_due &&
+                  (c.P().lat.prune_lazy == 0 || Decide([&]() {
+                     CParams &q = c.P();
+                     const unsigned long long tu = __hip_atomic_load(&q.ctl->tok_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - q.tok_base;
+                     const unsigned long long lu = __hip_atomic_load(&q.ctl->link_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - q.link_base;
+                     return tu * 4 >= q.tok_cap * 3 || lu * 4 >= q.link_cap * 3;
+                   }));
     }
     // ---- does the utterance change hands here?  (workgroup-uniform; sizes of the decode and the
     // kinds of workgroups the launch has, never timings: which kind runs a frame changes nothing

@@ -109,16 +109,20 @@ def test_negative_arc_on_a_positive_cycle_is_accepted_and_nan_is_not(driver):
     assert out[3].startswith("0") and "NaN" in out[3]
 
 
-def test_ilabels_beyond_twenty_bits_are_refused():
-    """An arc record keeps 20 bits for the ilabel (the other 12 carry the destination's arc
-    degrees): kd_graph_create says so instead of truncating.  (Checked before the GPU is
-    touched: this needs none.)"""
+def test_ilabels_beyond_twenty_bits_are_not_refused():
+    """Until round 6 kd_graph_create refused an ilabel that does not fit the arc record's 20 bits;
+    now the field's largest value is an escape code and the label stands in a side array
+    (kd_device.h kIlabelEscape; the decode: tests/test_kat.py).  Without a GPU the upload fails --
+    not a label check.  A negative label is still refused (before the GPU is touched)."""
     from kaldi_decoder import cabi, synth
-    g = synth.graph_from_arcs(2, 0, [(0, 1, (1 << 20), 0, 0.5)], {1: 0.0})
-    with pytest.raises(RuntimeError, match="exceeds the largest supported"):
+    for lab in ((1 << 20) - 1, 1 << 20, (1 << 31) - 1):
+        g = synth.graph_from_arcs(2, 0, [(0, 1, lab, 0, 0.5)], {1: 0.0})
+        try:
+            cabi.Graph(g)
+        except RuntimeError as e:
+            assert "largest supported" not in str(e) and cabi.device_count() == 0, e
+    g = synth.graph_from_arcs(2, 0, [(0, 1, 3, 0, 0.5)], {1: 0.0})
+    g["ilabel"] = g["ilabel"].copy()
+    g["ilabel"][0] = -1
+    with pytest.raises(RuntimeError, match="negative ilabel"):
         cabi.Graph(g)
-    g = synth.graph_from_arcs(2, 0, [(0, 1, (1 << 20) - 1, 0, 0.5)], {1: 0.0})
-    try:
-        cabi.Graph(g)
-    except RuntimeError as e:  # (without a GPU the upload fails -- not the label check)
-        assert "largest supported" not in str(e) and cabi.device_count() == 0, e

@@ -6,6 +6,8 @@
 # SearchKernel<1>.  Then: python tools/summarize_counters.py rNN
 R=${1:-r02}
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
+# (which library these numbers are of: tools/check_profiles.py compares it with the shipped one)
+sha256sum "$ROOT"/kaldi-decoder_amd/python/kaldi_decoder/lib/libkd_hip.so | cut -c1-16 > "$ROOT"/gpurun_out/pmc_${R}_lib.sha256
 cd /tmp && export TMPDIR=/tmp
 i=0
 for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \

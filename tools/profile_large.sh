@@ -4,6 +4,8 @@
 R=${1:-r03}
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p "$ROOT"/gpurun_out
+# (which library these numbers are of: tools/check_profiles.py compares it with the shipped one)
+sha256sum "$ROOT"/kaldi-decoder_amd/python/kaldi_decoder/lib/libkd_hip.so | cut -c1-16 > "$ROOT"/gpurun_out/prof_${R}_large_lib.sha256
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$ROOT"/gpurun_out/prof_${R}_large
 rocprofv3 --kernel-trace --stats -d "$ROOT"/gpurun_out/prof_${R}_large -o runc -f csv -- python3 "$ROOT"/bench.py --workload hlg-large --no-cpu --headline-only > "$ROOT"/gpurun_out/prof_${R}_large.json 2> "$ROOT"/gpurun_out/prof_${R}_large.err

@@ -58,5 +58,7 @@ d["derived"] = {
 }
 if "TCC_HIT_sum" in out and "TCC_REQ_sum" in out:
     d["l2_hit_rate"] = out["TCC_HIT_sum"] / out["TCC_REQ_sum"]
+_h = os.path.join(ROOT, "gpurun_out", f"pmc_{rnd}_lib.sha256")
+d["library_sha256"] = open(_h).read().strip() if os.path.exists(_h) else None  # (tools/check_profiles.py)
 json.dump(d, open(os.path.join(ROOT, "profiles", f"{rnd}_search_counters.json"), "w"), indent=1)
 print(json.dumps(d, indent=1))

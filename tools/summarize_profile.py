@@ -51,6 +51,11 @@ def counter(path, name):
     return sum(vals) / len(vals), len(vals)
 
 
+def lib_hash(name):
+    p = os.path.join(ROOT, "gpurun_out", name)
+    return open(p).read().strip() if os.path.exists(p) else None
+
+
 def main():
     rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
     large = len(sys.argv) > 2 and sys.argv[2] == "large"
@@ -105,6 +110,8 @@ def main():
                 "figure is an upper estimate (raw counter is half of it).  Counter passes serialise "
                 "the launches; the trace pass does not (launches of calls in flight overlap).",
         "bench_line_under_profiler": bench,
+        # sha256[:16] of libkd_hip.so on the box that made the traces (tools/check_profiles.py)
+        "library_sha256": lib_hash(f"{d_trace.replace('_trace', '')}_lib.sha256"),
     }
     with open(os.path.join(out, f"{name}_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
