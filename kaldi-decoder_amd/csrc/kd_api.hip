@@ -1052,10 +1052,12 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   b->workgroups = b->wgs_single;
   b->split_possible = !simple && cus >= 16;
   b->lazy_prune = EnvInt("KD_PRUNE_LAZY", 1) != 0;
-  // pools: 2^17 token records per utterance to begin with (an HLG decode at beam 15 writes
-  // about 10^5 per 10 s utterance), two links per token; both grow on demand
+  // pools: 160 k token records per utterance to begin with (an HLG decode at beam 15 writes
+  // about 10^5 per 10 s utterance; with PruneActiveTokens owed, not run, they all stay until
+  // FinalizeDecoding, and the owed prunes start to be paid when three quarters of a pool have
+  // been handed out: kd_search.hip run_prunes), two links per token; both grow on demand
   uint64_t tok = b->o.arena_tokens > 0 ? static_cast<uint64_t>(b->o.arena_tokens)
-                                        : std::max<uint64_t>(1ull << 20, static_cast<uint64_t>(max_batch) << 17);
+                                        : std::max<uint64_t>(1ull << 20, static_cast<uint64_t>(max_batch) * 163840ull);
   b->tok_cap = std::min<uint64_t>(tok, kIndexLimit);
   b->o.arena_tokens = static_cast<int64_t>(b->tok_cap);
   b->tok_chunk = static_cast<int32_t>(std::min<uint64_t>(8192, std::max<uint64_t>(64, b->tok_cap / (8ull * b->workgroups))));

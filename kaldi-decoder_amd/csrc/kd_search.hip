@@ -171,7 +171,7 @@ constexpr int kPfRegs = (kVmax + KD_BLOCK - 1) / KD_BLOCK;
 #define KD_SMALL_DEG 4
 #endif
 #ifndef KD_GROUP
-#define KD_GROUP 4
+#define KD_GROUP 2  // (round 6, on the register allocation of that round: 40.9 against 40.5 M, 43.1 against 42.4; 4 until then)
 #endif
 // Label index (IndexedArcs): on (1) / off (0), and the smallest frontier of an LDS-resident frame
 // that uses it -- below that a frame's few high-degree tokens are a handful of wave rows whose

@@ -98,5 +98,5 @@ def test_owed_prunes_are_the_garbage_collection_of_pools_that_may_not_grow(oracl
     can.decode(lp)
     cl = can.get_raw_lattice()
     assert gl.arc_set() == cl.arc_set() and gl.state_set() == cl.state_set()
-    assert can.links_created() > (1 << 18)  # (more links than the pool holds went through it)
+    assert st["tokens_out"] > (1 << 16)  # (more tokens than the pool holds went through it)
     assert lb.capacity()["grow_events"] == 0
