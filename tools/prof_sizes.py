@@ -27,6 +27,8 @@ dev = torch.from_numpy(np.stack(lps)).cuda()
 opts = dict(wl["opts"])
 if os.environ.get("KD_PRUNE_INTERVAL"):
     opts["prune_interval"] = int(os.environ["KD_PRUNE_INTERVAL"])
+if os.environ.get("KD_MIN_ACTIVE"):  # (200: LatticeFasterDecoderConfig's default)
+    opts["min_active"] = int(os.environ["KD_MIN_ACTIVE"])
 bt = (cabi.LatticeBatch if wl["lattice"] else cabi.Batch)(G, max_batch=B, max_frames=T, **opts)
 for _ in range(2):
     bt.decode_device([dev[i].data_ptr() for i in range(B)], [T] * B, V)
