@@ -374,12 +374,13 @@ int kd_batch_capacity(const kd_batch *b, int64_t *out);
  * comes and is run later -- the owed ones in order, each exactly as it would have run then: a prune
  * at frame m touches nothing above m -- when something can tell the difference: GetRawLattice of
  * the un-finalized lattice (kd_batch_raw_lattice_prepare before kd_batch_finalize_decoding), or
- * memory: once three quarters of the token or link pool have been handed out prunes are paid when
- * their frames come, and a frame that finds no room runs what it owes and starts again (the
- * collector behind a prune returns the utterance's old chunks: the pools are garbage-collected
- * before they are grown).  lazy = 0: every
+ * memory: a pool that is not to grow any further -- `no_grow`, or it has reached the batch's budget
+ * (2^29 token / 2^30 link records: 13 + 26 GB) -- is garbage-collected instead: once three
+ * quarters of it have been handed out prunes are paid when their frames come, and a frame that
+ * finds no room runs what it owes and starts again (the collector behind a prune returns the
+ * utterance's old chunks).  A pool that may still grow is grown: memory for time.  lazy = 0: every
  * prune runs when its frame comes, as in the reference.  Results are the same either way; memory
- * follows the utterance's length instead of its pruned lattice until a pool fills. */
+ * follows the utterance's length instead of its pruned lattice until a pool reaches its budget. */
 int kd_batch_set_lazy_prune(kd_batch *b, int32_t lazy);
 
 /* How a call's utterances are dealt out on the chip (round 6).  A call of at least

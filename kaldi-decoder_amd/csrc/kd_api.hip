@@ -201,6 +201,7 @@ struct kd_batch {
   bool lattice = false, finalized = false, simple = false, log_softmax = false;
   bool lat_stats_valid = false;  // h_final_rel is current
   bool lazy_prune = true;        // PruneActiveTokens owed, not run, until it shows (kd_batch_set_lazy_prune)
+  uint64_t gc_tok_budget = 1ull << 29, gc_link_budget = 1ull << 30;  // pools of this size collect, not grow
   int32_t exported_use_final = -1;  // the output pool holds GetRawLattice(use_final_probs = this)
   kd_lattice_options lo{};
   std::vector<float> h_final_rel;
@@ -312,6 +313,11 @@ struct kd_batch {
     p.lat.prune_interval = lattice && lo.prune_interval > 0 ? lo.prune_interval : 0x7FFFFFFF;
     p.lat.prune_scale = lo.prune_scale;
     p.lat.prune_lazy = lazy_prune ? 1 : 0;
+    // Owed prunes are a pool's garbage collection only when it is not to grow: no_grow, or the
+    // batch's budget reached (KD_GC_TOKENS / KD_GC_LINKS records; default 2^29 / 2^30: 12.9 GB of
+    // token and 25.8 GB of link records -- a 1024-utterance call of the large-LM workload un-pruned).
+    p.lat.gc_tokens = (o.no_grow || tok_cap >= gc_tok_budget) ? 1 : 0;
+    p.lat.gc_links = (o.no_grow || link_cap >= gc_link_budget) ? 1 : 0;
     p.lat.tok_extra = tok_extra.p;
     p.lat.tok_newid = tok_newid.p;
     p.lat.scratch = lat_scratch.p;
@@ -735,10 +741,20 @@ int ReadBack(kd_batch *b) {
     if (int r = pull_back(&b->link_raw, b->link_base, b->link_cap, offsetof(BatchCtl, link_top))) return r;
     b->h_tok_top = b->tok_raw - b->tok_base;
     b->h_link_top = b->link_raw - b->link_base;
+    // (a pool that cannot grow -- the device is out of memory, or the index limit -- is
+    // garbage-collected from here on if prunes may be owed: Params() tells the kernel so; a pool
+    // that could not grow AND is already collected is the end)
+    auto grow_or_collect = [&](int (*grow)(kd_batch *), uint64_t *budget, uint64_t cap) -> int {
+      const int r = grow(b);
+      if (r == KD_OK) return KD_OK;
+      if (!b->lattice || !b->lazy_prune || b->o.no_grow || cap >= *budget) return r;
+      *budget = cap;  // (gc_tokens / gc_links from the next launch on)
+      return KD_OK;
+    };
     if (any & KD_UTT_ARENA_FULL)
-      if (int r = GrowTokens(b)) return r;
+      if (int r = grow_or_collect(GrowTokens, &b->gc_tok_budget, b->tok_cap)) return r;
     if (any & KD_UTT_LINKS_FULL)
-      if (int r = GrowLinks(b)) return r;
+      if (int r = grow_or_collect(GrowLinks, &b->gc_link_budget, b->link_cap)) return r;
     if (any & KD_UTT_TABLE_FULL) {
       if (int r = GrowTables(b)) return r;
     } else if (any & KD_UTT_PATH_QUEUE_FULL) {
@@ -1052,12 +1068,12 @@ static int CreateBatch(const kd_graph *g, const kd_faster_options *opts,
   b->workgroups = b->wgs_single;
   b->split_possible = !simple && cus >= 16;
   b->lazy_prune = EnvInt("KD_PRUNE_LAZY", 1) != 0;
-  // pools: 160 k token records per utterance to begin with (an HLG decode at beam 15 writes
-  // about 10^5 per 10 s utterance; with PruneActiveTokens owed, not run, they all stay until
-  // FinalizeDecoding, and the owed prunes start to be paid when three quarters of a pool have
-  // been handed out: kd_search.hip run_prunes), two links per token; both grow on demand
+  if (const char *v = std::getenv("KD_GC_TOKENS")) b->gc_tok_budget = std::strtoull(v, nullptr, 10);
+  if (const char *v = std::getenv("KD_GC_LINKS")) b->gc_link_budget = std::strtoull(v, nullptr, 10);
+  // pools: 2^17 token records per utterance to begin with (an HLG decode at beam 15 writes
+  // about 10^5 per 10 s utterance), two links per token; both grow on demand
   uint64_t tok = b->o.arena_tokens > 0 ? static_cast<uint64_t>(b->o.arena_tokens)
-                                        : std::max<uint64_t>(1ull << 20, static_cast<uint64_t>(max_batch) * 163840ull);
+                                        : std::max<uint64_t>(1ull << 20, static_cast<uint64_t>(max_batch) << 17);
   b->tok_cap = std::min<uint64_t>(tok, kIndexLimit);
   b->o.arena_tokens = static_cast<int64_t>(b->tok_cap);
   b->tok_chunk = static_cast<int32_t>(std::min<uint64_t>(8192, std::max<uint64_t>(64, b->tok_cap / (8ull * b->workgroups))));

@@ -222,6 +222,8 @@ struct LatticeParams {
   float lattice_beam;
   int32_t prune_interval;    // PruneActiveTokens every this many frames (lattice-simple-decoder.cc:57-59)
   float prune_scale;         // ... with delta = lattice_beam * prune_scale
+  int32_t gc_tokens, gc_links;  // 1: that pool is not to grow any further (no_grow, or it has reached the
+                             // batch's memory budget): owed prunes are its garbage collection
   int32_t prune_lazy;        // 1: a prune is only OWED when its frame comes, and run -- in order, with the
                              // same result -- when the un-finalized lattice is exported or a frame
                              // finds no room in the pools (kd_search.hip run_prunes)

@@ -3729,16 +3729,19 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
     if constexpr (M == 1) {
       prune_due = frame > 0 && frame % c.P().lat.prune_interval == 0 && frame - 1 > visited;
       // (owed prunes are paid when their frame comes after all once three quarters of a pool
-      // have been handed out: the collector behind a prune needs room for the archive copies it
-      // makes, and every other utterance of the batch goes on allocating until its own next
-      // prune, so the garbage collection must not wait for the pool to be exhausted -- one lane
-      // looks at the cursors, every prune_interval frames)
+      // THAT IS NOT TO GROW ANY FURTHER -- no_grow, or the batch's memory budget reached: the host
+      // says which, gc_tokens / gc_links -- have been handed out: the collector behind a prune
+      // needs room for the archive copies it makes, and every other utterance of the batch goes
+      // on allocating until its own next prune, so the garbage collection must not wait for the
+      // pool to be exhausted -- one lane looks at the cursors, every prune_interval frames.  A
+      // pool that may still grow is grown instead: memory for time)
       prune_now = prune_due &&
                   (c.P().lat.prune_lazy == 0 || Decide([&]() {
                      CParams &q = c.P();
                      const unsigned long long tu = __hip_atomic_load(&q.ctl->tok_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - q.tok_base;
                      const unsigned long long lu = __hip_atomic_load(&q.ctl->link_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - q.link_base;
-                     return tu * 4 >= q.tok_cap * 3 || lu * 4 >= q.link_cap * 3;
+                     return (q.lat.gc_tokens != 0 && tu * 4 >= q.tok_cap * 3) ||
+                            (q.lat.gc_links != 0 && lu * 4 >= q.link_cap * 3);
                    }));
     }
     // ---- does the utterance change hands here?  (workgroup-uniform; sizes of the decode and the
@@ -3900,10 +3903,12 @@ __device__ __forceinline__ int RunUtterance(CParams &p, Shared &s, const int utt
     }
     if (r != 0) {
       if constexpr (M == 1) {
-        // No room for this frame's tokens or links, and prunes are owed: they are run now -- the
-        // collector gives the utterance its old chunks back -- and the frame, which was not
-        // committed, starts again from the arena.
-        if ((r & (KD_UTT_ARENA_FULL | KD_UTT_LINKS_FULL)) != 0 && first_owed() <= frame) {
+        // No room for this frame's tokens or links in a pool that is not to grow, and prunes are
+        // owed: they are run now -- the collector gives the utterance its old chunks back -- and
+        // the frame, which was not committed, starts again from the arena.  (A pool that may grow:
+        // the utterance stops here and the host grows it, as ever.)
+        if ((((r & KD_UTT_ARENA_FULL) != 0 && c.P().lat.gc_tokens != 0) ||
+             ((r & KD_UTT_LINKS_FULL) != 0 && c.P().lat.gc_links != 0)) && first_owed() <= frame) {
           gc_retry = true;  // (at the top of the loop, where the prunes are run)
           continue;
         }

@@ -100,3 +100,30 @@ def test_owed_prunes_are_the_garbage_collection_of_pools_that_may_not_grow(oracl
     assert gl.arc_set() == cl.arc_set() and gl.state_set() == cl.state_set()
     assert st["tokens_out"] > (1 << 16)  # (more tokens than the pool holds went through it)
     assert lb.capacity()["grow_events"] == 0
+
+
+def test_a_pool_at_its_budget_is_collected_not_grown(oracle, monkeypatch):
+    """Pools may grow here, but the batch's budget (KD_GC_TOKENS / KD_GC_LINKS records; default
+    2^29 / 2^30) is what they start with: a pool at its budget is garbage-collected by the owed
+    prunes instead of grown.  Same decode as above, same lattice, prunes paid; without the budget
+    the same pools simply grow and no prune is ever paid."""
+    g = synth.ctc_topo(100)
+    G, OG = cabi.Graph(g), oracle.Graph(g)
+    T, V = 1500, 100
+    lp = synth.make_logprobs(T, V, 77, peak=7.0)
+    opts = dict(beam=8.0, lattice_beam=4.0, min_active=0)
+    kw = dict(arena_tokens=1 << 16, arena_links=1 << 18, max_frames=T)
+    can = oracle.CanonLatticeDecoder(OG, **opts)
+    can.decode(lp)
+    cl = can.get_raw_lattice()
+    grown = cabi.LatticeBatch(G, max_batch=1, prune_interval=25, **kw, **opts)
+    grown.decode_host([lp])
+    assert int(grown.stats()[0, PRUNES]) == 0 and grown.capacity()["grow_events"] > 0
+    monkeypatch.setenv("KD_GC_TOKENS", str(1 << 16))
+    monkeypatch.setenv("KD_GC_LINKS", str(1 << 18))
+    kept = cabi.LatticeBatch(G, max_batch=1, prune_interval=25, **kw, **opts)
+    kept.decode_host([lp])
+    assert int(kept.stats()[0, PRUNES]) > 0 and kept.capacity()["grow_events"] == 0
+    for lb in (grown, kept):
+        gl = lb.raw_lattices()[0]
+        assert gl.arc_set() == cl.arc_set() and gl.state_set() == cl.state_set()

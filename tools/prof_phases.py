@@ -40,6 +40,8 @@ def run(kind, B=None):
     opts = dict(wl["opts"])
     if os.environ.get("KD_PRUNE_INTERVAL"):
         opts["prune_interval"] = int(os.environ["KD_PRUNE_INTERVAL"])
+    if os.environ.get("KD_MIN_ACTIVE"):  # (200: LatticeFasterDecoderConfig's default)
+        opts["min_active"] = int(os.environ["KD_MIN_ACTIVE"])
     bt = cls(G, max_batch=B, max_frames=T, **opts)
     for _ in range(2):
         bt.decode_device([dev[i].data_ptr() for i in range(B)], [T] * B, V)
