@@ -65,6 +65,7 @@ def test_a_plain_decode_owes_its_prunes_and_never_pays(oracle):
     assert out[0][0] == out[1][0]
     assert out[0][1] == B * ((T - 1) // 10) and out[1][1] == 0
     lats = cabi.LatticeBatch(G, max_batch=B, **opts)
+    lats.set_lazy_prune(1)
     lats.decode_host(lps)
     for i in (0, 3, 7):
         can = oracle.CanonLatticeDecoder(OG, beam=11.0, lattice_beam=5.0, min_active=0)
@@ -117,11 +118,13 @@ def test_a_pool_at_its_budget_is_collected_not_grown(oracle, monkeypatch):
     can.decode(lp)
     cl = can.get_raw_lattice()
     grown = cabi.LatticeBatch(G, max_batch=1, prune_interval=25, **kw, **opts)
+    grown.set_lazy_prune(1)
     grown.decode_host([lp])
     assert int(grown.stats()[0, PRUNES]) == 0 and grown.capacity()["grow_events"] > 0
     monkeypatch.setenv("KD_GC_TOKENS", str(1 << 16))
     monkeypatch.setenv("KD_GC_LINKS", str(1 << 18))
     kept = cabi.LatticeBatch(G, max_batch=1, prune_interval=25, **kw, **opts)
+    kept.set_lazy_prune(1)
     kept.decode_host([lp])
     assert int(kept.stats()[0, PRUNES]) > 0 and kept.capacity()["grow_events"] == 0
     for lb in (grown, kept):
