@@ -3,7 +3,10 @@
 Every profiles/rNN_* file that carries a `library_sha256` (written on the GPU box by
 tools/profile_round.sh, profile_large.sh, pmc_counters.sh) must name the library now in the
 tree; tools/final_check.sh refuses to finish otherwise (round 5's
-counters were of the build before its last kernel change)."""
+counters were of the build before its last kernel change).
+(The build is reproducible where it stands: `make` in a clean checkout at the same tree path --
+/root/repo -- gives the same bytes, hence the same hash; at another path hipcc's per-file unit
+ids, which are made from the source paths, differ in ~600 bytes of symbol names.)"""
 import glob, hashlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
