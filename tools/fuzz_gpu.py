@@ -62,7 +62,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     t_end = time.time() + budget
-    n_cases = n_lat = n_1b = n_bad = n_split = n_hand = 0
+    n_cases = n_lat = n_1b = n_bad = n_split = n_hand = n_full = n_gc = n_paid = 0
     keep_going = os.environ.get("KD_FUZZ_KEEP_GOING") == "1"  # (diagnosis: count mismatches, do not stop)
     while time.time() < t_end:
         g, lex, V = graph(rng)
@@ -116,16 +116,41 @@ def main():
             opts = dict(beam=beam, lattice_beam=lbeam, max_active=ma, min_active=mi)
             if small:
                 cap["arena_links"] = int(rng.integers(256, 4096))
-            lb = cabi.LatticeBatch(G, max_batch=B, prune_interval=pi, **opts, **cap)
+            # pools that are not to grow (small cases): `no_grow`, or a memory budget equal to what
+            # they start with (KD_GC_TOKENS / KD_GC_LINKS, read when the batch is created) -- the
+            # owed prunes are then the garbage collection, paid under pool pressure or by the frame
+            # that finds no room; a decode that does not fit even so may end in "pool full"
+            gc = int(rng.integers(0, 4)) if small else 0  # 0, 1: pools grow; 2: no_grow; 3: budget
+            if gc == 2:  # (nothing grows then: the frame index is sized for the utterance)
+                cap["no_grow"] = 1
+                cap["max_frames"] = T
+            if gc == 3:
+                os.environ["KD_GC_TOKENS"] = str(cap["arena_tokens"])
+                os.environ["KD_GC_LINKS"] = str(cap["arena_links"])
+            tag["gc"] = gc
+            try:
+                lb = cabi.LatticeBatch(G, max_batch=B, prune_interval=pi, **opts, **cap)
+            finally:
+                os.environ.pop("KD_GC_TOKENS", None)
+                os.environ.pop("KD_GC_LINKS", None)
             deal(lb)
             lb.set_lazy_prune(lazy)
-            if one_launch:
-                lb.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V)
-            else:
-                lb.init_decoding(B)
-                for _ in range(0, T, chunk):
-                    lb.advance_host(lps, max_num_frames=chunk)
-                lb.finalize_decoding()
+            try:
+                if one_launch:
+                    lb.decode_device([d.data_ptr() for d in dev], [lp.shape[0] for lp in lps], V)
+                else:
+                    lb.init_decoding(B)
+                    for _ in range(0, T, chunk):
+                        lb.advance_host(lps, max_num_frames=chunk)
+                    lb.finalize_decoding()
+            except RuntimeError as e:
+                if gc != 2 or "full" not in str(e):  # (token / link pool, or the tables of a heavy case)
+                    raise
+                n_full += 1
+                n_cases += 1
+                continue
+            n_gc += int(gc >= 2)
+            n_paid += int(gc >= 2 and lazy and int(lb.stats()[:, cabi.STAT_NAMES.index("prunes")].sum()) > 0)
             lats, frc = lb.raw_lattices(), lb.final_relative_cost()
             n_hand += int(lb.stats()[:, cabi.STAT_NAMES.index("handovers")].sum())
             for i, lp in enumerate(lps):
@@ -174,7 +199,8 @@ def main():
         print(f"fuzz FAILED: {n_split} cases dealt out over two kinds of workgroups and not one hand-over")
         sys.exit(1)
     print(f"fuzz ok: {n_cases} cases ({n_lat} lattice, {n_1b} 1-best; {n_split} over two kinds of "
-          f"workgroups, {n_hand} hand-overs) in {budget:.0f} s")
+          f"workgroups, {n_hand} hand-overs; {n_gc} in pools not to grow of which {n_paid} paid owed prunes, "
+          f"{n_full} more ended in 'pool full') in {budget:.0f} s")
 
 
 if __name__ == "__main__":
